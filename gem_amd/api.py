@@ -1,0 +1,392 @@
+"""Host-side mirror of the reference's interface for the hot path, on top of the C ABI.
+
+The reference's callers are ElevationMapping::processpoints / processmapcells / updateMapLocation
+(elevation_mapping/src/ElevationMapping.cpp:254-300, 1001-1044), SensorProcessorBase::process /
+GPUPointCloudprocess / readcomputerparam (src/sensor_processors/SensorProcessorBase.cpp:66-94,
+126-211, 270-290) and RobotMotionMapUpdater::update (src/RobotMotionMapUpdater.cpp:42-90).
+The classes below keep those names and argument meanings so the parity tests read like the
+reference's call sites; the C++ twin for the unmodified ROS node is include/gem/gem.hpp.
+
+All compute happens in libgem_hip.so on the GPU; there is no CPU path here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+
+# GridMap layer names of the reference (ElevationMap.cpp:43-44) -> device layers (gpu_process.cu:20-28)
+LAYER_BY_NAME = {
+    "elevation": _lib.LAYER_ELEVATION, "variance": _lib.LAYER_VARIANCE, "intensity": _lib.LAYER_INTENSITY,
+    "traver": _lib.LAYER_TRAVER, "lowest_scan_point": _lib.LAYER_LOWEST,
+    "color_r": _lib.LAYER_COLOR_R, "color_g": _lib.LAYER_COLOR_G, "color_b": _lib.LAYER_COLOR_B,
+}
+_INT_LAYERS = {_lib.LAYER_COLOR_R, _lib.LAYER_COLOR_G, _lib.LAYER_COLOR_B}
+
+
+class GemError(RuntimeError):
+    pass
+
+
+def _is_device_tensor(x) -> bool:
+    return hasattr(x, "data_ptr") and getattr(x, "is_cuda", False)
+
+
+def _host_ptr(a: Optional[np.ndarray], dtype, n: Optional[int] = None):
+    """contiguous numpy array of `dtype` -> (keepalive, void*)"""
+    if a is None:
+        return None, None
+    arr = np.ascontiguousarray(a, dtype=dtype)
+    if n is not None and arr.size != n:
+        raise ValueError(f"expected {n} elements, got {arr.size}")
+    return arr, arr.ctypes.data_as(C.c_void_p)
+
+
+def skew(v) -> np.ndarray:
+    """kindr::getSkewMatrixFromVector (same matrix as gpu_process.cu:302-307)."""
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]], dtype=np.float64)
+
+
+@dataclass
+class SensorModel:
+    """sensor_processor/* parameters (config/sensor_processors/*.yaml)."""
+    kind: int = _lib.MODEL_LASER
+    params: Sequence[float] = (0.018, 0.0006, 0.0015)       # velodyne.yaml: min_radius, beam_angle, beam_constant
+    ignore_points_above: float = float("inf")               # SensorProcessorBase.cpp:61
+    ignore_points_below: float = float("-inf")              # SensorProcessorBase.cpp:62
+    original_width: int = 0
+
+    @staticmethod
+    def velodyne() -> "SensorModel":                         # velodyne.yaml:4-9
+        return SensorModel(_lib.MODEL_LASER, (0.018, 0.0006, 0.0015), 0.8, -5.0)
+
+    @staticmethod
+    def realsense_d435() -> "SensorModel":                   # realsense_d435.yaml:4-11
+        return SensorModel(_lib.MODEL_STRUCTURED_LIGHT, (0.000611, 0.003587, 0.3515, 0.0, 1.0, 0.01576))
+
+    @staticmethod
+    def perfect() -> "SensorModel":
+        return SensorModel(_lib.MODEL_PERFECT, ())
+
+
+@dataclass
+class RejectFilter:
+    """The hard-coded sensor-frame filter of gpu_process.cu:393; reference() reproduces it."""
+    enabled: bool = False
+    box_x: float = 1.5
+    box_y: float = 1.5
+    band_y: float = 1.0
+    plane_y: float = 0.0
+
+    @staticmethod
+    def reference() -> "RejectFilter":
+        return RejectFilter(True)
+
+
+@dataclass
+class Frame:
+    """Per-frame constants as plain numpy data (what GPUPointCloudprocess derives, SPB.cpp:171-208)."""
+    T: np.ndarray                                            # 4x4 float32, sensor -> map
+    lower: float
+    upper: float
+    model: SensorModel
+    sensor_jacobian: np.ndarray
+    rotation_variance: np.ndarray = field(default_factory=lambda: np.zeros((3, 3), np.float32))
+    C_SB_T: np.ndarray = field(default_factory=lambda: np.eye(3, dtype=np.float32))
+    P_mul_C_BM_T: np.ndarray = field(default_factory=lambda: np.array([0, 0, 1], np.float32))
+    B_r_BS_skew: np.ndarray = field(default_factory=lambda: np.zeros((3, 3), np.float32))
+    filter: RejectFilter = field(default_factory=RejectFilter)
+
+    def to_struct(self, cls=_lib.FrameParams):
+        """Fill a ctypes struct with the gem_frame_params field layout (also used, with the oracle's
+        own struct class, by the tests)."""
+        p = cls()
+        p.T[:] = np.asarray(self.T, np.float32).reshape(16).tolist()
+        p.lower, p.upper = float(self.lower), float(self.upper)
+        p.sensor_model = int(self.model.kind)
+        sp = list(self.model.params) + [0.0] * (8 - len(self.model.params))
+        if hasattr(p, "sensor_params"):
+            p.sensor_params[:] = sp
+        else:
+            p.sp[:] = sp
+        p.sensor_jacobian[:] = np.asarray(self.sensor_jacobian, np.float32).reshape(3).tolist()
+        p.rotation_variance[:] = np.asarray(self.rotation_variance, np.float32).reshape(9).tolist()
+        p.C_SB_T[:] = np.asarray(self.C_SB_T, np.float32).reshape(9).tolist()
+        p.P_mul_C_BM_T[:] = np.asarray(self.P_mul_C_BM_T, np.float32).reshape(3).tolist()
+        p.B_r_BS_skew[:] = np.asarray(self.B_r_BS_skew, np.float32).reshape(9).tolist()
+        if hasattr(p, "filter"):
+            p.filter.enabled = int(self.filter.enabled)
+            p.filter.box_x, p.filter.box_y = self.filter.box_x, self.filter.box_y
+            p.filter.band_y, p.filter.plane_y = self.filter.band_y, self.filter.plane_y
+        else:
+            p.filter_on = int(self.filter.enabled)
+            p.filter_box_x, p.filter_box_y = self.filter.box_x, self.filter.box_y
+            p.filter_band_y, p.filter_plane_y = self.filter.band_y, self.filter.plane_y
+        p.original_width = int(self.model.original_width)
+        return p
+
+
+class SensorProcessor:
+    """SensorProcessorBase (SensorProcessorBase.hpp:52-180) for the GPU path.
+
+    update_transformations() takes what the three TF lookups of SPB.cpp:97-124 return:
+    T_map_sensor (map <- sensor), T_base_sensor (base <- sensor), T_map_base (map <- base), 4x4 doubles.
+    """
+
+    def __init__(self, model: SensorModel, reject_filter: Optional[RejectFilter] = None,
+                 rotation_variance: Optional[np.ndarray] = None):
+        self.model = model
+        self.filter = reject_filter or RejectFilter()
+        self.rotation_variance = np.zeros((3, 3), np.float32) if rotation_variance is None else np.asarray(rotation_variance, np.float32)
+        self.update_transformations(np.eye(4), np.eye(4), np.eye(4))
+
+    def update_transformations(self, T_map_sensor, T_base_sensor, T_map_base) -> None:
+        self.T_map_sensor = np.asarray(T_map_sensor, np.float64)
+        Tbs = np.asarray(T_base_sensor, np.float64)
+        Tmb = np.asarray(T_map_base, np.float64)
+        self.rotation_base_to_sensor = Tbs[:3, :3].copy()           # SPB.cpp:110
+        self.translation_base_to_sensor = Tbs[:3, 3].copy()         # SPB.cpp:111
+        self.rotation_map_to_base = Tmb[:3, :3].copy()              # SPB.cpp:116
+        self.translation_map_to_base = Tmb[:3, 3].copy()            # SPB.cpp:117
+
+    def frame(self) -> Frame:
+        """readcomputerparam (SPB.cpp:270-290) + the casts of GPUPointCloudprocess (SPB.cpp:171-184)."""
+        C_BM_T = self.rotation_map_to_base.T
+        C_SB_T = self.rotation_base_to_sensor.T
+        sensor_jacobian = (C_BM_T @ C_SB_T).astype(np.float32)[2, :]          # :275 e_z^T (double product, float cast)
+        C_BM_T_f = C_BM_T.astype(np.float32)
+        P_mul = C_BM_T_f[2, :]                                                 # :281-282
+        z_base = float(self.translation_map_to_base[2])
+        return Frame(
+            T=self.T_map_sensor.astype(np.float32),                           # :175-179
+            lower=z_base + self.model.ignore_points_below,                    # :183
+            upper=z_base + self.model.ignore_points_above,                    # :184
+            model=self.model,
+            sensor_jacobian=sensor_jacobian,
+            rotation_variance=self.rotation_variance,
+            C_SB_T=C_SB_T.astype(np.float32),                                 # :283
+            P_mul_C_BM_T=P_mul,
+            B_r_BS_skew=skew(self.translation_base_to_sensor.astype(np.float32)).astype(np.float32),   # :284
+            filter=self.filter,
+        )
+
+    def process(self, elevation_map: "ElevationMap", x, y, z, orig_index=None):
+        """SensorProcessorBase::process -> Process_points (SPB.cpp:66-94, 208): returns the
+        per-point arrays the reference hands to Fuse."""
+        return elevation_map.process_points(self.frame(), x, y, z, orig_index)
+
+
+class ElevationMap:
+    """The robot-centric map (device-resident; one libgem_hip handle).
+
+    The reference's ElevationMap::add/fuse were deleted from the tree; the map now lives in
+    gpu_process.cu's globals and is driven through Init_GPU_elevationmap / Move / Process_points /
+    Fuse / Mapvar_update.  This class exposes exactly those operations plus the fused add().
+    """
+
+    def __init__(self, length: int, resolution: float, mahalanobis_threshold: float = 5.0,
+                 variance_floor: float = 1e-4, strip: tuple = (0, 0), device: int = -1):
+        self._lib = _lib.load()
+        cfg = _lib.MapConfig(int(length), float(resolution), float(mahalanobis_threshold), float(variance_floor),
+                             0.7, int(strip[0]), int(strip[1]), int(device))
+        h = C.c_void_p()
+        rc = self._lib.gem_create(C.byref(cfg), C.byref(h))
+        if rc != _lib.GEM_OK:
+            raise GemError(f"gem_create failed ({rc}): {self._lib.gem_last_error(None).decode()}")
+        self._h = h
+        self.length = int(length)
+        self.resolution = float(resolution)
+
+    # -- plumbing ------------------------------------------------------------------------------
+    def _check(self, rc: int, what: str) -> None:
+        if rc != _lib.GEM_OK:
+            raise GemError(f"{what} failed ({rc}): {self._lib.gem_last_error(self._h).decode()}")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.gem_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream: Optional[int]) -> None:
+        self._check(self._lib.gem_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None), "gem_set_stream")
+
+    def synchronize(self) -> None:
+        self._check(self._lib.gem_synchronize(self._h), "gem_synchronize")
+
+    # -- Move (ElevationMapping::updateMapLocation -> Move, EMg.cpp:1032) ------------------------
+    def move(self, position):
+        pos = (C.c_float * 3)(*[float(v) for v in position])
+        c = (C.c_float * 2)(); s = (C.c_int * 2)(); a = (C.c_float * 2)()
+        self._check(self._lib.gem_move(self._h, pos, c, s, a), "gem_move")
+        return np.array(c[:], np.float32), np.array(s[:], np.int32), np.array(a[:], np.float32)
+
+    def pose(self):
+        c = (C.c_float * 2)(); s = (C.c_int * 2)()
+        self._check(self._lib.gem_get_pose(self._h, c, s), "gem_get_pose")
+        return np.array(c[:], np.float32), np.array(s[:], np.int32)
+
+    # -- Process_points (SPB.cpp:208) ---------------------------------------------------------------
+    def process_points(self, frame: Frame, x, y, z, orig_index=None, write_back_xyz: bool = False):
+        n = int(np.asarray(x).size)
+        xa = np.array(x, np.float32, copy=True).reshape(-1); ya = np.array(y, np.float32, copy=True).reshape(-1)
+        za = np.array(z, np.float32, copy=True).reshape(-1)
+        ok, okp = _host_ptr(orig_index, np.int32, n)
+        out = {"index": np.empty(n, np.int32), "var": np.empty(n, np.float32), "x_ts": np.empty(n, np.float32),
+               "y_ts": np.empty(n, np.float32), "height": np.empty(n, np.float32)}
+        p = frame.to_struct()
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._check(self._lib.gem_process_points(self._h, C.byref(p), n, vp(xa), vp(ya), vp(za), okp, int(write_back_xyz),
+                                                 vp(out["index"]), vp(out["var"]), vp(out["x_ts"]), vp(out["y_ts"]),
+                                                 vp(out["height"])), "gem_process_points")
+        if write_back_xyz:
+            out["x"], out["y"], out["z"] = xa, ya, za
+        return out
+
+    # -- Fuse (EMg.cpp:280) --------------------------------------------------------------------------
+    def fuse(self, index, height, var, R=None, G=None, B=None, intensity=None) -> None:
+        n = int(np.asarray(index).size)
+        ki, pi = _host_ptr(index, np.int32, n); kh, ph = _host_ptr(height, np.float32, n); kv, pv = _host_ptr(var, np.float32, n)
+        kr, pr = _host_ptr(R, np.int32, n); kg, pg = _host_ptr(G, np.int32, n); kb, pb = _host_ptr(B, np.int32, n)
+        kI, pI = _host_ptr(intensity, np.float32, n)
+        self._check(self._lib.gem_fuse(self._h, n, pi, pr, pg, pb, pI, ph, pv), "gem_fuse")
+
+    # -- the fused path: process + Fuse in one call (ElevationMapping::processpoints, EMg.cpp:254-283) --
+    def add(self, frame: Frame, xyzi, rgb=None, orig_index=None) -> None:
+        p = frame.to_struct()
+        if _is_device_tensor(xyzi):
+            n = int(xyzi.shape[0])
+            if not xyzi.is_contiguous() or xyzi.element_size() != 4 or xyzi.numel() != 4 * n:
+                raise ValueError("xyzi must be a contiguous float32 [N,4] device tensor")
+            dp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+            self._check(self._lib.gem_add_device(self._h, C.byref(p), n, dp(xyzi), dp(rgb), dp(orig_index)), "gem_add_device")
+            return
+        a = np.ascontiguousarray(xyzi, np.float32).reshape(-1, 4)
+        n = a.shape[0]
+        kr, pr = _host_ptr(rgb, np.uint32, n); ko, po = _host_ptr(orig_index, np.int32, n)
+        self._check(self._lib.gem_add(self._h, C.byref(p), n, a.ctypes.data_as(C.c_void_p), pr, po), "gem_add")
+
+    def add_batch(self, frames: Sequence[Frame], xyzi_device, offsets, var_updates=None) -> None:
+        """BASELINE config 4: for each sweep s: Mapvar_update(var_updates[s]); add(frames[s], cloud s)."""
+        ns = len(frames)
+        arr = (_lib.FrameParams * ns)(*[f.to_struct() for f in frames])
+        off = (C.c_longlong * (ns + 1))(*[int(v) for v in offsets])
+        vu = (C.c_float * ns)(*[float(v) for v in var_updates]) if var_updates is not None else None
+        if not _is_device_tensor(xyzi_device):
+            raise ValueError("add_batch takes a device-resident float32 [N,4] tensor")
+        self._check(self._lib.gem_add_batch_device(self._h, ns, arr, C.c_void_p(xyzi_device.data_ptr()), off, vu),
+                    "gem_add_batch_device")
+
+    # -- Mapvar_update (RMU.cpp:81) ------------------------------------------------------------------
+    def mapvar_update(self, var_update: float) -> None:
+        self._check(self._lib.gem_mapvar_update(self._h, float(var_update)), "gem_mapvar_update")
+
+    # -- layers ----------------------------------------------------------------------------------------
+    def layer(self, name_or_id, layout: int = _lib.LAYOUT_STORAGE_ROWMAJOR) -> np.ndarray:
+        lid = LAYER_BY_NAME[name_or_id] if isinstance(name_or_id, str) else int(name_or_id)
+        is_int = lid in _INT_LAYERS and layout == _lib.LAYOUT_STORAGE_ROWMAJOR
+        out = np.empty((self.length, self.length), np.int32 if is_int else np.float32)
+        self._check(self._lib.gem_get_layer(self._h, lid, layout, out.ctypes.data_as(C.c_void_p)), "gem_get_layer")
+        if layout == _lib.LAYOUT_GRIDMAP_COLMAJOR_NAN:
+            return out.T          # buffer holds column-major data: view it as [row, col]
+        return out
+
+    def set_layer(self, name_or_id, values) -> None:
+        lid = LAYER_BY_NAME[name_or_id] if isinstance(name_or_id, str) else int(name_or_id)
+        a = np.ascontiguousarray(values, np.int32 if lid in _INT_LAYERS else np.float32)
+        if a.size != self.length * self.length:
+            raise ValueError("layer size mismatch")
+        self._check(self._lib.gem_set_layer(self._h, lid, a.ctypes.data_as(C.c_void_p)), "gem_set_layer")
+
+    def layer_device_ptr(self, name_or_id) -> int:
+        lid = LAYER_BY_NAME[name_or_id] if isinstance(name_or_id, str) else int(name_or_id)
+        out = C.c_void_p()
+        self._check(self._lib.gem_layer_device_ptr(self._h, lid, C.byref(out)), "gem_layer_device_ptr")
+        return int(out.value)
+
+    # -- stats --------------------------------------------------------------------------------------------
+    def set_timing(self, on: bool) -> None:
+        self._check(self._lib.gem_set_timing(self._h, int(on)), "gem_set_timing")
+
+    def set_counting(self, on: bool) -> None:
+        self._check(self._lib.gem_set_counting(self._h, int(on)), "gem_set_counting")
+
+    def stats(self, reset: bool = False) -> dict:
+        s = _lib.Stats()
+        self._check(self._lib.gem_get_stats(self._h, C.byref(s), int(reset)), "gem_get_stats")
+        return {k: getattr(s, k) for k, _ in _lib.Stats._fields_}
+
+    # -- multi-GPU ------------------------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = _lib.load().gem_comm_unique_id(buf)
+        if rc != _lib.GEM_OK:
+            raise GemError(f"gem_comm_unique_id failed ({rc})")
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, nranks: int, rank: int) -> None:
+        buf = C.create_string_buffer(unique_id, 128)
+        self._check(self._lib.gem_comm_init(self._h, buf, int(nranks), int(rank)), "gem_comm_init")
+
+    def allgather_layers(self, with_attributes: bool = False) -> None:
+        self._check(self._lib.gem_allgather_layers(self._h, int(with_attributes)), "gem_allgather_layers")
+
+
+class RobotMotionMapUpdater:
+    """RobotMotionMapUpdater (RobotMotionMapUpdater.cpp:42-145): pose covariance -> scalar variance
+    increment -> Mapvar_update.  Host-side doubles, exactly one float reaches the device."""
+
+    def __init__(self, covariance_scale: float = 1.0):
+        self.covariance_scale = float(covariance_scale)                 # RMU.cpp:25,38
+        self.previous_reduced_covariance = np.zeros((4, 4))            # RMU.cpp:27
+        self.previous_position = np.zeros(3)
+        self.previous_rotation = np.eye(3)
+
+    @staticmethod
+    def _yaw_pitch(R):
+        return np.arctan2(R[1, 0], R[0, 0]), np.arctan2(-R[2, 0], np.hypot(R[0, 0], R[1, 0]))
+
+    @staticmethod
+    def _rotation_vector_z(R):
+        c = min(1.0, max(-1.0, 0.5 * (np.trace(R) - 1.0)))
+        angle = np.arccos(c)
+        wz = 0.5 * (R[1, 0] - R[0, 1])
+        return wz if angle < 1e-12 else wz * angle / np.sin(angle)
+
+    def compute(self, position, R_IB, covariance6x6, map_rotation=None) -> float:
+        """Returns var_update (the float handed to Mapvar_update, RMU.cpp:80) and advances the state."""
+        R = np.asarray(R_IB, np.float64); p = np.asarray(position, np.float64)
+        cov = self.covariance_scale * np.asarray(covariance6x6, np.float64)
+        Rm = np.eye(3) if map_rotation is None else np.asarray(map_rotation, np.float64)
+        yaw, pitch = self._yaw_pitch(R)
+        J = np.zeros((4, 6)); J[:3, :3] = np.eye(3)
+        J[3, 3:] = [np.cos(yaw) * np.tan(pitch), np.sin(yaw) * np.tan(pitch), 1.0]
+        reduced = J @ cov @ J.T                                         # RMU.cpp:107
+        rz = self._rotation_vector_z(R)
+        Rt = np.array([[np.cos(rz), -np.sin(rz), 0], [np.sin(rz), np.cos(rz), 0], [0, 0, 1.0]])
+        v = self.previous_rotation.T @ (p - self.previous_position)    # RMU.cpp:121-123
+        F = np.eye(4); F[:3, 3] = skew([0, 0, 1.0]) @ Rt @ v           # RMU.cpp:126-129
+        G = np.zeros((4, 4)); G[3, 3] = 1.0; Gt = G.copy()
+        G[:3, :3] = Rt.T; Gt[:3, :3] = Rt                              # RMU.cpp:132-137
+        relative = G @ (reduced - F @ self.previous_reduced_covariance @ F.T) @ Gt   # RMU.cpp:140-142
+        R_BM = R.T @ Rm                                                # RMU.cpp:62-63
+        Jr = -R_BM.T                                                   # RMU.cpp:66
+        upd = np.float32((Jr @ relative[:3, :3] @ Jr.T)[2, 2])         # RMU.cpp:69,80
+        self.previous_reduced_covariance = reduced
+        self.previous_position, self.previous_rotation = p.copy(), R.copy()
+        return float(upd)
+
+    def update(self, elevation_map: ElevationMap, position, R_IB, covariance6x6, map_rotation=None) -> float:
+        u = self.compute(position, R_IB, covariance6x6, map_rotation)
+        elevation_map.mapvar_update(u)                                  # RMU.cpp:81
+        return u

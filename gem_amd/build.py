@@ -1,0 +1,61 @@
+"""Builds libgem_hip.so (gfx950) in-tree with hipcc.
+
+The shared library is the product: hand-written HIP kernels + the C ABI of include/gem_hip.h.
+It is built into gem_amd/lib/ so that it travels with the source tree (no JIT cache).
+hipcc cross-compiles for gfx950 without a GPU present.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+CSRC = ROOT / "csrc"
+LIBDIR = ROOT / "lib"
+LIB = LIBDIR / "libgem_hip.so"
+
+SOURCES = [CSRC / "gem_kernels.hip", CSRC / "gem_capi.cpp"]
+HEADERS = [CSRC / "gem_device.hpp", CSRC / "gem_kernels.hpp", ROOT.parent / "include" / "gem_hip.h"]
+
+# -ffp-contract=off: cell indices must be bit-exact with the reference arithmetic, so no product+sum
+# may be contracted into an FMA (see csrc/gem_device.hpp).  hipcc's default IEEE divide/sqrt stay on.
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+    "-Wno-unused-value",
+]
+
+
+def hipcc_path() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm to build libgem_hip.so)")
+
+
+def is_stale() -> bool:
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    return any(p.stat().st_mtime > t for p in SOURCES + HEADERS)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile libgem_hip.so if missing or older than its sources.  Returns its path."""
+    if not force and not is_stale():
+        return LIB
+    LIBDIR.mkdir(exist_ok=True)
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [hipcc_path(), *FLAGS, *map(str, SOURCES), "-o", str(LIB), f"-L{rocm}/lib", "-lrccl",
+           f"-Wl,-rpath,{rocm}/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

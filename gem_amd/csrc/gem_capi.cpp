@@ -1,0 +1,744 @@
+// gem_capi.cpp -- the C ABI of libgem_hip.so (see include/gem_hip.h): handle, persistent device
+// arenas, host-side Move logic and launch orchestration for the gfx950 kernels.
+//
+// The reference keeps the map as hidden process-global __device__ state and does 15 cudaMalloc +
+// 15 cudaFree + 15 cudaMemcpy per frame on this path (gpu_process.cu:1096-1141, 1165-1192).
+// Here a handle owns persistent arenas that only ever grow, everything is enqueued on one HIP
+// stream, and nothing returns to the host unless the caller asks for it.
+#include "../../include/gem_hip.h"
+#include "gem_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace gem;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Arena {
+    void*  p = nullptr;
+    size_t cap = 0;
+};
+
+struct EventPair { hipEvent_t a, b; int kind; };
+
+} // namespace
+
+struct gem_handle {
+    std::mutex  mu;
+    std::string err;
+    int         device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    gem_map_config cfg{};
+    int   L = 0, cells = 0;
+    float res = 0.f;
+    LayerPtrs layers{};
+    float center[2] = {0.f, 0.f};
+    int   start[2] = {0, 0};
+    float sensor_z = 0.f;
+    int   row0 = 0, row1 = 0;
+    int   ts = 5, tiles_per_row = 0, T = 0;
+
+    Arena stage;        // staging of host-pointer inputs / outputs
+    Arena rec, seg;     // pipeline intermediates
+    Arena tables;       // batched-call tables (frames, sweep_unit0, sweep_first, var_updates)
+    Arena scratch;      // layer export
+    unsigned long long* d_counters = nullptr;
+
+    float pending[kMaxPending] = {0, 0, 0, 0};
+    int   n_pending = 0;
+    bool  floor_dirty = true;          // some cell may hold variance < floor (init / clear / set_layer)
+
+    bool  timing = false, counting = false;
+    std::vector<EventPair> events;     // recorded, not yet folded
+    std::vector<EventPair> pool;
+    gem_stats stats{};
+    hipEvent_t copy_done = nullptr;
+
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+
+    int ipt_override = 0;
+};
+
+namespace {
+
+int fail(gem_handle* h, int code, const char* what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof(buf), "%s", what);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define GEM_HIP(h, call)                                                        \
+    do { hipError_t _e = (call); if (_e != hipSuccess) return fail(h, GEM_ERR_HIP, #call, _e); } while (0)
+
+int ensure(gem_handle* h, Arena& a, size_t bytes)
+{
+    if (bytes <= a.cap) return GEM_OK;
+    // arenas may still be in use by enqueued work
+    GEM_HIP(h, hipStreamSynchronize(h->stream));
+    if (a.p) GEM_HIP(h, hipFree(a.p));
+    a.p = nullptr; a.cap = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipMalloc(&a.p, want);
+    if (e != hipSuccess) return fail(h, GEM_ERR_NOMEM, "hipMalloc(arena)", e);
+    a.cap = want;
+    return GEM_OK;
+}
+
+void fill_frame(const gem_handle* h, const gem_frame_params* p, FrameConst& f)
+{
+    memset(&f, 0, sizeof(f));
+    if (p) {
+        for (int i = 0; i < 12; ++i) f.T[i] = p->T[i];
+        f.lower = p->lower; f.upper = p->upper;
+        for (int i = 0; i < 8; ++i) f.sp[i] = p->sensor_params[i];
+        for (int i = 0; i < 3; ++i) { f.Js[i] = p->sensor_jacobian[i]; f.P[i] = p->P_mul_C_BM_T[i]; }
+        for (int i = 0; i < 9; ++i) { f.Q[i] = p->rotation_variance[i]; f.C[i] = p->C_SB_T[i]; f.Bs[i] = p->B_r_BS_skew[i]; }
+        f.filter_on = p->filter.enabled;
+        f.fbx = p->filter.box_x; f.fby = p->filter.box_y; f.fband = p->filter.band_y; f.fplane = p->filter.plane_y;
+        f.model = p->sensor_model;
+        f.orig_width = p->original_width;
+    }
+    f.cx = h->center[0]; f.cy = h->center[1];
+    f.sx = h->start[0];  f.sy = h->start[1];
+    f.L = h->L; f.res = h->res;
+    f.row0 = h->row0; f.row1 = h->row1;
+}
+
+int choose_ipt(const gem_handle* h, long long n)
+{
+    if (h->ipt_override == 1 || h->ipt_override == 2 || h->ipt_override == 4) return h->ipt_override;
+    if (n <= 65536) return 1;
+    if (n <= 262144) return 2;
+    return 4;
+}
+
+hipEvent_t get_event(gem_handle* h)
+{
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    (void)h;
+    return e;
+}
+
+struct Timed {
+    gem_handle* h; int kind; EventPair ep{};
+    bool on;
+    Timed(gem_handle* hh, int k) : h(hh), kind(k), on(hh->timing)
+    {
+        if (!on) return;
+        if (!h->pool.empty()) { ep = h->pool.back(); h->pool.pop_back(); }
+        else { ep.a = get_event(h); ep.b = get_event(h); }
+        ep.kind = kind;
+        hipEventRecord(ep.a, h->stream);
+    }
+    ~Timed()
+    {
+        if (!on) return;
+        hipEventRecord(ep.b, h->stream);
+        h->events.push_back(ep);
+    }
+};
+
+void fold_events(gem_handle* h)
+{
+    for (auto& ep : h->events) {
+        float ms = 0.f;
+        if (hipEventSynchronize(ep.b) == hipSuccess && hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
+            if (ep.kind == 0) { h->stats.ms_bin += ms; h->stats.launches_bin++; }
+            else              { h->stats.ms_fuse += ms; h->stats.launches_fuse++; }
+        }
+        h->pool.push_back(ep);
+    }
+    h->events.clear();
+}
+
+// standalone dense pass: queued Mapvar_update increments (+ optionally the variance floor)
+int flush_pending(gem_handle* h, bool with_floor)
+{
+    if (h->n_pending == 0 && !with_floor) return GEM_OK;
+    GEM_HIP(h, launch_dense_variance(h->stream, h->layers.variance, h->cells, h->n_pending, h->pending, with_floor ? 1 : 0,
+                                     h->cfg.variance_floor));
+    h->n_pending = 0;
+    if (with_floor) h->floor_dirty = false;
+    return GEM_OK;
+}
+
+int index_to_range(int index, int L)          // gpu_process.cu:914-919
+{
+    if (index < 0) index += ((-index / L) + 1) * L;
+    return index % L;
+}
+
+// One pipeline pass over up to `n` points that are already on the device.
+struct PassInput {
+    int src = 0;                       // 0 = XYZI cloud, 1 = Fuse() arrays
+    int n_sweeps = 1;
+    long long n = 0;
+    const gem_frame_params* params = nullptr;      // [n_sweeps] (src 0)
+    const long long* offsets = nullptr;            // [n_sweeps+1] (batched)
+    const float* var_updates = nullptr;            // [n_sweeps]  (batched, host)
+    const float4* xyzi = nullptr; const uint32_t* rgb = nullptr; const int* orig = nullptr;
+    const int* f_index = nullptr; const float* f_height = nullptr; const float* f_var = nullptr;
+    const int* f_R = nullptr; const int* f_G = nullptr; const int* f_B = nullptr; const float* f_I = nullptr;
+};
+
+int run_pipeline(gem_handle* h, const PassInput& in)
+{
+    const bool batched = in.n_sweeps > 1;
+    long long max_sweep = in.n;
+    if (batched) { max_sweep = 0; for (int s = 0; s < in.n_sweeps; ++s) max_sweep = std::max(max_sweep, in.offsets[s + 1] - in.offsets[s]); }
+    const int ipt = choose_ipt(h, max_sweep);
+    const int U = 64 * ipt;
+
+    // units per sweep
+    std::vector<int> unit0(in.n_sweeps + 1, 0);
+    int bpad = 0;
+    for (int s = 0; s < in.n_sweeps; ++s) {
+        const long long cnt = batched ? in.offsets[s + 1] - in.offsets[s] : in.n;
+        const long long units = (cnt + U - 1) / U;
+        if (units > 0x3fffffff) return fail(h, GEM_ERR_INVALID, "cloud too large");
+        unit0[s + 1] = unit0[s] + (int)units;
+        bpad = std::max(bpad, (int)units);
+    }
+    const int B = unit0[in.n_sweeps];
+    const bool dense = h->n_pending > 0 || h->floor_dirty || (batched && in.var_updates != nullptr);
+
+    if (B == 0) {
+        // Fuse with zero points still runs the floor pass (gpu_process.cu:533-534)
+        if (batched && in.var_updates)
+            for (int s = 0; s < in.n_sweeps; ++s) {
+                if (h->n_pending == kMaxPending) { int rc = flush_pending(h, true); if (rc) return rc; }
+                h->pending[h->n_pending++] = in.var_updates[s];
+            }
+        return (h->n_pending || h->floor_dirty) ? flush_pending(h, true) : GEM_OK;
+    }
+    if (fuse_lds_bytes(h->ts, h->ts == 5 ? kFuseR32 : kFuseR64, bpad) > 160 * 1024)
+        return fail(h, GEM_ERR_INVALID, "too many units per sweep for one pass");
+
+    int rc;
+    if ((rc = ensure(h, h->rec, (size_t)B * U * sizeof(uint4)))) return rc;
+    if ((rc = ensure(h, h->seg, (size_t)h->T * B * sizeof(uint32_t)))) return rc;
+
+    BinArgs ba{};
+    FuseArgs fa{};
+    if (batched) {
+        // tables: frames | unit0 | first | var_updates
+        const size_t o_frames = 0;
+        const size_t o_unit0 = o_frames + sizeof(FrameConst) * in.n_sweeps;
+        const size_t o_first = (o_unit0 + sizeof(int) * (in.n_sweeps + 1) + 15) & ~(size_t)15;
+        const size_t o_var = o_first + sizeof(long long) * (in.n_sweeps + 1);
+        const size_t total = o_var + sizeof(float) * in.n_sweeps;
+        if ((rc = ensure(h, h->tables, total))) return rc;
+        std::vector<unsigned char> host(total, 0);
+        for (int s = 0; s < in.n_sweeps; ++s) fill_frame(h, &in.params[s], reinterpret_cast<FrameConst*>(host.data() + o_frames)[s]);
+        memcpy(host.data() + o_unit0, unit0.data(), sizeof(int) * (in.n_sweeps + 1));
+        memcpy(host.data() + o_first, in.offsets, sizeof(long long) * (in.n_sweeps + 1));
+        if (in.var_updates) memcpy(host.data() + o_var, in.var_updates, sizeof(float) * in.n_sweeps);
+        GEM_HIP(h, hipMemcpyAsync(h->tables.p, host.data(), total, hipMemcpyHostToDevice, h->stream));
+        GEM_HIP(h, hipStreamSynchronize(h->stream));      // `host` is a local
+        unsigned char* d = static_cast<unsigned char*>(h->tables.p);
+        ba.frames = reinterpret_cast<const FrameConst*>(d + o_frames);
+        ba.sweep_unit0 = reinterpret_cast<const int*>(d + o_unit0);
+        ba.sweep_first = reinterpret_cast<const long long*>(d + o_first);
+        fa.sweep_unit0 = ba.sweep_unit0;
+        fa.var_updates = in.var_updates ? reinterpret_cast<const float*>(d + o_var) : nullptr;
+    } else {
+        fill_frame(h, in.src == 0 ? in.params : nullptr, ba.frame0);
+    }
+    ba.n_sweeps = in.n_sweeps; ba.n = in.n;
+    ba.xyzi = in.xyzi; ba.rgb = in.rgb; ba.orig = in.orig;
+    ba.f_index = in.f_index; ba.f_height = in.f_height; ba.f_var = in.f_var;
+    ba.f_R = in.f_R; ba.f_G = in.f_G; ba.f_B = in.f_B; ba.f_I = in.f_I;
+    ba.T = h->T; ba.tiles_per_row = h->tiles_per_row; ba.B = B;
+    ba.rec = static_cast<uint4*>(h->rec.p); ba.seg = static_cast<uint32_t*>(h->seg.p);
+    ba.counters = h->counting ? h->d_counters : nullptr;
+
+    int attr = 0;
+    if (in.src == 0 && in.rgb) attr = 1;
+    if (in.src == 1 && in.f_R && in.f_G && in.f_B && in.f_I) attr = 2;
+
+    fa.rec = ba.rec; fa.seg = ba.seg; fa.B_total = B; fa.U = U; fa.n_sweeps = in.n_sweeps; fa.Bpad = bpad;
+    fa.T = h->T; fa.tiles_per_row = h->tiles_per_row; fa.L = h->L; fa.row0 = h->row0; fa.row1 = h->row1;
+    fa.mahal = h->cfg.mahalanobis_threshold; fa.var_floor = h->cfg.variance_floor;
+    fa.dense = dense ? 1 : 0;
+    fa.n_pending = h->n_pending;
+    for (int i = 0; i < kMaxPending; ++i) fa.pending[i] = h->pending[i];
+    fa.elevation = h->layers.elevation; fa.variance = h->layers.variance;
+    fa.intensity = h->layers.intensity; fa.colorR = h->layers.colorR; fa.colorG = h->layers.colorG; fa.colorB = h->layers.colorB;
+    fa.xyzi = in.xyzi; fa.rgb = in.rgb; fa.f_R = in.f_R; fa.f_G = in.f_G; fa.f_B = in.f_B; fa.f_I = in.f_I;
+    fa.counters = ba.counters;
+
+    if (h->counting) GEM_HIP(h, hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
+    { Timed t(h, 0); GEM_HIP(h, launch_bin(h->stream, ba, ipt, in.src, h->ts)); }
+    { Timed t(h, 1); GEM_HIP(h, launch_fuse(h->stream, fa, h->ts, attr)); }
+    h->n_pending = 0;
+    h->floor_dirty = false;
+    h->stats.points_in = in.n;
+    return GEM_OK;
+}
+
+} // namespace
+
+// ================================================================================================
+extern "C" {
+
+int gem_abi_version(void) { return GEM_ABI_VERSION; }
+
+const char* gem_last_error(const gem_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int gem_create(const gem_map_config* cfg, gem_handle** out)
+{
+    if (!cfg || !out) return fail(nullptr, GEM_ERR_INVALID, "gem_create: null argument");
+    *out = nullptr;
+    if (cfg->length <= 0 || cfg->length > 32768 || !(cfg->resolution > 0.f))
+        return fail(nullptr, GEM_ERR_INVALID, "gem_create: bad length / resolution");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, GEM_ERR_NO_DEVICE, "gem_create: no HIP device (libgem_hip has no CPU fallback)", e);
+    int dev = cfg->device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= ndev) return fail(nullptr, GEM_ERR_INVALID, "gem_create: device ordinal out of range");
+    if ((e = hipSetDevice(dev)) != hipSuccess) return fail(nullptr, GEM_ERR_NO_DEVICE, "hipSetDevice", e);
+
+    gem_handle* h = new gem_handle();
+    h->device = dev;
+    h->cfg = *cfg;
+    if (!(h->cfg.variance_floor > 0.f)) h->cfg.variance_floor = 0.0001f;          // gpu_process.cu:500
+    if (!(h->cfg.mahalanobis_threshold > 0.f)) h->cfg.mahalanobis_threshold = 5.f; // gpu_process.cu:504
+    h->L = cfg->length; h->cells = cfg->length * cfg->length; h->res = cfg->resolution;
+    h->row0 = 0; h->row1 = h->L;
+    if (cfg->strip_rows > 0) {
+        if (cfg->strip_row0 < 0 || cfg->strip_row0 + cfg->strip_rows > h->L) { delete h; return fail(nullptr, GEM_ERR_INVALID, "gem_create: bad strip"); }
+        h->row0 = cfg->strip_row0; h->row1 = cfg->strip_row0 + cfg->strip_rows;
+    }
+    h->ts = h->L <= 1024 ? 5 : 6;
+    if (const char* s = getenv("GEM_TILE_SHIFT")) { int v = atoi(s); if (v == 5 || v == 6) h->ts = v; }
+    if (const char* s = getenv("GEM_IPT")) h->ipt_override = atoi(s);
+    const int te = 1 << h->ts;
+    h->tiles_per_row = (h->L + te - 1) / te;
+    h->T = h->tiles_per_row * h->tiles_per_row;
+
+    auto bail = [&](const char* what, hipError_t err) { int rc = fail(nullptr, GEM_ERR_HIP, what, err); gem_destroy(h); return rc; };
+    if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    h->stream = h->own_stream;
+    if ((e = hipEventCreateWithFlags(&h->copy_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    // one allocation for the 8 layers (gpu_process.cu:954-961 uses 8 cudaMalloc)
+    void* base = nullptr;
+    const size_t layer_bytes = ((size_t)h->cells * 4 + 255) & ~(size_t)255;
+    if ((e = hipMalloc(&base, layer_bytes * GEM_LAYER_COUNT)) != hipSuccess) return bail("hipMalloc(layers)", e);
+    unsigned char* b = static_cast<unsigned char*>(base);
+    h->layers.elevation = reinterpret_cast<float*>(b + layer_bytes * GEM_LAYER_ELEVATION);
+    h->layers.variance  = reinterpret_cast<float*>(b + layer_bytes * GEM_LAYER_VARIANCE);
+    h->layers.intensity = reinterpret_cast<float*>(b + layer_bytes * GEM_LAYER_INTENSITY);
+    h->layers.traver    = reinterpret_cast<float*>(b + layer_bytes * GEM_LAYER_TRAVER);
+    h->layers.lowest    = reinterpret_cast<float*>(b + layer_bytes * GEM_LAYER_LOWEST);
+    h->layers.colorR    = reinterpret_cast<int*>(b + layer_bytes * GEM_LAYER_COLOR_R);
+    h->layers.colorG    = reinterpret_cast<int*>(b + layer_bytes * GEM_LAYER_COLOR_G);
+    h->layers.colorB    = reinterpret_cast<int*>(b + layer_bytes * GEM_LAYER_COLOR_B);
+    if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_counters), 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc(counters)", e);
+    if ((e = launch_init(h->stream, h->layers, h->cells, 1)) != hipSuccess) return bail("k_init", e);   // G_Init_map
+    if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return bail("hipStreamSynchronize", e);
+    h->floor_dirty = true;
+    *out = h;
+    return GEM_OK;
+}
+
+void gem_destroy(gem_handle* h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->comm) ncclCommDestroy(h->comm);
+    fold_events(h);
+    for (auto& ep : h->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
+    if (h->layers.elevation) hipFree(h->layers.elevation);      // base of the single layer allocation
+    if (h->d_counters) hipFree(h->d_counters);
+    for (Arena* a : {&h->stage, &h->rec, &h->seg, &h->tables, &h->scratch}) if (a->p) hipFree(a->p);
+    if (h->copy_done) hipEventDestroy(h->copy_done);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+int gem_set_stream(gem_handle* h, void* hip_stream)
+{
+    if (!h) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    GEM_HIP(h, hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return GEM_OK;
+}
+
+int gem_synchronize(gem_handle* h)
+{
+    if (!h) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    GEM_HIP(h, hipStreamSynchronize(h->stream));
+    return GEM_OK;
+}
+
+int gem_get_pose(gem_handle* h, float out_center[2], int out_start[2])
+{
+    if (!h) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (out_center) { out_center[0] = h->center[0]; out_center[1] = h->center[1]; }
+    if (out_start) { out_start[0] = h->start[0]; out_start[1] = h->start[1]; }
+    return GEM_OK;
+}
+
+// Move, gpu_process.cu:1004-1083.  Centre / start live on the host (the handle is their only
+// writer), so the reference's two cudaMemcpyFromSymbol round trips per frame disappear.
+int gem_move(gem_handle* h, const float position[3], float out_center[2], int out_start[2], float out_aligned_shift[2])
+{
+    if (!h || !position) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    const int L = h->L; const float res = h->res;
+    h->sensor_z = position[2];
+    int shift[2]; float aligned[2];
+    for (int i = 0; i < 2; ++i) {
+        const float d = position[i] - h->center[i];
+        shift[i] = static_cast<int>(static_cast<double>(d / res) + 0.5 * (d > 0 ? 1 : -1));     // :897
+        aligned[i] = static_cast<float>(shift[i]) * res;                                        // :909
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (shift[i] != 0) {
+            h->floor_dirty = true;
+            if (shift[i] >= L || shift[i] <= -L) {
+                // :1034-1038 G_Clear_allmap.  (For shift <= -L the reference indexes past the arrays; we clear all.)
+                GEM_HIP(h, launch_init(h->stream, h->layers, h->cells, 0));
+            } else {
+                const int sign = shift[i] > 0 ? 1 : -1;
+                const int start_index = h->start[i] - (sign > 0 ? 1 : 0);
+                const int end_index = start_index + sign - shift[i];
+                const int n_cells = std::abs(shift[i]);
+                int index = index_to_range(sign < 0 ? start_index : end_index, L);
+                if (index + n_cells <= L) {
+                    GEM_HIP(h, launch_clear_strip(h->stream, h->layers, L, index, n_cells, i == 0));
+                } else {
+                    const int first_n = L - index;
+                    GEM_HIP(h, launch_clear_strip(h->stream, h->layers, L, index, first_n, i == 0));
+                    GEM_HIP(h, launch_clear_strip(h->stream, h->layers, L, 0, n_cells - first_n, i == 0));
+                }
+            }
+        }
+        h->start[i] = index_to_range(h->start[i] - shift[i], L);
+        // PositionToRange, :996-1002
+        const int p_index = static_cast<int>(roundf(h->center[i] / res));
+        const int s_index = static_cast<int>(roundf(aligned[i] / res));
+        h->center[i] = static_cast<float>(p_index + s_index) * res;
+    }
+    if (out_center) { out_center[0] = h->center[0]; out_center[1] = h->center[1]; }
+    if (out_start) { out_start[0] = h->start[0]; out_start[1] = h->start[1]; }
+    if (out_aligned_shift) { out_aligned_shift[0] = aligned[0]; out_aligned_shift[1] = aligned[1]; }
+    return GEM_OK;
+}
+
+int gem_process_points(gem_handle* h, const gem_frame_params* p, int n, float* x, float* y, float* z,
+                       const int* orig_index, int write_back_xyz,
+                       int* map_index, float* var, float* x_ts, float* y_ts, float* z_ts)
+{
+    if (!h || !p || n < 0 || (n > 0 && (!x || !y || !z))) return h ? fail(h, GEM_ERR_INVALID, "gem_process_points: bad argument") : GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    if (n == 0) return GEM_OK;
+    const size_t N = (size_t)n, S = N * 4;
+    int rc;
+    if ((rc = ensure(h, h->stage, S * 9))) return rc;
+    unsigned char* d = static_cast<unsigned char*>(h->stage.p);
+    float* dx = reinterpret_cast<float*>(d);           float* dy = reinterpret_cast<float*>(d + S);
+    float* dz = reinterpret_cast<float*>(d + 2 * S);   int* dorig = reinterpret_cast<int*>(d + 3 * S);
+    int* didx = reinterpret_cast<int*>(d + 4 * S);     float* dvar = reinterpret_cast<float*>(d + 5 * S);
+    float* dxt = reinterpret_cast<float*>(d + 6 * S);  float* dyt = reinterpret_cast<float*>(d + 7 * S);
+    float* dzt = reinterpret_cast<float*>(d + 8 * S);
+    GEM_HIP(h, hipMemcpyAsync(dx, x, S, hipMemcpyHostToDevice, h->stream));
+    GEM_HIP(h, hipMemcpyAsync(dy, y, S, hipMemcpyHostToDevice, h->stream));
+    GEM_HIP(h, hipMemcpyAsync(dz, z, S, hipMemcpyHostToDevice, h->stream));
+    if (orig_index) GEM_HIP(h, hipMemcpyAsync(dorig, orig_index, S, hipMemcpyHostToDevice, h->stream));
+    FrameConst fc; fill_frame(h, p, fc);
+    GEM_HIP(h, launch_project(h->stream, fc, n, dx, dy, dz, orig_index ? dorig : nullptr, write_back_xyz, didx, dvar, dxt, dyt, dzt));
+    if (map_index) GEM_HIP(h, hipMemcpyAsync(map_index, didx, S, hipMemcpyDeviceToHost, h->stream));
+    if (var)  GEM_HIP(h, hipMemcpyAsync(var, dvar, S, hipMemcpyDeviceToHost, h->stream));
+    if (x_ts) GEM_HIP(h, hipMemcpyAsync(x_ts, dxt, S, hipMemcpyDeviceToHost, h->stream));
+    if (y_ts) GEM_HIP(h, hipMemcpyAsync(y_ts, dyt, S, hipMemcpyDeviceToHost, h->stream));
+    if (z_ts) GEM_HIP(h, hipMemcpyAsync(z_ts, dzt, S, hipMemcpyDeviceToHost, h->stream));
+    if (write_back_xyz) {
+        GEM_HIP(h, hipMemcpyAsync(x, dx, S, hipMemcpyDeviceToHost, h->stream));
+        GEM_HIP(h, hipMemcpyAsync(y, dy, S, hipMemcpyDeviceToHost, h->stream));
+        GEM_HIP(h, hipMemcpyAsync(z, dz, S, hipMemcpyDeviceToHost, h->stream));
+    }
+    GEM_HIP(h, hipStreamSynchronize(h->stream));
+    return GEM_OK;
+}
+
+int gem_fuse(gem_handle* h, int n, const int* index, const int* R, const int* G, const int* B,
+             const float* intensity, const float* height, const float* var)
+{
+    if (!h || n < 0 || (n > 0 && (!index || !height || !var))) return h ? fail(h, GEM_ERR_INVALID, "gem_fuse: bad argument") : GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    const bool attr = R && G && B && intensity;
+    const size_t S = (size_t)n * 4;
+    PassInput in; in.src = 1; in.n = n;
+    if (n > 0) {
+        int rc;
+        if ((rc = ensure(h, h->stage, S * 7))) return rc;
+        unsigned char* d = static_cast<unsigned char*>(h->stage.p);
+        GEM_HIP(h, hipMemcpyAsync(d, index, S, hipMemcpyHostToDevice, h->stream));
+        GEM_HIP(h, hipMemcpyAsync(d + S, height, S, hipMemcpyHostToDevice, h->stream));
+        GEM_HIP(h, hipMemcpyAsync(d + 2 * S, var, S, hipMemcpyHostToDevice, h->stream));
+        in.f_index = reinterpret_cast<const int*>(d); in.f_height = reinterpret_cast<const float*>(d + S);
+        in.f_var = reinterpret_cast<const float*>(d + 2 * S);
+        if (attr) {
+            GEM_HIP(h, hipMemcpyAsync(d + 3 * S, R, S, hipMemcpyHostToDevice, h->stream));
+            GEM_HIP(h, hipMemcpyAsync(d + 4 * S, G, S, hipMemcpyHostToDevice, h->stream));
+            GEM_HIP(h, hipMemcpyAsync(d + 5 * S, B, S, hipMemcpyHostToDevice, h->stream));
+            GEM_HIP(h, hipMemcpyAsync(d + 6 * S, intensity, S, hipMemcpyHostToDevice, h->stream));
+            in.f_R = reinterpret_cast<const int*>(d + 3 * S); in.f_G = reinterpret_cast<const int*>(d + 4 * S);
+            in.f_B = reinterpret_cast<const int*>(d + 5 * S); in.f_I = reinterpret_cast<const float*>(d + 6 * S);
+        }
+        // the caller's arrays are only valid for the call (they are stack VLAs in the reference, EMg.cpp:260-267)
+        GEM_HIP(h, hipEventRecord(h->copy_done, h->stream));
+        GEM_HIP(h, hipEventSynchronize(h->copy_done));
+    }
+    return run_pipeline(h, in);
+}
+
+int gem_add_device(gem_handle* h, const gem_frame_params* p, int n, const void* d_xyzi, const void* d_rgb, const void* d_orig_index)
+{
+    if (!h || !p || n < 0 || (n > 0 && !d_xyzi)) return h ? fail(h, GEM_ERR_INVALID, "gem_add_device: bad argument") : GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    PassInput in; in.src = 0; in.n = n; in.params = p;
+    in.xyzi = static_cast<const float4*>(d_xyzi); in.rgb = static_cast<const uint32_t*>(d_rgb); in.orig = static_cast<const int*>(d_orig_index);
+    return run_pipeline(h, in);
+}
+
+int gem_add(gem_handle* h, const gem_frame_params* p, int n, const float* xyzi, const uint32_t* rgb, const int* orig_index)
+{
+    if (!h || !p || n < 0 || (n > 0 && !xyzi)) return h ? fail(h, GEM_ERR_INVALID, "gem_add: bad argument") : GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    PassInput in; in.src = 0; in.n = n; in.params = p;
+    if (n > 0) {
+        const size_t S = (size_t)n * 4;
+        int rc;
+        if ((rc = ensure(h, h->stage, S * 6))) return rc;
+        unsigned char* d = static_cast<unsigned char*>(h->stage.p);
+        GEM_HIP(h, hipMemcpyAsync(d, xyzi, S * 4, hipMemcpyHostToDevice, h->stream));
+        in.xyzi = reinterpret_cast<const float4*>(d);
+        if (rgb) { GEM_HIP(h, hipMemcpyAsync(d + 4 * S, rgb, S, hipMemcpyHostToDevice, h->stream)); in.rgb = reinterpret_cast<const uint32_t*>(d + 4 * S); }
+        if (orig_index) { GEM_HIP(h, hipMemcpyAsync(d + 5 * S, orig_index, S, hipMemcpyHostToDevice, h->stream)); in.orig = reinterpret_cast<const int*>(d + 5 * S); }
+        GEM_HIP(h, hipEventRecord(h->copy_done, h->stream));
+        GEM_HIP(h, hipEventSynchronize(h->copy_done));
+    }
+    return run_pipeline(h, in);
+}
+
+int gem_add_batch_device(gem_handle* h, int n_sweeps, const gem_frame_params* params, const void* d_xyzi,
+                         const long long* offsets, const float* var_updates)
+{
+    if (!h || n_sweeps <= 0 || !params || !offsets) return h ? fail(h, GEM_ERR_INVALID, "gem_add_batch_device: bad argument") : GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    for (int s = 0; s < n_sweeps; ++s) if (offsets[s + 1] < offsets[s]) return fail(h, GEM_ERR_INVALID, "gem_add_batch_device: offsets not monotone");
+    if (n_sweeps == 1) {
+        if (var_updates) {
+            if (!(var_updates[0] >= 0.f)) h->floor_dirty = true;
+            if (h->n_pending == kMaxPending) { int rc = flush_pending(h, false); if (rc) return rc; }
+            h->pending[h->n_pending++] = var_updates[0];
+        }
+        PassInput in; in.src = 0; in.n = offsets[1] - offsets[0]; in.params = params;
+        in.xyzi = static_cast<const float4*>(d_xyzi) + offsets[0];
+        return run_pipeline(h, in);
+    }
+    PassInput in; in.src = 0; in.n_sweeps = n_sweeps; in.n = offsets[n_sweeps]; in.params = params;
+    in.offsets = offsets; in.var_updates = var_updates;
+    in.xyzi = static_cast<const float4*>(d_xyzi);
+    return run_pipeline(h, in);
+}
+
+int gem_mapvar_update(gem_handle* h, float var_update)
+{
+    if (!h) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    // queued and folded into the next fuse's single pass over the tiles; a negative (or NaN)
+    // increment can push a variance under the floor, which the next Fuse must repair everywhere
+    if (!(var_update >= 0.f)) h->floor_dirty = true;
+    if (h->n_pending == kMaxPending) { int rc = flush_pending(h, false); if (rc) return rc; }
+    h->pending[h->n_pending++] = var_update;
+    return GEM_OK;
+}
+
+static void* layer_ptr(gem_handle* h, int layer)
+{
+    switch (layer) {
+    case GEM_LAYER_ELEVATION: return h->layers.elevation;
+    case GEM_LAYER_VARIANCE:  return h->layers.variance;
+    case GEM_LAYER_INTENSITY: return h->layers.intensity;
+    case GEM_LAYER_TRAVER:    return h->layers.traver;
+    case GEM_LAYER_LOWEST:    return h->layers.lowest;
+    case GEM_LAYER_COLOR_R:   return h->layers.colorR;
+    case GEM_LAYER_COLOR_G:   return h->layers.colorG;
+    case GEM_LAYER_COLOR_B:   return h->layers.colorB;
+    default: return nullptr;
+    }
+}
+
+int gem_get_layer(gem_handle* h, int layer, int layout, void* dst_host)
+{
+    if (!h || !dst_host) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    void* src = layer_ptr(h, layer);
+    if (!src) return fail(h, GEM_ERR_INVALID, "gem_get_layer: bad layer");
+    int rc = flush_pending(h, false);
+    if (rc) return rc;
+    const size_t bytes = (size_t)h->cells * 4;
+    if (layout == GEM_LAYOUT_STORAGE_ROWMAJOR) {
+        GEM_HIP(h, hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    } else if (layout == GEM_LAYOUT_GRIDMAP_COLMAJOR_NAN) {
+        if ((rc = ensure(h, h->scratch, bytes))) return rc;
+        const int is_int = layer >= GEM_LAYER_COLOR_R;
+        GEM_HIP(h, launch_export_gridmap(h->stream, src, h->layers.elevation, static_cast<float*>(h->scratch.p), h->L, is_int));
+        GEM_HIP(h, hipMemcpyAsync(dst_host, h->scratch.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    } else {
+        return fail(h, GEM_ERR_INVALID, "gem_get_layer: bad layout");
+    }
+    GEM_HIP(h, hipStreamSynchronize(h->stream));
+    return GEM_OK;
+}
+
+int gem_set_layer(gem_handle* h, int layer, const void* src_host)
+{
+    if (!h || !src_host) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    void* dst = layer_ptr(h, layer);
+    if (!dst) return fail(h, GEM_ERR_INVALID, "gem_set_layer: bad layer");
+    int rc = flush_pending(h, false);
+    if (rc) return rc;
+    GEM_HIP(h, hipMemcpyAsync(dst, src_host, (size_t)h->cells * 4, hipMemcpyHostToDevice, h->stream));
+    GEM_HIP(h, hipStreamSynchronize(h->stream));
+    if (layer == GEM_LAYER_VARIANCE) h->floor_dirty = true;
+    return GEM_OK;
+}
+
+int gem_layer_device_ptr(gem_handle* h, int layer, void** out_device_ptr)
+{
+    if (!h || !out_device_ptr) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    *out_device_ptr = layer_ptr(h, layer);
+    return *out_device_ptr ? GEM_OK : fail(h, GEM_ERR_INVALID, "gem_layer_device_ptr: bad layer");
+}
+
+int gem_set_timing(gem_handle* h, int enabled)
+{
+    if (!h) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->timing = enabled != 0;
+    return GEM_OK;
+}
+
+int gem_set_counting(gem_handle* h, int enabled)
+{
+    if (!h) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->counting = enabled != 0;
+    return GEM_OK;
+}
+
+int gem_get_stats(gem_handle* h, gem_stats* out, int reset)
+{
+    if (!h || !out) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    GEM_HIP(h, hipStreamSynchronize(h->stream));
+    fold_events(h);
+    if (h->counting) {
+        unsigned long long c[2] = {0, 0};
+        GEM_HIP(h, hipMemcpy(c, h->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+        h->stats.points_binned = (long long)c[0];
+        h->stats.cells_touched = (long long)c[1];
+    }
+    *out = h->stats;
+    if (reset) { const long long pin = h->stats.points_in; h->stats = gem_stats{}; h->stats.points_in = pin; }
+    return GEM_OK;
+}
+
+// ---- RCCL: all-gather of the fused row strips over xGMI -------------------------------------------
+int gem_comm_unique_id(void* out_128_bytes)
+{
+    if (!out_128_bytes) return GEM_ERR_INVALID;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return GEM_ERR_COMM;
+    memcpy(out_128_bytes, &id, sizeof(id));
+    return GEM_OK;
+}
+
+int gem_comm_init(gem_handle* h, const void* unique_id_128_bytes, int nranks, int rank)
+{
+    if (!h || !unique_id_128_bytes || nranks <= 0 || rank < 0 || rank >= nranks) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    ncclUniqueId id;
+    memcpy(&id, unique_id_128_bytes, sizeof(id));
+    ncclResult_t r = ncclCommInitRank(&h->comm, nranks, id, rank);
+    if (r != ncclSuccess) { h->comm = nullptr; return fail(h, GEM_ERR_COMM, ncclGetErrorString(r)); }
+    h->nranks = nranks; h->rank = rank;
+    // row strips in STORAGE coordinates: Move never migrates data between devices
+    h->row0 = (int)((long long)h->L * rank / nranks);
+    h->row1 = (int)((long long)h->L * (rank + 1) / nranks);
+    return GEM_OK;
+}
+
+int gem_allgather_layers(gem_handle* h, int with_attributes)
+{
+    if (!h) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    if (!h->comm) return fail(h, GEM_ERR_COMM, "gem_allgather_layers: gem_comm_init not called");
+    int rc = flush_pending(h, false);
+    if (rc) return rc;
+    const int nl = with_attributes ? 6 : 2;
+    void* ptrs[6] = {h->layers.elevation, h->layers.variance, h->layers.intensity, h->layers.colorR, h->layers.colorG, h->layers.colorB};
+    const bool even = (h->L % h->nranks) == 0;
+    ncclResult_t r = ncclGroupStart();
+    for (int l = 0; l < nl && r == ncclSuccess; ++l) {
+        unsigned char* base = static_cast<unsigned char*>(ptrs[l]);
+        if (even) {
+            const size_t count = (size_t)(h->L / h->nranks) * h->L;      // 4-byte elements per rank
+            r = ncclAllGather(base + (size_t)h->rank * count * 4, base, count, ncclFloat, h->comm, h->stream);   // in place
+        } else {
+            for (int k = 0; k < h->nranks && r == ncclSuccess; ++k) {
+                const size_t r0 = (size_t)((long long)h->L * k / h->nranks), r1 = (size_t)((long long)h->L * (k + 1) / h->nranks);
+                r = ncclBroadcast(base + r0 * h->L * 4, base + r0 * h->L * 4, (r1 - r0) * h->L, ncclFloat, k, h->comm, h->stream);
+            }
+        }
+    }
+    ncclResult_t r2 = ncclGroupEnd();
+    if (r != ncclSuccess || r2 != ncclSuccess) return fail(h, GEM_ERR_COMM, ncclGetErrorString(r != ncclSuccess ? r : r2));
+    return GEM_OK;
+}
+
+} // extern "C"

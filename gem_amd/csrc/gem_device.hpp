@@ -1,0 +1,184 @@
+// gem_device.hpp -- per-point device arithmetic of the GEM hot path for gfx950.
+//
+// Semantics follow the reference's G_pointsprocess / PointsToMapIndex
+// (elevation_mapping/elevation_mapping/cuda/gpu_process.cu:384-455, 332-358; "GPU:" below).
+// The translation unit is compiled with -ffp-contract=off: cell indices must be bit-exact, so no
+// product+sum may be contracted into an FMA, and the IEEE divide/sqrt of hipcc's default mode
+// are kept (no -ffast-math).  3-term sums written c0 + (c1 + c2) mirror Eigen's fixed-size
+// redux order for the products the reference writes with Eigen types (GPU:403-425).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gem {
+
+constexpr float kEmptyElevation = -10.0f;   // GPU:204 "elevation == -10" is the empty-cell sentinel
+constexpr float kInitVariance   = -10.0f;   // GPU:205
+constexpr int   kInvalidTile    = 0x7fffffff;
+
+// Everything a kernel needs for one frame; passed BY VALUE as a kernel argument so it lives in
+// SGPRs / the scalar cache (the reference uploads the same data with 5 cudaMemcpyToSymbol calls
+// and 5 Eigen by-value kernel arguments per frame, GPU:1110-1119).
+struct FrameConst {
+    float  T[12];            // rows 0..2 of the sensor->map transform
+    double lower, upper;     // GPU:50-51 are doubles
+    double sp[8];            // sensor-model parameters
+    float  Js[3];            // sensorJacobian
+    float  Q[9];             // rotationVariance
+    float  C[9];             // C_SB_transpose
+    float  P[3];             // P_mul_C_BM_transpose
+    float  Bs[9];            // B_r_BS_skew
+    float  fbx, fby, fband, fplane;
+    int    filter_on;
+    int    model;
+    int    orig_width;
+    // map pose / geometry (GPU:30-31,35-36)
+    float  cx, cy;
+    int    sx, sy;
+    int    L;
+    float  res;
+    // strip of storage rows owned by this device (multi-GPU tiling); whole map = [0, L)
+    int    row0, row1;
+};
+
+struct Projected {
+    float h, var, xt, yt;
+    int   cell;              // storage index, -1 if outside the map (or the point was rejected)
+    bool  accepted;          // passed the reject filter and the height window (GPU:397)
+};
+
+__device__ __forceinline__ float dot3(float a0, float b0, float a1, float b1, float a2, float b2)
+{
+    const float c0 = a0 * b0, c1 = a1 * b1, c2 = a2 * b2;
+    return c0 + (c1 + c2);
+}
+
+// one axis of GPU:340-348
+__device__ __forceinline__ int axis_index(int L, float res, float shift)
+{
+    if ((L & 1) == 0) {
+        const float v = (float)(L / 2) - shift / res;
+        if (!(v > -2147483648.0f && v < 2147483648.0f)) return -1;   // non-finite / unrepresentable -> outside
+        return (int)v;                                               // truncation toward zero
+    } else {
+        const double v = (double)(shift / res) + 0.5 * (shift > 0 ? 1 : -1);
+        if (!(v > -2147483648.0 && v < 2147483648.0)) return -1;
+        return L / 2 - (int)v;
+    }
+}
+
+// GPU:332-358 (PointsToMapIndex)
+__device__ __forceinline__ int map_index(const FrameConst& f, float px, float py)
+{
+    const float shx = px - f.cx, shy = py - f.cy;
+    const int ix = axis_index(f.L, f.res, shx), iy = axis_index(f.L, f.res, shy);
+    if (ix >= 0 && ix < f.L && iy >= 0 && iy < f.L) {
+        const int stx = (ix + f.sx) % f.L;
+        const int sty = (iy + f.sy) % f.L;
+        return stx * f.L + sty;
+    }
+    return -1;
+}
+
+__device__ __forceinline__ void sensor_variances(const FrameConst& f, float x, float y, float z, int orig,
+                                                 float& vn, float& vl)
+{
+    switch (f.model) {
+    default:
+    case 0: {   // laser, GPU:404-408
+        const float d = sqrtf(dot3(x, x, y, y, z, z));
+        const float min_r = (float)f.sp[0], beam_a = (float)f.sp[1], beam_c = (float)f.sp[2];
+        vn = min_r * min_r;
+        const float t = beam_c + beam_a * d;
+        vl = t * t;
+        break; }
+    case 1: {   // structured light, StructuredLightSensorProcessor.cpp:128-139 (double expression)
+        const double zd = (double)z;
+        const float dev_n = (float)(f.sp[0] + f.sp[1] * (zd - f.sp[2]) * (zd - f.sp[2]) + f.sp[3] * pow(zd, f.sp[4]));
+        vn = dev_n * dev_n;
+        const float dev_l = (float)(f.sp[5] * zd);
+        vl = dev_l * dev_l;
+        break; }
+    case 2: {   // stereo, StereoSensorProcessor.cpp:78-92
+        const int w = f.orig_width > 0 ? f.orig_width : 1;
+        const int I = orig / w, J = orig % w;
+        const double disparity = f.sp[6] / (double)z;
+        const float d = sqrtf(dot3(x, x, y, y, z, z));
+        const double t = f.sp[2] * disparity + f.sp[3] - (double)J;
+        const double u = 240.0 - (double)I;
+        const double g = f.sp[6] / (disparity * disparity);
+        vn = (float)(g * g * ((f.sp[4] * disparity + f.sp[1]) * sqrt(t * t + u * u) + f.sp[0]));
+        const double l = f.sp[5] * (double)d;
+        vl = (float)(l * l);
+        break; }
+    case 3:     // perfect, PerfectSensorProcessor.cpp:86-88
+        vn = 0.0f; vl = 0.0f;
+        break;
+    }
+}
+
+// GPU:403-425
+__device__ __forceinline__ float height_variance(const FrameConst& f, float x, float y, float z, int orig)
+{
+    float vn, vl;
+    sensor_variances(f, x, y, z, orig, vn, vl);
+    const float q0 = dot3(f.C[0], x, f.C[1], y, f.C[2], z);
+    const float q1 = dot3(f.C[3], x, f.C[4], y, f.C[5], z);
+    const float q2 = dot3(f.C[6], x, f.C[7], y, f.C[8], z);
+    const float S0 = 0.0f + f.Bs[0], S1 = -q2 + f.Bs[1],  S2 = q1 + f.Bs[2];
+    const float S3 = q2 + f.Bs[3],   S4 = 0.0f + f.Bs[4], S5 = -q0 + f.Bs[5];
+    const float S6 = -q1 + f.Bs[6],  S7 = q0 + f.Bs[7],   S8 = 0.0f + f.Bs[8];
+    const float Jq0 = dot3(f.P[0], S0, f.P[1], S3, f.P[2], S6);
+    const float Jq1 = dot3(f.P[0], S1, f.P[1], S4, f.P[2], S7);
+    const float Jq2 = dot3(f.P[0], S2, f.P[1], S5, f.P[2], S8);
+    const float a0 = dot3(Jq0, f.Q[0], Jq1, f.Q[3], Jq2, f.Q[6]);
+    const float a1 = dot3(Jq0, f.Q[1], Jq1, f.Q[4], Jq2, f.Q[7]);
+    const float a2 = dot3(Jq0, f.Q[2], Jq1, f.Q[5], Jq2, f.Q[8]);
+    float hv = a0 * Jq0 + a1 * Jq1 + a2 * Jq2;                      // cuda_computer, GPU:293-298
+    const float b0 = dot3(f.Js[0], vl, f.Js[1], 0.0f, f.Js[2], 0.0f);
+    const float b1 = dot3(f.Js[0], 0.0f, f.Js[1], vl, f.Js[2], 0.0f);
+    const float b2 = dot3(f.Js[0], 0.0f, f.Js[1], 0.0f, f.Js[2], vn);
+    hv += b0 * f.Js[0] + b1 * f.Js[1] + b2 * f.Js[2];
+    return hv;
+}
+
+// one point of G_pointsprocess (GPU:384-455), without the racy map_lowest side effect
+__device__ __forceinline__ Projected project_point(const FrameConst& f, float x, float y, float z, int orig)
+{
+    Projected r;
+    const float h = f.T[8] * x + f.T[9] * y + f.T[10] * z + f.T[11];               // GPU:389
+    bool flag = false;
+    if (f.filter_on)                                                               // GPU:393
+        flag = (x > -f.fbx && x < f.fbx && y > -f.fby && y < f.fby) || (y > -f.fband && y < f.fband) || (y > f.fplane);
+    if (((double)h > f.lower && (double)h < f.upper) && !flag) {                   // GPU:397
+        r.xt = f.T[0] * x + f.T[1] * y + f.T[2] * z + f.T[3];                      // GPU:399
+        r.yt = f.T[4] * x + f.T[5] * y + f.T[6] * z + f.T[7];                      // GPU:400
+        r.h = h;
+        r.var = height_variance(f, x, y, z, orig);
+        r.cell = map_index(f, r.xt, r.yt);                                         // GPU:431
+        r.accepted = true;
+    } else {                                                                       // GPU:441-451
+        r.xt = -1.0f; r.yt = -1.0f; r.h = -1.0f; r.var = -1.0f; r.cell = -1; r.accepted = false;
+    }
+    return r;
+}
+
+// The per-cell recurrence of G_fuse (GPU:484-529) on register state (e, s).  Returns true when the
+// point was "taken" (colour / intensity of this point may overwrite the cell's, GPU:487-494 etc.).
+__device__ __forceinline__ bool fuse_step(float& e, float& s, float h, float v, float mahal_thr, float var_floor)
+{
+    if (e == kEmptyElevation) { e = h; s = v; return true; }                       // GPU:484-486
+    if (s < var_floor) s = var_floor;                                              // GPU:500-501
+    const float m = fabsf(h - e) / sqrtf(s);                                       // GPU:502
+    if (m > mahal_thr) {                                                           // GPU:504
+        if (e < h) { e = h; s = v; return true; }                                  // GPU:505-507
+        return false;
+    }
+    const float en = (s * h + v * e) / (s + v);                                    // GPU:518
+    s = (v * s) / (v + s);                                                         // GPU:519
+    e = en;
+    return true;
+}
+
+} // namespace gem

@@ -1,0 +1,77 @@
+// gem_kernels.hpp -- argument blocks and host launchers of the gfx950 kernels (internal header).
+#pragma once
+
+#include "gem_device.hpp"
+
+namespace gem {
+
+constexpr int kFuseR32 = 8;     // k_fuse batch = 256*R points per tile pass, 32x32-cell tiles
+constexpr int kFuseR64 = 16;    //                                           64x64-cell tiles
+constexpr int kMaxPending = 4;  // queued Mapvar_update increments folded into the next fuse
+
+struct LayerPtrs {
+    float *elevation, *variance, *intensity, *traver, *lowest;
+    int   *colorR, *colorG, *colorB;
+};
+
+// A "unit" is 64*IPT consecutive points of one sweep, binned by one wave.  Unit u owns record
+// slots [u*U, (u+1)*U) of the arena and column u of the (tile x unit) descriptor table.
+struct BinArgs {
+    FrameConst frame0;                 // single-sweep call: the frame, by value (SGPRs)
+    // batched call (n_sweeps > 1): per-sweep tables in device memory
+    const FrameConst* frames;          // [n_sweeps]
+    const int*        sweep_unit0;     // [n_sweeps+1] first unit of each sweep
+    const long long*  sweep_first;     // [n_sweeps+1] first point of each sweep in the concatenated cloud
+    int               n_sweeps;
+    long long         n;               // total points
+    // input, SRC 0: interleaved XYZI (+ optional packed rgb, original pixel index)
+    const float4*   xyzi;
+    const uint32_t* rgb;
+    const int*      orig;
+    // input, SRC 1: Fuse()'s arrays (GPU:1154)
+    const int*   f_index; const float* f_height; const float* f_var;
+    const int*   f_R; const int* f_G; const int* f_B; const float* f_I;
+    // tiling
+    int T;                             // number of tiles
+    int tiles_per_row;
+    int B;                             // number of units (grid size)
+    // outputs
+    uint4*    rec;                     // [B * U]
+    uint32_t* seg;                     // [T][B]  start | count << 16
+    unsigned long long* counters;      // optional: [0] += binned points
+};
+
+struct FuseArgs {
+    const uint4*    rec;
+    const uint32_t* seg;               // [T][B_total]
+    int   B_total;                     // row stride of seg
+    int   U;                           // records per unit slot
+    int   n_sweeps;
+    const int* sweep_unit0;            // [n_sweeps+1] (NULL when n_sweeps == 1: units [0, B_total))
+    int   Bpad;                        // max units of one sweep (sizes the LDS prefix table)
+    int   T, tiles_per_row, L;
+    int   row0, row1;                  // owned storage rows
+    float mahal, var_floor;
+    int   dense;                       // 1: visit every tile (pending variance increments / floor not yet established)
+    int   n_pending; float pending[kMaxPending];   // applied before sweep 0 (GPU:540-547)
+    const float* var_updates;          // [n_sweeps] applied before each sweep (batched call), or NULL
+    float *elevation, *variance;
+    // attributes (ATTR 1: xyzi.w + packed rgb, ATTR 2: Fuse() arrays)
+    float* intensity; int *colorR, *colorG, *colorB;
+    const float4* xyzi; const uint32_t* rgb;
+    const int* f_R; const int* f_G; const int* f_B; const float* f_I;
+    unsigned long long* counters;      // optional: [1] += distinct touched cells (per sweep)
+};
+
+hipError_t launch_project(hipStream_t st, const FrameConst& fc, int n, float* x, float* y, float* z, const int* orig,
+                          int write_back, int* map_idx, float* var, float* xt, float* yt, float* zt);
+hipError_t launch_bin(hipStream_t st, const BinArgs& a, int ipt, int src, int ts);
+hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr);
+size_t     fuse_lds_bytes(int ts, int r, int bpad);
+hipError_t launch_init(hipStream_t st, const LayerPtrs& m, int cells, int clear_lowest);
+hipError_t launch_clear_strip(hipStream_t st, const LayerPtrs& m, int L, int start, int count, int is_row);
+hipError_t launch_dense_variance(hipStream_t st, float* variance, int cells, int n_pending, const float* pending,
+                                 int apply_floor, float var_floor);
+hipError_t launch_export_gridmap(hipStream_t st, const void* src, const float* elevation, float* dst, int L, int is_int);
+
+} // namespace gem

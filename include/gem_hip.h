@@ -1,0 +1,168 @@
+/*
+ * gem_hip.h -- C ABI of libgem_hip.so: the MI355X (gfx950) implementation of GEM's
+ * point-cloud -> elevation-grid hot path.  This is the drop-in boundary: plain pointers and
+ * sizes, no C++ / Eigen / torch types.  Each entry point cites the reference interface it
+ * replaces (GPU = elevation_mapping/elevation_mapping/cuda/gpu_process.cu, EMg.cpp =
+ * .../src/ElevationMapping.cpp, SPB.cpp = .../src/sensor_processors/SensorProcessorBase.cpp,
+ * RMU.cpp = .../src/RobotMotionMapUpdater.cpp).  The nine C++-linkage symbols the unmodified
+ * ROS node links against are re-created on top of this ABI in include/gem/gem_compat_eigen.hpp.
+ *
+ * Conventions
+ *   - every function returns GEM_OK (0) or a negative gem_status; gem_last_error() gives text.
+ *   - one gem_handle == one robot-centric map (the reference keeps this as hidden process-global
+ *     __device__ state, GPU:20-33); a handle is internally locked, so the reference's
+ *     {Process_points -> Fuse} || {Mapvar_update} thread pair (EMg.cpp:391-394) is safe.
+ *   - host-pointer entry points copy in/out and are synchronous w.r.t. the caller's buffers;
+ *     *_device entry points take device pointers, enqueue on the handle's stream and return.
+ *   - there is NO CPU fallback: without a HIP device gem_create fails with GEM_ERR_NO_DEVICE.
+ */
+#ifndef GEM_HIP_H
+#define GEM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GEM_ABI_VERSION 1
+
+typedef enum gem_status {
+    GEM_OK = 0,
+    GEM_ERR_INVALID = -1,      /* bad argument */
+    GEM_ERR_NO_DEVICE = -2,    /* no HIP device / HIP runtime error at create */
+    GEM_ERR_HIP = -3,          /* HIP runtime error (text in gem_last_error) */
+    GEM_ERR_NOMEM = -4,
+    GEM_ERR_COMM = -5          /* RCCL error */
+} gem_status;
+
+/* sensor noise models.  Laser is the only model on the reference's GPU path (GPU:403-425,
+ * SPB.cpp:286-288); the others are the reference's CPU computeVariances() bodies
+ * (StructuredLightSensorProcessor.cpp:121-153, StereoSensorProcessor.cpp:72-104,
+ * PerfectSensorProcessor.cpp:74-102). */
+enum { GEM_MODEL_LASER = 0, GEM_MODEL_STRUCTURED_LIGHT = 1, GEM_MODEL_STEREO = 2, GEM_MODEL_PERFECT = 3 };
+
+/* map layers (device layout GPU:20-28; GridMap names EM.cpp:43-44) */
+enum {
+    GEM_LAYER_ELEVATION = 0, GEM_LAYER_VARIANCE = 1, GEM_LAYER_INTENSITY = 2, GEM_LAYER_TRAVER = 3,
+    GEM_LAYER_LOWEST = 4, GEM_LAYER_COLOR_R = 5, GEM_LAYER_COLOR_G = 6, GEM_LAYER_COLOR_B = 7,
+    GEM_LAYER_COUNT = 8
+};
+/* layouts for gem_get_layer / gem_set_layer */
+enum {
+    GEM_LAYOUT_STORAGE_ROWMAJOR = 0,   /* the reference's flat [storage_x * L + storage_y] arrays (EM.cpp:98-111)   */
+    GEM_LAYOUT_GRIDMAP_COLMAJOR_NAN = 1 /* grid_map::Matrix (Eigen column-major, buffer order), NaN for empty cells */
+};
+
+typedef struct gem_map_config {
+    int   length;                  /* cells per side, = length_in_x / resolution (EMg.cpp:195)                 */
+    float resolution;              /* metres per cell (GPU:36)                                                 */
+    float mahalanobis_threshold;   /* the reference uploads one (GPU:977) but uses the literal 5 (GPU:504): pass 5 */
+    float variance_floor;          /* literal 0.0001 in the reference (GPU:500,533)                            */
+    float obstacle_threshold;      /* GPU:940 4th argument; not used on this path                              */
+    int   strip_row0, strip_rows;  /* storage-row strip this handle owns (multi-GPU tiling); 0,0 = whole map   */
+    int   device;                  /* HIP device ordinal; -1 = current device                                  */
+} gem_map_config;
+
+/* the hard-coded sensor-frame reject filter of GPU:393, parameterised; defaults 1.5,1.5,1.0,0.0 */
+typedef struct gem_reject_filter {
+    int   enabled;
+    float box_x, box_y;            /* reject |x|<box_x && |y|<box_y */
+    float band_y;                  /* reject |y|<band_y             */
+    float plane_y;                 /* reject y>plane_y              */
+} gem_reject_filter;
+
+/* per-frame constants: exactly what SensorProcessorBase::GPUPointCloudprocess hands to
+ * Process_points (SPB.cpp:171-208): transform, height window, model parameters, Jacobian pieces. */
+typedef struct gem_frame_params {
+    float  T[16];                  /* sensor->map, row-major (Eigen::Matrix4f Transform, SPB.cpp:175-179)      */
+    double lower, upper;           /* relativeLower/UpperThreshold (SPB.cpp:183-184)                          */
+    int    sensor_model;           /* GEM_MODEL_*                                                              */
+    double sensor_params[8];       /* laser: min_radius, beam_angle, beam_constant (SPB.cpp:286-288);
+                                      structured light: normal_factor_a..e, lateral_factor;
+                                      stereo: p_1..p_5, lateral_factor, depth_to_disparity_factor            */
+    float  sensor_jacobian[3];     /* SPB.cpp:275 */
+    float  rotation_variance[9];   /* row-major; zero in the reference (SPB.cpp:202-204) */
+    float  C_SB_T[9];              /* row-major, SPB.cpp:283 */
+    float  P_mul_C_BM_T[3];        /* SPB.cpp:281-282 */
+    float  B_r_BS_skew[9];         /* row-major, SPB.cpp:284 */
+    gem_reject_filter filter;
+    int    original_width;         /* stereo: image width for getI/getJ (StereoSensorProcessor.cpp:108-116)  */
+} gem_frame_params;
+
+typedef struct gem_handle gem_handle;
+
+/* counters of the most recent add/fuse call (read back lazily; forces a stream sync) */
+typedef struct gem_stats {
+    long long points_in;
+    long long points_binned;       /* accepted AND inside the map (and inside this handle's strip)             */
+    long long cells_touched;       /* distinct cells that received >= 1 point                                  */
+    float     ms_bin, ms_fuse;     /* accumulated kernel time of the two pipeline kernels since reset          */
+    int       launches_bin, launches_fuse;
+} gem_stats;
+
+/* ---- lifecycle: replaces Init_GPU_elevationmap (GPU:940-994, called EMg.cpp:199) --------------- */
+int  gem_create(const gem_map_config* cfg, gem_handle** out);
+void gem_destroy(gem_handle* h);
+const char* gem_last_error(const gem_handle* h);      /* h may be NULL: error of the last failed gem_create */
+int  gem_abi_version(void);
+
+/* stream the handle enqueues on (a hipStream_t passed as void*); NULL = the handle's own stream */
+int  gem_set_stream(gem_handle* h, void* hip_stream);
+int  gem_synchronize(gem_handle* h);
+
+/* ---- Move (GPU:1004-1083, called EMg.cpp:1032) -------------------------------------------------- */
+int  gem_move(gem_handle* h, const float position[3], float out_center[2], int out_start[2],
+              float out_aligned_shift[2]);
+int  gem_get_pose(gem_handle* h, float out_center[2], int out_start[2]);
+
+/* ---- Process_points (GPU:1085-1144, called SPB.cpp:208): host SoA arrays in, host arrays out.
+ *      x,y,z are overwritten with -1 for rejected points like the reference's device copies
+ *      (GPU:443-446) only if write_back_xyz != 0.  Any output pointer may be NULL.              */
+int  gem_process_points(gem_handle* h, const gem_frame_params* p, int n,
+                        float* x, float* y, float* z, const int* orig_index, int write_back_xyz,
+                        int* map_index, float* var, float* x_ts, float* y_ts, float* z_ts);
+
+/* ---- Fuse (GPU:1154-1193, called EMg.cpp:280): host arrays in.  R,G,B,intensity may be NULL. -- */
+int  gem_fuse(gem_handle* h, int n, const int* index, const int* R, const int* G, const int* B,
+              const float* intensity, const float* height, const float* var);
+
+/* ---- the fused path: SensorProcessorBase::process + Fuse (EMg.cpp:254-283) in one call on an
+ *      interleaved XYZI cloud (16 B / point); rgb = packed 0x00RRGGBB per point or NULL.
+ *      Nothing returns to the host.  This is the ElevationMap::add-shaped entry.                  */
+int  gem_add(gem_handle* h, const gem_frame_params* p, int n, const float* xyzi,
+             const uint32_t* rgb, const int* orig_index);
+int  gem_add_device(gem_handle* h, const gem_frame_params* p, int n, const void* d_xyzi,
+                    const void* d_rgb, const void* d_orig_index);
+
+/* ---- batched sweeps (BASELINE config 4): for s in 0..n_sweeps-1:
+ *        Mapvar_update(var_updates[s]) ; add(params[s], cloud s)
+ *      with the map pose fixed for the batch.  Clouds are device-resident, concatenated:
+ *      cloud s = d_xyzi + 16*offsets[s], offsets has n_sweeps+1 entries.                           */
+int  gem_add_batch_device(gem_handle* h, int n_sweeps, const gem_frame_params* params,
+                          const void* d_xyzi, const long long* offsets, const float* var_updates);
+
+/* ---- Mapvar_update (GPU:1146-1152, called RMU.cpp:81) ------------------------------------------ */
+int  gem_mapvar_update(gem_handle* h, float var_update);
+
+/* ---- layer access (what the dead G_get_mapinfo / G_set_mapinfo hinted at, GPU:457-475; feeds
+ *      ElevationMap::show, EM.cpp:85-149).  dst/src hold L*L 4-byte elements (float, or int32 for
+ *      the colour layers in STORAGE_ROWMAJOR; float in GRIDMAP layout).                            */
+int  gem_get_layer(gem_handle* h, int layer, int layout, void* dst_host);
+int  gem_set_layer(gem_handle* h, int layer, const void* src_host);     /* STORAGE_ROWMAJOR only */
+int  gem_layer_device_ptr(gem_handle* h, int layer, void** out_device_ptr);
+
+/* ---- statistics / timing (bench harness) --------------------------------------------------------- */
+int  gem_set_timing(gem_handle* h, int enabled);      /* record hipEvents around each pipeline kernel */
+int  gem_set_counting(gem_handle* h, int enabled);    /* count binned points / touched cells on device */
+int  gem_get_stats(gem_handle* h, gem_stats* out, int reset);
+
+/* ---- multi-GPU: RCCL all-gather of the fused strips over xGMI ------------------------ */
+int  gem_comm_unique_id(void* out_128_bytes);
+int  gem_comm_init(gem_handle* h, const void* unique_id_128_bytes, int nranks, int rank);
+int  gem_allgather_layers(gem_handle* h, int with_attributes);   /* elevation+variance (+intensity, colours) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,186 @@
+"""ctypes binding of the CPU ORACLE (oracle/gem_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under gem_amd/ imports this module.  PARITY UNPINNED by the reference
+(no tests / golden vectors there); pinned by tests/test_oracle_kat.py.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from ctypes import POINTER, c_double, c_float, c_int, c_longlong, c_void_p
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+LIB = HERE / "libgem_oracle.so"
+
+
+class OFrame(C.Structure):
+    _fields_ = [("T", c_float * 16), ("lower", c_double), ("upper", c_double), ("sensor_model", c_int),
+                ("sp", c_double * 8), ("sensor_jacobian", c_float * 3), ("rotation_variance", c_float * 9),
+                ("C_SB_T", c_float * 9), ("P_mul_C_BM_T", c_float * 3), ("B_r_BS_skew", c_float * 9),
+                ("filter_on", c_int), ("filter_box_x", c_float), ("filter_box_y", c_float),
+                ("filter_band_y", c_float), ("filter_plane_y", c_float), ("original_width", c_int)]
+
+
+class OMap(C.Structure):
+    _fields_ = [("L", c_int), ("res", c_float), ("mahal", c_float), ("var_floor", c_float),
+                ("elevation", POINTER(c_float)), ("variance", POINTER(c_float)), ("intensity", POINTER(c_float)),
+                ("traver", POINTER(c_float)), ("lowest", POINTER(c_float)),
+                ("colorR", POINTER(c_int)), ("colorG", POINTER(c_int)), ("colorB", POINTER(c_int)),
+                ("center", c_float * 2), ("start", c_int * 2), ("sensor_z", c_float)]
+
+
+class OMotion(C.Structure):
+    _fields_ = [("prev_reduced_cov", c_double * 16), ("prev_pos", c_double * 3), ("prev_R", c_double * 9),
+                ("covariance_scale", c_double)]
+
+
+def build(force: bool = False) -> Path:
+    srcs = [HERE / "gem_oracle.c", HERE / "gem_oracle_motion.c", HERE / "gem_oracle.h"]
+    if force or not LIB.exists() or any(s.stat().st_mtime > LIB.stat().st_mtime for s in srcs):
+        subprocess.run(["make", "-C", str(HERE), "-B" if force else "-s", "libgem_oracle.so"], check=True,
+                       capture_output=True)
+    return LIB
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        l = C.CDLL(str(build()))
+        l.gemo_create.restype = POINTER(OMap); l.gemo_create.argtypes = [c_int, c_float, c_float, c_float]
+        l.gemo_destroy.argtypes = [POINTER(OMap)]
+        l.gemo_move.restype = c_int
+        l.gemo_move.argtypes = [POINTER(OMap), POINTER(c_float), POINTER(c_float), POINTER(c_int), POINTER(c_float)]
+        l.gemo_points_to_index.restype = c_int; l.gemo_points_to_index.argtypes = [POINTER(OMap), c_float, c_float]
+        l.gemo_points_to_map_index.restype = c_int; l.gemo_points_to_map_index.argtypes = [POINTER(OMap), c_float, c_float]
+        l.gemo_process_points.restype = c_int
+        l.gemo_process_points.argtypes = [POINTER(OMap), POINTER(OFrame), c_int] + [c_void_p] * 9
+        l.gemo_fuse.argtypes = [POINTER(OMap), c_int] + [c_void_p] * 7
+        l.gemo_fuse_literal.argtypes = [POINTER(OMap), c_int] + [c_void_p] * 7
+        l.gemo_mapvar_update.argtypes = [POINTER(OMap), c_float]
+        l.gemo_add.restype = c_int
+        l.gemo_add.argtypes = [POINTER(OMap), POINTER(OFrame), c_int, c_void_p, c_void_p, c_void_p, POINTER(c_longlong)]
+        l.gemo_motion_init.argtypes = [POINTER(OMotion), c_double]
+        l.gemo_motion_update.restype = c_double
+        l.gemo_motion_update.argtypes = [POINTER(OMotion)] + [POINTER(c_double)] * 4
+        _lib = l
+    return _lib
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(c_void_p)
+
+
+class OracleMap:
+    """Same call surface as gem_amd.ElevationMap, computed by the C oracle on the CPU."""
+
+    LAYERS = ("elevation", "variance", "intensity", "traver", "lowest")
+    INT_LAYERS = {"color_r": "colorR", "color_g": "colorG", "color_b": "colorB"}
+
+    def __init__(self, length: int, resolution: float, mahalanobis_threshold: float = 5.0, variance_floor: float = 1e-4):
+        self._l = lib()
+        self._m = self._l.gemo_create(int(length), float(resolution), float(mahalanobis_threshold), float(variance_floor))
+        self.length, self.resolution = int(length), float(resolution)
+        self.last_counts = (0, 0)
+
+    def close(self):
+        if getattr(self, "_m", None):
+            self._l.gemo_destroy(self._m)
+            self._m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def move(self, position):
+        pos = (c_float * 3)(*[float(v) for v in position])
+        c = (c_float * 2)(); s = (c_int * 2)(); a = (c_float * 2)()
+        self._l.gemo_move(self._m, pos, c, s, a)
+        return np.array(c[:], np.float32), np.array(s[:], np.int32), np.array(a[:], np.float32)
+
+    def pose(self):
+        m = self._m.contents
+        return np.array(m.center[:], np.float32), np.array(m.start[:], np.int32)
+
+    def points_to_index(self, x, y) -> int:
+        return self._l.gemo_points_to_index(self._m, c_float(x), c_float(y))
+
+    def points_to_map_index(self, x, y) -> int:
+        return self._l.gemo_points_to_map_index(self._m, c_float(x), c_float(y))
+
+    def process_points(self, frame, x, y, z, orig_index=None, write_back_xyz: bool = False):
+        n = int(np.asarray(x).size)
+        xa = np.array(x, np.float32, copy=True).reshape(-1); ya = np.array(y, np.float32, copy=True).reshape(-1)
+        za = np.array(z, np.float32, copy=True).reshape(-1)
+        oi = None if orig_index is None else np.ascontiguousarray(orig_index, np.int32)
+        out = {"index": np.empty(n, np.int32), "var": np.empty(n, np.float32), "x_ts": np.empty(n, np.float32),
+               "y_ts": np.empty(n, np.float32), "height": np.empty(n, np.float32)}
+        p = frame.to_struct(OFrame)
+        out["accepted"] = self._l.gemo_process_points(self._m, C.byref(p), n, _vp(xa), _vp(ya), _vp(za), _vp(oi),
+                                                      _vp(out["index"]), _vp(out["var"]), _vp(out["x_ts"]),
+                                                      _vp(out["y_ts"]), _vp(out["height"]))
+        if write_back_xyz:
+            out["x"], out["y"], out["z"] = xa, ya, za
+        return out
+
+    def _fuse(self, fn, index, height, var, R, G, B, intensity):
+        n = int(np.asarray(index).size)
+        c = lambda a, t: None if a is None else np.ascontiguousarray(a, t)
+        i, h, v = c(index, np.int32), c(height, np.float32), c(var, np.float32)
+        r, g, b, I = c(R, np.int32), c(G, np.int32), c(B, np.int32), c(intensity, np.float32)
+        fn(self._m, n, _vp(i), _vp(r), _vp(g), _vp(b), _vp(I), _vp(h), _vp(v))
+
+    def fuse(self, index, height, var, R=None, G=None, B=None, intensity=None):
+        self._fuse(self._l.gemo_fuse, index, height, var, R, G, B, intensity)
+
+    def fuse_literal(self, index, height, var, R=None, G=None, B=None, intensity=None):
+        self._fuse(self._l.gemo_fuse_literal, index, height, var, R, G, B, intensity)
+
+    def add(self, frame, xyzi, rgb=None, orig_index=None):
+        a = np.ascontiguousarray(xyzi, np.float32).reshape(-1, 4)
+        r = None if rgb is None else np.ascontiguousarray(rgb, np.uint32)
+        o = None if orig_index is None else np.ascontiguousarray(orig_index, np.int32)
+        counts = (c_longlong * 2)()
+        p = frame.to_struct(OFrame)
+        self._l.gemo_add(self._m, C.byref(p), a.shape[0], _vp(a), _vp(r), _vp(o), counts)
+        self.last_counts = (int(counts[0]), int(counts[1]))
+
+    def mapvar_update(self, u: float):
+        self._l.gemo_mapvar_update(self._m, c_float(u))
+
+    def layer(self, name: str) -> np.ndarray:
+        m = self._m.contents
+        n = self.length * self.length
+        if name == "lowest_scan_point":
+            name = "lowest"
+        if name in self.INT_LAYERS:
+            return np.ctypeslib.as_array(getattr(m, self.INT_LAYERS[name]), (n,)).reshape(self.length, self.length).copy()
+        return np.ctypeslib.as_array(getattr(m, name), (n,)).reshape(self.length, self.length).copy()
+
+    def set_layer(self, name: str, values):
+        m = self._m.contents
+        n = self.length * self.length
+        if name in self.INT_LAYERS:
+            np.ctypeslib.as_array(getattr(m, self.INT_LAYERS[name]), (n,))[:] = np.asarray(values, np.int32).reshape(-1)
+        else:
+            np.ctypeslib.as_array(getattr(m, name), (n,))[:] = np.asarray(values, np.float32).reshape(-1)
+
+
+class OracleMotion:
+    def __init__(self, covariance_scale: float = 1.0):
+        self._l = lib()
+        self._s = OMotion()
+        self._l.gemo_motion_init(C.byref(self._s), covariance_scale)
+
+    def compute(self, position, R_IB, cov6x6, map_rotation=None) -> float:
+        d = lambda a, n: (c_double * n)(*np.asarray(a, np.float64).reshape(-1).tolist())
+        Rm = np.eye(3) if map_rotation is None else map_rotation
+        return float(self._l.gemo_motion_update(C.byref(self._s), d(position, 3), d(R_IB, 9), d(cov6x6, 36), d(Rm, 9)))

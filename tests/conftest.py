@@ -1,0 +1,46 @@
+"""pytest configuration: `gpu` marker + shared fixtures.
+
+CPU tests (-m "not gpu") cover the oracle against its known-answer tests and golden fixtures, the
+host logic, and that libgem_hip.so loads and exports every symbol of include/gem_hip.h.
+GPU tests (-m gpu) are the parity tests proper: HIP path vs oracle through the C ABI.
+"""
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "oracle"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
+
+
+def _has_gpu() -> bool:
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+HAS_GPU = _has_gpu()
+
+
+def pytest_collection_modifyitems(config, items):
+    if HAS_GPU:
+        return
+    skip = pytest.mark.skip(reason="no HIP device in this environment")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    import oracle as om
+    om.build()
+    return om

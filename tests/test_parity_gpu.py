@@ -1,0 +1,280 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Bar (BASELINE.json north_star): cell indices bit-exact; fused height / variance within
+1e-5 relative.  The kernels replay the oracle's float operations in the same order with FMA
+contraction off, so most comparisons are in fact checked for exact equality.
+"""
+import numpy as np
+import pytest
+
+from gem_amd import ElevationMap, Frame, RejectFilter, SensorModel, synth
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+REL_TOL = 1e-5          # north_star: "fused height/variance within 1e-5 relative"
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(a.astype(np.float64) - b) / np.maximum(np.abs(b.astype(np.float64)), 1e-30)))
+
+
+def assert_maps_match(gpu, ref, exact=True, layers=("elevation", "variance")):
+    for name in layers:
+        g, o = gpu.layer(name), ref.layer(name)
+        if name == "elevation":
+            assert np.array_equal(g == -10, o == -10), "set of non-empty cells differs"
+        if exact:
+            bad = np.flatnonzero(g.ravel() != o.ravel())
+            assert bad.size == 0, f"{name}: {bad.size} cells differ, first {bad[:5]}, gpu {g.ravel()[bad[:5]]} oracle {o.ravel()[bad[:5]]}"
+        else:
+            assert rel_err(g, o) <= REL_TOL, f"{name}: rel err {rel_err(g, o)}"
+
+
+def make_pair(oracle_mod, L, res, **kw):
+    return ElevationMap(L, res, **kw), oracle_mod.OracleMap(L, res, **kw)
+
+
+# ---- Process_points -------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", ["c1", "c2", "c2_filter"])
+def test_process_points_parity(oracle_mod, cfg):
+    wl = {"c1": synth.config_c1, "c2": synth.config_c2, "c2_filter": lambda: synth.config_c2(reference_filter=True)}[cfg]()
+    gpu, ref = make_pair(oracle_mod, wl.length, wl.resolution)
+    c = wl.clouds[0]
+    g = gpu.process_points(wl.frames[0], c[:, 0], c[:, 1], c[:, 2], write_back_xyz=True)
+    o = ref.process_points(wl.frames[0], c[:, 0], c[:, 1], c[:, 2], write_back_xyz=True)
+    assert np.array_equal(g["index"], o["index"])                   # bit-exact cell indices
+    for k in ("var", "x_ts", "y_ts", "height", "x", "y", "z"):
+        assert np.array_equal(g[k], o[k]), k
+    frac_in = float((o["index"] >= 0).mean())
+    assert 0.05 < frac_in < 1.0                                     # both branches exercised
+
+
+def test_process_points_moved_map_and_odd_length(oracle_mod):
+    gpu, ref = make_pair(oracle_mod, 75, 0.2)                       # kitti_demo_map.yaml geometry (odd L)
+    for m in (gpu, ref):
+        m.move([1.3, -2.9, 0.0])
+    c = synth.random_cloud(3, 20000, 9.0)
+    f = synth._frame_for(synth.pose_matrix(0.2, 0.1, 0.5, 0.3, 0.02, -0.01), SensorModel.velodyne())
+    g = gpu.process_points(f, c[:, 0], c[:, 1], c[:, 2]); o = ref.process_points(f, c[:, 0], c[:, 1], c[:, 2])
+    assert np.array_equal(g["index"], o["index"]) and np.array_equal(g["var"], o["var"])
+
+
+def test_process_points_nonfinite_inputs(oracle_mod):
+    gpu, ref = make_pair(oracle_mod, 200, 0.1)
+    f = synth.config_c1().frames[0]
+    f.lower, f.upper = -np.inf, np.inf
+    x = np.array([np.nan, np.inf, -np.inf, 1e38, 1.0, 0.0], F32)
+    y = np.array([0, 0, 0, 0, np.nan, 3e38], F32); z = np.zeros(6, F32)
+    g = gpu.process_points(f, x, y, z); o = ref.process_points(f, x, y, z)
+    assert np.array_equal(g["index"], o["index"]) and np.all(g["index"] == -1)
+
+
+@pytest.mark.parametrize("model", ["structured_light", "stereo", "perfect"])
+def test_other_noise_models(oracle_mod, model):
+    gpu, ref = make_pair(oracle_mod, 400, 0.025)
+    wl = synth.config_c3()
+    f = wl.frames[0]
+    if model == "structured_light":
+        f.model = SensorModel.realsense_d435()
+    elif model == "stereo":
+        f.model = SensorModel(2, (0.1, 0.001, 380.0, 1.0, 0.002, 0.001, 30.0), original_width=640)
+    else:
+        f.model = SensorModel.perfect()
+    c = wl.clouds[0][:50000]
+    oi = wl.orig_index[:50000]
+    g = gpu.process_points(f, c[:, 0], c[:, 1], c[:, 2], orig_index=oi); o = ref.process_points(f, c[:, 0], c[:, 1], c[:, 2], orig_index=oi)
+    assert np.array_equal(g["index"], o["index"])
+    assert rel_err(g["var"][o["index"] >= 0], o["var"][o["index"] >= 0]) <= 1e-5     # double pow()/sqrt() may differ in the last ulp
+
+
+# ---- the fused add path -----------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", ["c1", "c2", "c2_filter", "c3"])
+def test_add_parity(oracle_mod, cfg):
+    wl = {"c1": synth.config_c1, "c2": synth.config_c2, "c2_filter": lambda: synth.config_c2(reference_filter=True),
+          "c3": synth.config_c3}[cfg]()
+    gpu, ref = make_pair(oracle_mod, wl.length, wl.resolution)
+    if wl.map_position is not None:
+        for m in (gpu, ref):
+            m.move(wl.map_position)
+    gpu.set_counting(True)
+    for rep in range(2):                       # 2nd pass: non-empty cells, Kalman / Mahalanobis branches
+        gpu.add(wl.frames[0], wl.clouds[0]); ref.add(wl.frames[0], wl.clouds[0])
+        st = gpu.stats()
+        assert st["cells_touched"] == ref.last_counts[1]
+        assert_maps_match(gpu, ref)
+    assert ref.last_counts[1] > 1000
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 255, 257, 4097])
+def test_add_ragged_sizes(oracle_mod, n):
+    gpu, ref = make_pair(oracle_mod, 64, 0.1)
+    c = synth.random_cloud(n + 5, max(n, 1), 3.5)[:n]
+    f = synth._frame_for(np.eye(4), SensorModel.velodyne())
+    gpu.add(f, c); ref.add(f, c)
+    assert_maps_match(gpu, ref)
+    gpu.add(f, c[::-1].copy()); ref.add(f, c[::-1].copy())
+    assert_maps_match(gpu, ref)
+
+
+def test_add_heavy_collisions(oracle_mod):
+    # 200k points into a 40x40 map: ~125 points per cell on average, long in-order chains, several tile batches
+    gpu, ref = make_pair(oracle_mod, 40, 0.1)
+    c = synth.random_cloud(21, 200_000, 2.2, z_sigma=0.05)
+    f = synth._frame_for(np.eye(4), SensorModel.velodyne())
+    gpu.add(f, c); ref.add(f, c)
+    assert_maps_match(gpu, ref)
+
+
+def test_add_single_cell_chain(oracle_mod):
+    # every point in ONE cell: the pure sequential recurrence (order must be the input order)
+    gpu, ref = make_pair(oracle_mod, 32, 0.1)
+    rng = np.random.default_rng(5)
+    n = 10_000
+    c = np.zeros((n, 4), F32); c[:, 0] = 0.31 + rng.uniform(0, 0.05, n); c[:, 1] = -0.72 + rng.uniform(0, 0.05, n)
+    c[:, 2] = rng.normal(0, 0.05, n)
+    f = synth._frame_for(np.eye(4), SensorModel.velodyne())
+    gpu.add(f, c); ref.add(f, c)
+    assert ref.last_counts[1] <= 4
+    assert_maps_match(gpu, ref)
+
+
+def test_add_all_rejected(oracle_mod):
+    gpu, ref = make_pair(oracle_mod, 64, 0.1)
+    c = synth.random_cloud(2, 1000, 3.0)
+    f = synth._frame_for(np.eye(4), SensorModel.velodyne()); f.lower, f.upper = 50.0, 60.0
+    gpu.add(f, c); ref.add(f, c)
+    assert_maps_match(gpu, ref)                      # floor pass still ran: variance -10 -> 1e-4 everywhere
+    assert np.all(gpu.layer("variance") == F32(1e-4))
+
+
+def test_add_with_rgb_and_intensity(oracle_mod):
+    gpu, ref = make_pair(oracle_mod, 100, 0.1)
+    rng = np.random.default_rng(9)
+    c = synth.random_cloud(9, 60000, 5.5)            # intensity in {0,1,2,3}
+    rgb = (rng.integers(0, 3, (60000, 3)) * 100).astype(np.uint32)     # zeros are common
+    packed = (rgb[:, 0] << 16) | (rgb[:, 1] << 8) | rgb[:, 2]
+    f = synth._frame_for(np.eye(4), SensorModel.velodyne())
+    for _ in range(2):
+        gpu.add(f, c, rgb=packed); ref.add(f, c, rgb=packed)
+        assert_maps_match(gpu, ref, layers=("elevation", "variance", "intensity", "color_r", "color_g", "color_b"))
+    assert (ref.layer("color_r") != 0).sum() > 100
+
+
+# ---- Fuse with the reference's host arrays ----------------------------------------------------------------
+def test_fuse_arrays_parity(oracle_mod):
+    gpu, ref = make_pair(oracle_mod, 50, 0.1)
+    rng = np.random.default_rng(13)
+    n = 30000
+    idx = rng.integers(-1, 2500 + 5, n).astype(np.int32)             # includes -1 and out-of-range indices
+    h = rng.normal(0, 0.2, n).astype(F32); h[rng.integers(0, n, 50)] = -1.0      # the h == -1 sentinel (GPU:482)
+    v = rng.uniform(1e-6, 2e-3, n).astype(F32)
+    R, G, B = (rng.integers(0, 3, n).astype(np.int32) * 90 for _ in range(3))
+    I = rng.integers(0, 2, n).astype(F32)
+    for _ in range(2):
+        gpu.fuse(idx, h, v, R, G, B, I); ref.fuse(idx, h, v, R, G, B, I)
+        assert_maps_match(gpu, ref, layers=("elevation", "variance", "intensity", "color_r", "color_g", "color_b"))
+    gpu.fuse(idx, h, v); ref.fuse(idx, h, v)                         # without attribute arrays
+    assert_maps_match(gpu, ref)
+
+
+def test_process_then_fuse_equals_add(oracle_mod):
+    wl = synth.config_c2()
+    a = ElevationMap(wl.length, wl.resolution); b = ElevationMap(wl.length, wl.resolution)
+    c = wl.clouds[0]
+    a.add(wl.frames[0], c)
+    out = b.process_points(wl.frames[0], c[:, 0], c[:, 1], c[:, 2])
+    b.fuse(out["index"], out["height"], out["var"])
+    assert np.array_equal(a.layer("elevation"), b.layer("elevation")) and np.array_equal(a.layer("variance"), b.layer("variance"))
+
+
+# ---- Move + Mapvar_update interleavings -------------------------------------------------------------------------
+def test_move_and_add_sequence(oracle_mod):
+    gpu, ref = make_pair(oracle_mod, 120, 0.1)       # simple_demo_map.yaml geometry
+    rng = np.random.default_rng(17)
+    pos = np.zeros(3)
+    for k in range(12):
+        pos = pos + np.array([rng.normal(0.4, 0.3), rng.normal(-0.2, 0.3), 0.0])
+        if k == 7:
+            pos = pos + np.array([30.0, 0, 0])       # jump > map size: whole-map clear
+        rg, ro = gpu.move(pos), ref.move(pos)
+        for x, y in zip(rg, ro):
+            assert np.array_equal(x, y)
+        T = synth.pose_matrix(pos[0], pos[1], 0.8, 0.2 * k, 0.01, 0.0)
+        c = synth.lidar_sweep(np.random.default_rng(100 + k), T, beams=16, azimuth_steps=512, max_range=30.0)
+        f = synth._frame_for(T, SensorModel.velodyne())
+        gpu.mapvar_update(2e-6 * k); ref.mapvar_update(2e-6 * k)
+        gpu.add(f, c); ref.add(f, c)
+        assert_maps_match(gpu, ref)
+
+
+def test_mapvar_update_queue_semantics(oracle_mod):
+    gpu, ref = make_pair(oracle_mod, 64, 0.1)
+    f = synth._frame_for(np.eye(4), SensorModel.velodyne())
+    c = synth.random_cloud(4, 5000, 3.0)
+    for m in (gpu, ref):
+        m.mapvar_update(0.5)                          # before any fuse: no-op (all -10)
+        m.add(f, c)
+        for u in (1e-5, 2e-5, 3e-5, 4e-5, 5e-5, 6e-5):   # more than the 4-deep queue
+            m.mapvar_update(u)
+    assert_maps_match(gpu, ref)                       # get_layer flushes the queue
+    for m in (gpu, ref):
+        m.mapvar_update(-3e-4)                        # pushes variances under the floor ...
+        m.add(f, c[:10])                              # ... the next Fuse repairs every cell
+    assert_maps_match(gpu, ref)
+    for m in (gpu, ref):
+        m.mapvar_update(1e-5); m.move([0.5, 0.0, 0.0]); m.mapvar_update(2e-5)
+        m.add(f, c)
+    assert_maps_match(gpu, ref)
+
+
+def test_set_get_layers_and_gridmap_layout(oracle_mod):
+    from gem_amd import _lib
+    gpu, ref = make_pair(oracle_mod, 48, 0.1)
+    f = synth._frame_for(np.eye(4), SensorModel.velodyne())
+    c = synth.random_cloud(8, 3000, 2.0)
+    gpu.add(f, c); ref.add(f, c)
+    e = gpu.layer("elevation")
+    gm = gpu.layer("elevation", layout=_lib.LAYOUT_GRIDMAP_COLMAJOR_NAN)
+    assert np.array_equal(np.isnan(gm), e == -10) and np.array_equal(gm[e != -10], e[e != -10])
+    new_e = np.where(e == -10, e, e + 1.0).astype(F32)
+    gpu.set_layer("elevation", new_e); ref.set_layer("elevation", new_e)
+    gpu.add(f, c); ref.add(f, c)
+    assert_maps_match(gpu, ref)
+
+
+# ---- batched sweeps (BASELINE config 4) -------------------------------------------------------------------------------
+def test_add_batch_parity(oracle_mod):
+    import torch
+    wl = synth.config_c4(n_sweeps=5)
+    gpu, ref = make_pair(oracle_mod, wl.length, wl.resolution)
+    sizes = [131072, 100000, 7, 0, 131072]
+    clouds = [c[:n] for c, n in zip(wl.clouds, sizes)]
+    offsets = np.concatenate([[0], np.cumsum(sizes)])
+    d = torch.from_numpy(np.concatenate(clouds, 0)).to("cuda:0")
+    gpu.mapvar_update(7e-6); ref.mapvar_update(7e-6)
+    gpu.add_batch(wl.frames, d, offsets, wl.var_updates)
+    for k in range(5):
+        ref.mapvar_update(wl.var_updates[k]); ref.add(wl.frames[k], clouds[k])
+    assert_maps_match(gpu, ref)
+    # same thing as individual device-resident adds
+    gpu2 = ElevationMap(wl.length, wl.resolution)
+    gpu2.mapvar_update(7e-6)
+    for k in range(5):
+        gpu2.mapvar_update(wl.var_updates[k]); gpu2.add(wl.frames[k], d[offsets[k]:offsets[k + 1]])
+    assert np.array_equal(gpu2.layer("elevation"), gpu.layer("elevation")) and np.array_equal(gpu2.layer("variance"), gpu.layer("variance"))
+
+
+# ---- row strips (multi-GPU tiling on one device) ----------------------------------------------------------------------
+def test_row_strips_compose(oracle_mod):
+    wl = synth.config_c2()
+    L = wl.length
+    full, ref = make_pair(oracle_mod, L, wl.resolution)
+    full.add(wl.frames[0], wl.clouds[0]); ref.add(wl.frames[0], wl.clouds[0])
+    e = np.full((L, L), -10, F32); v = np.full((L, L), -10, F32)
+    bounds = [0, 150, 301, 450, 600]
+    for r0, r1 in zip(bounds[:-1], bounds[1:]):
+        part = ElevationMap(L, wl.resolution, strip=(r0, r1 - r0))
+        part.add(wl.frames[0], wl.clouds[0])
+        e[r0:r1] = part.layer("elevation")[r0:r1]; v[r0:r1] = part.layer("variance")[r0:r1]
+        pe = part.layer("elevation"); pe[r0:r1] = -10
+        assert np.all(pe == -10)                     # nothing outside the owned strip is written
+    assert np.array_equal(e, ref.layer("elevation")) and np.array_equal(v, ref.layer("variance"))
