@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- fused points/s of the GEM point-cloud -> elevation-grid hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one pass of the hot path over one batch of synthetic input: one 64-beam LiDAR sweep
+(64 x 2048 = 131 072 XYZI points, BASELINE.json configs[1]) projected, binned and Kalman-fused into
+the robot-centric 600 x 600 @ 0.05 m map with gem_add_device (inputs already resident in HBM).
+Steps cycle through 8 distinct seeded sweeps (moving sensor), so after the first steps the map is
+populated and the Kalman / Mahalanobis branches are the ones exercised.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling by spatial tiling --
+each step fuses N sweeps (N x 131 072 points); rank r owns storage-row strip r of the map, bins all
+N sweeps, fuses only its strip, and the strips are exchanged with an RCCL all-gather (xGMI) through
+the C ABI (gem_allgather_layers) every step.
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel (HIP-event timed on the
+stream it runs on, in a second timed loop), `cpu_baseline` the CPU oracle on this box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+N_DISTINCT = 8
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-oracle baseline budget (rank 0, N=1 only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def make_sweeps(n_sweeps: int):
+    from gem_amd import synth
+    wl = synth.config_c4(n_sweeps=n_sweeps, seed0=100)
+    return wl
+
+
+def cpu_baseline(wl, seconds: float):
+    """The CPU oracle (plain-C port of the reference semantics, 1 thread) on a bounded sample."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import oracle
+    ref = oracle.OracleMap(wl.length, wl.resolution)
+    pts, t0, k = 0, time.perf_counter(), 0
+    ref.add(wl.frames[0], wl.clouds[0])                      # warm-up / page-in
+    t0 = time.perf_counter()
+    while True:
+        i = k % len(wl.clouds)
+        ref.add(wl.frames[i], wl.clouds[i]); pts += wl.clouds[i].shape[0]; k += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
+    return {"value": pts / dt, "unit": "points/s", "cores": 1, "kind": "port",
+            "sample": f"{k} sweeps x 131072 pts of the same workload ({dt:.1f} s), oracle/gem_oracle.c gemo_add, 1 thread, "
+                      f"host has {os.cpu_count()} cores"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from gem_amd import ElevationMap
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if args.gpus != world and distributed:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        dist.init_process_group("nccl", device_id=dev)
+
+    wl = make_sweeps(N_DISTINCT)
+    n_per = wl.clouds[0].shape[0]
+    d_clouds = [torch.from_numpy(c).to(dev) for c in wl.clouds]
+    emap = ElevationMap(wl.length, wl.resolution, device=local_rank)
+
+    if distributed:
+        # bootstrap the C ABI's RCCL communicator: rank 0 creates the id, torch.distributed carries it
+        uid = [ElevationMap.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        emap.comm_init(uid[0], world, rank)
+
+    sweeps_per_step = world
+
+    def step(i: int):
+        for j in range(sweeps_per_step):
+            k = (i * sweeps_per_step + j) % N_DISTINCT
+            emap.add(wl.frames[k], d_clouds[k])
+        if distributed:
+            emap.allgather_layers(False)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        emap.synchronize()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_points = args.steps * sweeps_per_step * n_per
+    value = total_points / elapsed
+
+    # ---- roofline of the dominant kernel: HIP events around every kernel, same workload ------------
+    emap.set_timing(True); emap.set_counting(True)
+    emap.stats(reset=True)
+    cells = 0
+    for i in range(args.steps):
+        step(args.warmup + args.steps + i)
+        if i % 16 == 0:                       # sample the touched-cell counter (forces a sync)
+            cells = emap.stats()["cells_touched"]
+    st = emap.stats()
+    emap.set_timing(False); emap.set_counting(False)
+    us_bin = 1e3 * st["ms_bin"] / max(st["launches_bin"], 1)
+    us_fuse = 1e3 * st["ms_fuse"] / max(st["launches_fuse"], 1)
+    # algorithmic bytes per launch (B_alg = 16 N + 16 C_touched): k_bin reads one 16-byte
+    # XYZI record per point; k_fuse reads + writes elevation and variance once per touched cell.
+    alg_bin = 16.0 * n_per
+    alg_fuse = 16.0 * cells
+    if us_fuse >= us_bin:
+        dom, dom_us, dom_bytes = "k_fuse", us_fuse, alg_fuse
+    else:
+        dom, dom_us, dom_bytes = "k_bin", us_bin, alg_bin
+    achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "us_per_launch": {"k_bin": us_bin, "k_fuse": us_fuse},
+                "algorithmic_bytes_per_launch": {"k_bin": alg_bin, "k_fuse": alg_fuse},
+                "pipeline_GBps": (alg_bin + alg_fuse) / ((us_bin + us_fuse) * 1e-6) / 1e9 if us_bin + us_fuse > 0 else 0.0,
+                "note": "frame is ~3 MB: both kernels are launch/latency bound, see DESIGN.md"}
+
+    out = {
+        "metric": "fused points/sec into 600x600 grid; achieved HBM GB/s vs roofline",
+        "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C2: single 64-beam LiDAR sweep (64x2048 = 131072 XYZI pts) -> 600x600 @ 0.05 m grid, "
+                               "per step; 8 distinct seeded sweeps cycled; reject filter off",
+                   "points_per_step": sweeps_per_step * n_per, "grid": "600x600@0.05m",
+                   "parallelism": f"tile{world}" if distributed else "single",
+                   "cells_touched_per_sweep": cells},
+        "roofline": roofline,
+    }
+    if rank == 0 and not distributed and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out))
+    emap.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -78,7 +78,14 @@ def load(rebuild_if_stale: bool = True) -> C.CDLL:
     if _lib is not None:
         return _lib
     path = _build.build() if rebuild_if_stale else _build.LIB
-    lib = C.CDLL(str(path), mode=C.RTLD_GLOBAL)
+    # A process that also uses PyTorch must end up with ONE HIP runtime / RCCL: torch ships its own
+    # copies (torch/lib), and whichever libamdhip64 is mapped first serves both.  Import torch first
+    # so device pointers, streams and events are interchangeable between torch and libgem_hip.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    lib = C.CDLL(str(path))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export it
         fn.restype = res

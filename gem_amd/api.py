@@ -11,7 +11,10 @@ All compute happens in libgem_hip.so on the GPU; there is no CPU path here.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
+import sys
+import weakref
 from dataclasses import dataclass, field
 from typing import Optional, Sequence
 
@@ -30,6 +33,19 @@ _INT_LAYERS = {_lib.LAYER_COLOR_R, _lib.LAYER_COLOR_G, _lib.LAYER_COLOR_B}
 
 class GemError(RuntimeError):
     pass
+
+
+# handles still alive at interpreter exit are destroyed before the HIP runtime is torn down
+_live_maps: "weakref.WeakSet" = weakref.WeakSet()
+
+
+@atexit.register
+def _close_live_maps() -> None:
+    for m in list(_live_maps):
+        try:
+            m.close()
+        except Exception:
+            pass
 
 
 def _is_device_tensor(x) -> bool:
@@ -101,10 +117,18 @@ class Frame:
     B_r_BS_skew: np.ndarray = field(default_factory=lambda: np.zeros((3, 3), np.float32))
     filter: RejectFilter = field(default_factory=RejectFilter)
 
+    def __setattr__(self, name, value):
+        object.__setattr__(self, name, value)
+        if name != "_cache":
+            object.__setattr__(self, "_cache", {})
+
     def to_struct(self, cls=_lib.FrameParams):
         """Fill a ctypes struct with the gem_frame_params field layout (also used, with the oracle's
-        own struct class, by the tests)."""
-        p = cls()
+        own struct class, by the tests).  Cached until a field is reassigned."""
+        cache = self.__dict__.setdefault("_cache", {})
+        if cls in cache:
+            return cache[cls]
+        p = cache[cls] = cls()
         p.T[:] = np.asarray(self.T, np.float32).reshape(16).tolist()
         p.lower, p.upper = float(self.lower), float(self.upper)
         p.sensor_model = int(self.model.kind)
@@ -200,6 +224,7 @@ class ElevationMap:
         self._h = h
         self.length = int(length)
         self.resolution = float(resolution)
+        _live_maps.add(self)
 
     # -- plumbing ------------------------------------------------------------------------------
     def _check(self, rc: int, what: str) -> None:
@@ -212,6 +237,8 @@ class ElevationMap:
             self._h = None
 
     def __del__(self):
+        if sys.is_finalizing():          # too late to talk to the HIP runtime
+            return
         try:
             self.close()
         except Exception:

@@ -538,12 +538,13 @@ size_t fuse_lds_bytes(int ts, int r, int bpad)
 template <int TS, int R>
 static hipError_t launch_fuse_attr(hipStream_t st, const FuseArgs& a, int attr, size_t lds)
 {
-    static bool configured[3] = {false, false, false};
-    const void* fn = attr == 0 ? (const void*)k_fuse<TS, R, 0> : attr == 1 ? (const void*)k_fuse<TS, R, 1> : (const void*)k_fuse<TS, R, 2>;
-    if (!configured[attr]) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // more than 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel
+    static size_t configured[3] = {0, 0, 0};
+    if (lds > 64 * 1024 && lds > configured[attr]) {
+        const void* fn = attr == 0 ? (const void*)k_fuse<TS, R, 0> : attr == 1 ? (const void*)k_fuse<TS, R, 1> : (const void*)k_fuse<TS, R, 2>;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        configured[attr] = true;
+        configured[attr] = lds;
     }
     if (attr == 0)      hipLaunchKernelGGL((k_fuse<TS, R, 0>), dim3(a.T), dim3(256), lds, st, a);
     else if (attr == 1) hipLaunchKernelGGL((k_fuse<TS, R, 1>), dim3(a.T), dim3(256), lds, st, a);
