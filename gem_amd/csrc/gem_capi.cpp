@@ -69,7 +69,11 @@ struct gem_handle {
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
 
+    Arena dbg;          // optional k_fuse phase stamps
+    bool  dbg_on = false;
     int ipt_override = 0;
+    int fuse_variant = 0;
+    uint32_t epoch = 0;                // descriptor-table epoch of the last pass (0 = table holds no live words)
 };
 
 namespace {
@@ -123,8 +127,8 @@ void fill_frame(const gem_handle* h, const gem_frame_params* p, FrameConst& f)
 int choose_ipt(const gem_handle* h, long long n)
 {
     if (h->ipt_override == 1 || h->ipt_override == 2 || h->ipt_override == 4) return h->ipt_override;
-    if (n <= 65536) return 1;
-    if (n <= 262144) return 2;
+    if (n <= 524288) return 1;         // 64-point wave units (k_bin_wave)
+    if (n <= 1048576) return 2;
     return 4;
 }
 
@@ -211,7 +215,8 @@ int run_pipeline(gem_handle* h, const PassInput& in)
     int bpad = 0;
     for (int s = 0; s < in.n_sweeps; ++s) {
         const long long cnt = batched ? in.offsets[s + 1] - in.offsets[s] : in.n;
-        const long long units = (cnt + U - 1) / U;
+        long long units = (cnt + U - 1) / U;
+        units = (units + 3) & ~3ll;                 // descriptor rows are read 4 units (16 B) at a time
         if (units > 0x3fffffff) return fail(h, GEM_ERR_INVALID, "cloud too large");
         unit0[s + 1] = unit0[s] + (int)units;
         bpad = std::max(bpad, (int)units);
@@ -228,12 +233,26 @@ int run_pipeline(gem_handle* h, const PassInput& in)
             }
         return (h->n_pending || h->floor_dirty) ? flush_pending(h, true) : GEM_OK;
     }
-    if (fuse_lds_bytes(h->ts, h->ts == 5 ? kFuseR32 : kFuseR64, bpad) > 160 * 1024)
+    int attr = 0;
+    if (in.src == 0 && in.rgb) attr = 1;
+    if (in.src == 1 && in.f_R && in.f_G && in.f_B && in.f_I) attr = 2;
+    int nt, rr;
+    fuse_geometry(h->ts, h->fuse_variant, &nt, &rr);
+    if (fuse_lds_bytes(h->ts, nt, rr, bpad, attr) > 160 * 1024)
         return fail(h, GEM_ERR_INVALID, "too many units per sweep for one pass");
 
     int rc;
     if ((rc = ensure(h, h->rec, (size_t)B * U * sizeof(uint4)))) return rc;
-    if ((rc = ensure(h, h->seg, (size_t)h->T * B * sizeof(uint32_t)))) return rc;
+    {   // descriptor table: words are stamped with an epoch instead of being cleared every pass
+        const size_t need = (size_t)h->T * B * sizeof(uint32_t);
+        const bool grow = need > h->seg.cap;
+        if ((rc = ensure(h, h->seg, need))) return rc;
+        if (grow || h->epoch >= kSegEpochMax) {
+            GEM_HIP(h, hipMemsetAsync(h->seg.p, 0, h->seg.cap, h->stream));
+            h->epoch = 0;
+        }
+        ++h->epoch;
+    }
 
     BinArgs ba{};
     FuseArgs fa{};
@@ -266,13 +285,12 @@ int run_pipeline(gem_handle* h, const PassInput& in)
     ba.f_index = in.f_index; ba.f_height = in.f_height; ba.f_var = in.f_var;
     ba.f_R = in.f_R; ba.f_G = in.f_G; ba.f_B = in.f_B; ba.f_I = in.f_I;
     ba.T = h->T; ba.tiles_per_row = h->tiles_per_row; ba.B = B;
+    ba.tile_bits = 0; while ((1 << ba.tile_bits) < h->T) ++ba.tile_bits;
+    ba.epoch = h->epoch;
     ba.rec = static_cast<uint4*>(h->rec.p); ba.seg = static_cast<uint32_t*>(h->seg.p);
     ba.counters = h->counting ? h->d_counters : nullptr;
 
-    int attr = 0;
-    if (in.src == 0 && in.rgb) attr = 1;
-    if (in.src == 1 && in.f_R && in.f_G && in.f_B && in.f_I) attr = 2;
-
+    fa.epoch = h->epoch;
     fa.rec = ba.rec; fa.seg = ba.seg; fa.B_total = B; fa.U = U; fa.n_sweeps = in.n_sweeps; fa.Bpad = bpad;
     fa.T = h->T; fa.tiles_per_row = h->tiles_per_row; fa.L = h->L; fa.row0 = h->row0; fa.row1 = h->row1;
     fa.mahal = h->cfg.mahalanobis_threshold; fa.var_floor = h->cfg.variance_floor;
@@ -283,10 +301,16 @@ int run_pipeline(gem_handle* h, const PassInput& in)
     fa.intensity = h->layers.intensity; fa.colorR = h->layers.colorR; fa.colorG = h->layers.colorG; fa.colorB = h->layers.colorB;
     fa.xyzi = in.xyzi; fa.rgb = in.rgb; fa.f_R = in.f_R; fa.f_G = in.f_G; fa.f_B = in.f_B; fa.f_I = in.f_I;
     fa.counters = ba.counters;
+    fa.dbg = nullptr;
+    if (h->dbg_on) {
+        if ((rc = ensure(h, h->dbg, (size_t)h->T * 16 * 8))) return rc;
+        GEM_HIP(h, hipMemsetAsync(h->dbg.p, 0, (size_t)h->T * 16 * 8, h->stream));
+        fa.dbg = static_cast<unsigned long long*>(h->dbg.p);
+    }
 
     if (h->counting) GEM_HIP(h, hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
     { Timed t(h, 0); GEM_HIP(h, launch_bin(h->stream, ba, ipt, in.src, h->ts)); }
-    { Timed t(h, 1); GEM_HIP(h, launch_fuse(h->stream, fa, h->ts, attr)); }
+    { Timed t(h, 1); GEM_HIP(h, launch_fuse(h->stream, fa, h->ts, attr, h->fuse_variant)); }
     h->n_pending = 0;
     h->floor_dirty = false;
     h->stats.points_in = in.n;
@@ -329,7 +353,8 @@ int gem_create(const gem_map_config* cfg, gem_handle** out)
         h->row0 = cfg->strip_row0; h->row1 = cfg->strip_row0 + cfg->strip_rows;
     }
     h->ts = h->L <= 1024 ? 5 : 6;
-    if (const char* s = getenv("GEM_TILE_SHIFT")) { int v = atoi(s); if (v == 5 || v == 6) h->ts = v; }
+    if (const char* s = getenv("GEM_TILE_SHIFT")) { int v = atoi(s); if (v >= 4 && v <= 6) h->ts = v; }
+    if (const char* s = getenv("GEM_FUSE_VARIANT")) h->fuse_variant = atoi(s);
     if (const char* s = getenv("GEM_IPT")) h->ipt_override = atoi(s);
     const int te = 1 << h->ts;
     h->tiles_per_row = (h->L + te - 1) / te;
@@ -370,7 +395,7 @@ void gem_destroy(gem_handle* h)
     for (auto& ep : h->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
     if (h->layers.elevation) hipFree(h->layers.elevation);      // base of the single layer allocation
     if (h->d_counters) hipFree(h->d_counters);
-    for (Arena* a : {&h->stage, &h->rec, &h->seg, &h->tables, &h->scratch}) if (a->p) hipFree(a->p);
+    for (Arena* a : {&h->stage, &h->rec, &h->seg, &h->tables, &h->scratch, &h->dbg}) if (a->p) hipFree(a->p);
     if (h->copy_done) hipEventDestroy(h->copy_done);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
@@ -683,6 +708,22 @@ int gem_get_stats(gem_handle* h, gem_stats* out, int reset)
     *out = h->stats;
     if (reset) { const long long pin = h->stats.points_in; h->stats = gem_stats{}; h->stats.points_in = pin; }
     return GEM_OK;
+}
+
+// profiling aid (not part of the drop-in surface): per-tile cycle stamps of the last k_fuse launch
+int gem_debug_fuse_stamps(gem_handle* h, int enable, unsigned long long* out, int max_tiles)
+{
+    if (!h) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    h->dbg_on = enable != 0;
+    if (out && h->dbg.p) {
+        GEM_HIP(h, hipStreamSynchronize(h->stream));
+        const int n = max_tiles < h->T ? max_tiles : h->T;
+        GEM_HIP(h, hipMemcpy(out, h->dbg.p, (size_t)n * 16 * 8, hipMemcpyDeviceToHost));
+        return n;
+    }
+    return 0;
 }
 
 // ---- RCCL: all-gather of the fused row strips over xGMI -------------------------------------------

@@ -166,19 +166,24 @@ __device__ __forceinline__ Projected project_point(const FrameConst& f, float x,
 
 // The per-cell recurrence of G_fuse (GPU:484-529) on register state (e, s).  Returns true when the
 // point was "taken" (colour / intensity of this point may overwrite the cell's, GPU:487-494 etc.).
+// Straight-line form: the Mahalanobis quotient and the two Kalman quotients are independent
+// correctly-rounded divisions, so all three are issued together and the reference's three-way
+// branch becomes a select.  Every value that is kept is computed by exactly the reference's
+// expression (GPU:502, 518, 519); discarded lanes may hold inf / NaN, which is harmless.
 __device__ __forceinline__ bool fuse_step(float& e, float& s, float h, float v, float mahal_thr, float var_floor)
 {
-    if (e == kEmptyElevation) { e = h; s = v; return true; }                       // GPU:484-486
-    if (s < var_floor) s = var_floor;                                              // GPU:500-501
-    const float m = fabsf(h - e) / sqrtf(s);                                       // GPU:502
-    if (m > mahal_thr) {                                                           // GPU:504
-        if (e < h) { e = h; s = v; return true; }                                  // GPU:505-507
-        return false;
-    }
-    const float en = (s * h + v * e) / (s + v);                                    // GPU:518
-    s = (v * s) / (v + s);                                                         // GPU:519
-    e = en;
-    return true;
+    const bool empty = e == kEmptyElevation;                                       // GPU:484
+    const float sf = s < var_floor ? var_floor : s;                                // GPU:500-501 (written back)
+    const float m  = fabsf(h - e) / sqrtf(sf);                                     // GPU:502
+    const float en = (sf * h + v * e) / (sf + v);                                  // GPU:518
+    const float sn = (v * sf) / (v + sf);                                          // GPU:519
+    const bool outlier = m > mahal_thr;                                            // GPU:504
+    const bool replace = empty || (outlier && e < h);                              // GPU:484-486, 505-507
+    const bool fuse = !empty && !outlier;
+    const float e_new = replace ? h : (fuse ? en : e);
+    const float s_new = replace ? v : (fuse ? sn : sf);
+    e = e_new; s = s_new;
+    return replace || fuse;
 }
 
 } // namespace gem

@@ -33,27 +33,48 @@ __device__ __forceinline__ uint64_t lanemask_lt()
     return l == 0 ? 0ull : (~0ull >> (64 - l));
 }
 
+// Wave-wide inclusive scans on the DPP network (row_shr within rows of 16 lanes, then row_bcast
+// across rows): six VALU instructions instead of six LDS-crossbar permutes.
+#define GEM_DPP(old, src, ctrl, rowmask) \
+    (uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(src), (ctrl), (rowmask), 0xf, false)
+
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
 {
-    const int l = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(v, d, 64);
-        if (l >= d) v += t;
-    }
+    v += GEM_DPP(0, v, 0x111, 0xf);      // row_shr:1
+    v += GEM_DPP(0, v, 0x112, 0xf);      // row_shr:2
+    v += GEM_DPP(0, v, 0x114, 0xf);      // row_shr:4
+    v += GEM_DPP(0, v, 0x118, 0xf);      // row_shr:8
+    v += GEM_DPP(0, v, 0x142, 0xa);      // row_bcast:15 -> rows 1 and 3
+    v += GEM_DPP(0, v, 0x143, 0xc);      // row_bcast:31 -> rows 2 and 3
     return v;
 }
 
-// exclusive scan over a 256-thread block; scratch = 5 uint32 in LDS.  Returns prefix, *total = block sum.
-__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* scratch, uint32_t* total)
+__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v)    // identity 0
 {
+    v = max(v, GEM_DPP(0, v, 0x111, 0xf));
+    v = max(v, GEM_DPP(0, v, 0x112, 0xf));
+    v = max(v, GEM_DPP(0, v, 0x114, 0xf));
+    v = max(v, GEM_DPP(0, v, 0x118, 0xf));
+    v = max(v, GEM_DPP(0, v, 0x142, 0xa));
+    v = max(v, GEM_DPP(0, v, 0x143, 0xc));
+    return v;
+}
+
+// value of the previous lane (0 for lane 0): wave_shr:1
+__device__ __forceinline__ uint32_t wave_prev(uint32_t v) { return GEM_DPP(0, v, 0x138, 0xf); }
+
+// exclusive scan over an NT-thread block (NT/64 <= 16 waves); scratch = 16 uint32 in LDS.
+template <int NT>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* scratch, uint32_t* total)
+{
+    constexpr int NW = NT / 64;
     const int w = (int)(threadIdx.x >> 6);
     const uint32_t inc = wave_inclusive_scan(v);
     if (lane_id() == 63) scratch[w] = inc;
     __syncthreads();
     uint32_t base = 0, tot = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NW; ++i) {
         const uint32_t s = scratch[i];
         if (i < w) base += s;
         tot += s;
@@ -63,28 +84,18 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
     return base + inc - v;
 }
 
-// Stable rank of each valid lane among the lanes holding the same key, plus a running base kept
-// in an LDS table: pos = table[key]++ applied in lane order.  Iterates once per DISTINCT key in
-// the wave (<= 64), independent of how many lanes share a key.  All table traffic goes through
-// the group's leader lane, so there is no intra-wave race.
-__device__ __forceinline__ uint32_t wave_stable_place(bool valid, uint32_t key, uint32_t* table)
+// "match-any" on a 64-lane wave: the mask of valid lanes holding the same key as this lane,
+// from one ballot per key bit (no loop over distinct keys, no LDS, no divergence).
+// rank among equal keys in lane order = popc(peers & lanemask_lt); group size = popc(peers).
+__device__ __forceinline__ uint64_t wave_peers(bool valid, uint32_t key, int nbits)
 {
-    const int l = lane_id();
-    const uint64_t lt = lanemask_lt();
-    uint64_t remaining = __ballot(valid);
-    uint32_t pos = 0;
-    while (remaining) {                                   // wave-uniform loop
-        const int leader = __ffsll((unsigned long long)remaining) - 1;
-        const uint32_t k0 = (uint32_t)__shfl((int)key, leader, 64);
-        const bool mine = valid && key == k0;
-        const uint64_t m = __ballot(mine);
-        uint32_t b = 0;
-        if (l == leader) { b = table[k0]; table[k0] = b + (uint32_t)__popcll(m); }
-        b = (uint32_t)__shfl((int)b, leader, 64);
-        if (mine) pos = b + (uint32_t)__popcll(m & lt);
-        remaining &= ~m;
+    uint64_t peers = __ballot(valid);
+    for (int b = 0; b < nbits; ++b) {                     // wave-uniform trip count
+        const bool bit = (key >> b) & 1u;
+        const uint64_t m = __ballot(bit);
+        peers &= bit ? m : ~m;
     }
-    return pos;
+    return valid ? peers : 0ull;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -103,10 +114,89 @@ __global__ __launch_bounds__(256) void k_project(FrameConst fc, int n, float* __
 }
 
 // ------------------------------------------------------------------------------------------
-// k_bin
+// k_bin_wave : one WAVE = one unit of 64 consecutive points.  No LDS, no loops, no barriers.
+// ------------------------------------------------------------------------------------------
+// Descriptor word of (tile, unit):  epoch << 17 | start << 9 | count.  Only the tiles a unit
+// actually touches are written; stale words are recognised by their epoch, so the table is
+// never cleared between frames.
+template <int SRC, int TS, bool BATCH>
+__global__ __launch_bounds__(256) void k_bin_wave(BinArgs a)
+{
+    constexpr int TE = 1 << TS;
+    constexpr int U = 64;
+    const int lane = lane_id();
+    const int unit = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (unit >= a.B) return;                               // whole wave leaves together
+
+    int sweep = 0;
+    long long base, sweep_begin = 0, sweep_end = a.n;
+    if (BATCH) {
+        int lo = 0, hi = a.n_sweeps;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.sweep_unit0[mid] <= unit) lo = mid; else hi = mid; }
+        sweep = lo;
+        sweep_begin = a.sweep_first[sweep]; sweep_end = a.sweep_first[sweep + 1];
+        base = sweep_begin + (long long)(unit - a.sweep_unit0[sweep]) * U;
+    } else {
+        base = (long long)unit * U;
+    }
+    const FrameConst fc = BATCH ? a.frames[sweep] : a.frame0;
+    const long long i = base + lane;
+
+    bool valid = false;
+    uint32_t tile = 0, cl = 0, src = 0; float hh = 0.0f, vv = 0.0f;
+    if (i < sweep_end) {
+        int cell; float h, v; bool colour_ok = false;
+        if (SRC == 0) {
+            const float4 p = a.xyzi[i];
+            const Projected r = project_point(fc, p.x, p.y, p.z, a.orig ? a.orig[i] : (int)(i - sweep_begin));
+            cell = r.cell; h = r.h; v = r.var;
+            if (a.rgb) {
+                const uint32_t c = a.rgb[i];
+                colour_ok = ((c >> 16) & 0xff) != 0 && ((c >> 8) & 0xff) != 0 && (c & 0xff) != 0 && p.w != 0.0f;
+            }
+        } else {
+            cell = a.f_index[i]; h = a.f_height[i]; v = a.f_var[i];
+            if (cell >= fc.L * fc.L) cell = -1;
+            if (a.f_R) colour_ok = a.f_R[i] != 0 && a.f_G[i] != 0 && a.f_B[i] != 0 && a.f_I[i] != 0.0f;
+        }
+        // GPU:482: "point_index[i] != map_index || points_h[i] == -1" -> the point is skipped
+        if (cell >= 0 && h != -1.0f) {
+            const int row = cell / fc.L, col = cell - row * fc.L;
+            if (row >= fc.row0 && row < fc.row1) {
+                valid = true;
+                tile = (uint32_t)((row >> TS) * a.tiles_per_row + (col >> TS));
+                cl = (uint32_t)(((row & (TE - 1)) << TS) | (col & (TE - 1))) | (colour_ok ? 0x80000000u : 0u);
+                hh = h; vv = v; src = (uint32_t)i;
+            }
+        }
+    }
+
+    // group the wave's points by tile, stable in lane (= input) order
+    const uint64_t peers = wave_peers(valid, tile, a.tile_bits);
+    const uint64_t lt = lanemask_lt();
+    const uint32_t rank = (uint32_t)__popcll(peers & lt);
+    const uint32_t cnt = (uint32_t)__popcll(peers);
+    const bool leader = valid && rank == 0;
+    const uint32_t x = leader ? cnt : 0u;
+    const uint32_t start_leader = wave_inclusive_scan(x) - x;       // groups laid out in order of first appearance
+    const int my_leader = valid ? (__ffsll((unsigned long long)peers) - 1) : lane;
+    const uint32_t start = (uint32_t)__shfl((int)start_leader, my_leader, 64);
+    if (valid) a.rec[(size_t)unit * U + start + rank] = make_uint4(cl, __float_as_uint(hh), __float_as_uint(vv), src);
+    if (leader) a.seg[(size_t)tile * a.B + unit] = (a.epoch << kSegEpochShift) | (start << kSegCountBits) | cnt;
+
+    if (a.counters) {
+        const uint32_t nb = (uint32_t)__popcll(__ballot(valid));
+        if (lane == 0 && nb) atomicAdd(&a.counters[0], (unsigned long long)nb);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_bin_lds : one WAVE = one unit of 64*IPT points (IPT = 2, 4); per-tile counts in LDS so that a
+// tile's points from all chunks of the unit land contiguously.  Used for larger clouds, where
+// 64-point units would make the (tile x unit) descriptor table too big.
 // ------------------------------------------------------------------------------------------
 template <int IPT, int SRC, int TS, bool BATCH>
-__global__ __launch_bounds__(64) void k_bin(BinArgs a)
+__global__ __launch_bounds__(64) void k_bin_lds(BinArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_cnt[];      // [T]
     constexpr int TE = 1 << TS;
@@ -115,7 +205,6 @@ __global__ __launch_bounds__(64) void k_bin(BinArgs a)
     const int unit = (int)blockIdx.x;
     const int T = a.T;
 
-    // which sweep does this unit belong to, and which points does it cover
     int sweep = 0;
     long long base, sweep_begin = 0, sweep_end = a.n;
     if (BATCH) {
@@ -158,8 +247,7 @@ __global__ __launch_bounds__(64) void k_bin(BinArgs a)
                 if (cell >= fc.L * fc.L) cell = -1;
                 if (a.f_R) colour_ok = a.f_R[i] != 0 && a.f_G[i] != 0 && a.f_B[i] != 0 && a.f_I[i] != 0.0f;
             }
-            // GPU:482: "point_index[i] != map_index || points_h[i] == -1" -> the point is skipped
-            if (cell >= 0 && h != -1.0f) {
+            if (cell >= 0 && h != -1.0f) {                       // GPU:482
                 const int row = cell / fc.L, col = cell - row * fc.L;
                 if (row >= fc.row0 && row < fc.row1) {
                     tile[j] = (uint32_t)((row >> TS) * a.tiles_per_row + (col >> TS));
@@ -185,7 +273,7 @@ __global__ __launch_bounds__(64) void k_bin(BinArgs a)
         if (t < T) {
             const uint32_t c = lds_cnt[t];
             lds_cnt[t] = run;                                       // becomes the running base of tile t
-            seg[(size_t)t * a.B + unit] = run | (c << 16);          // start (16 bit) | count (16 bit)
+            if (c) seg[(size_t)t * a.B + unit] = (a.epoch << kSegEpochShift) | (run << kSegCountBits) | c;
             run += c;
         }
     }
@@ -193,11 +281,19 @@ __global__ __launch_bounds__(64) void k_bin(BinArgs a)
 
     // stable placement, chunk by chunk in input order, into this unit's slice of the arena
     uint4* rec = a.rec + (size_t)unit * U;
+    const uint64_t lt = lanemask_lt();
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
         const bool valid = tile[j] != (uint32_t)kInvalidTile;
-        const uint32_t pos = wave_stable_place(valid, tile[j], lds_cnt);
-        if (valid) rec[pos] = make_uint4(cl[j], __float_as_uint(hh[j]), __float_as_uint(vv[j]), src[j]);
+        const uint64_t peers = wave_peers(valid, tile[j], a.tile_bits);
+        const uint32_t rank = (uint32_t)__popcll(peers & lt);
+        uint32_t old = 0;
+        if (valid) {
+            old = lds_cnt[tile[j]];                                  // same address within a group: broadcast
+            if (rank == 0) lds_cnt[tile[j]] = old + (uint32_t)__popcll(peers);
+            rec[old + rank] = make_uint4(cl[j], __float_as_uint(hh[j]), __float_as_uint(vv[j]), src[j]);
+        }
+        __syncthreads();                                             // one wave: orders the LDS update before the next chunk's reads
     }
 
     if (a.counters) {
@@ -209,31 +305,33 @@ __global__ __launch_bounds__(64) void k_bin(BinArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
-// k_fuse
+// k_fuse : one workgroup of NT threads per tile of TE x TE cells.
 // ------------------------------------------------------------------------------------------
-// Thread t owns cells {t + 256*q} of the tile for the whole kernel: their (elevation, variance)
+// Thread t owns cells {t + NT*q} of the tile for the whole kernel: their (elevation, variance)
 // live in registers from the single read to the single write-back.  LDS holds the per-batch sort:
-//   wc[4][CELLS] u32 | cstart[CELLS] u16 | ccount[CELLS] u16 | s_h[PB] f32 | s_v[PB] f32
-//   | s_src[PB] u32 | scratch[8] u32 | touched[CELLS/32] u32 | prefix[Bpad+1] u32 | ustart[Bpad] u16
-template <int TS, int R, int ATTR>
-__global__ __launch_bounds__(256) void k_fuse(FuseArgs a)
+//   wc[NW][CELLS] u16 | cstart[CELLS] u16 | ccount[CELLS] u16 | s_h[PB] f32 | s_v[PB] f32
+//   | s_src[PB] u32 (ATTR only) | scratch[16] u32 | touched[CELLS/32] u32
+// (s_h doubles as the list of record addresses of the batch until the records are in registers)
+template <int TS, int NT, int R, int ATTR>
+__global__ __launch_bounds__(NT, (NT == 256 ? 6 : 4)) void k_fuse(FuseArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr int TE = 1 << TS;
     constexpr int CELLS = TE * TE;
-    constexpr int PB = 256 * R;
-    constexpr int CPT = CELLS / 256;                 // cells per thread
+    constexpr int NW = NT / 64;
+    constexpr int PB = NT * R;
+    constexpr int CPT = CELLS / NT;                  // cells per thread (>= 1)
+    static_assert(CELLS % NT == 0 && CPT >= 1, "tile must have at least one cell per thread");
 
-    uint32_t* wc      = reinterpret_cast<uint32_t*>(lds_raw);              // [4][CELLS]
-    uint16_t* cstart  = reinterpret_cast<uint16_t*>(wc + 4 * CELLS);
+    uint16_t* wc      = reinterpret_cast<uint16_t*>(lds_raw);              // [NW][CELLS]
+    uint16_t* cstart  = wc + NW * CELLS;
     uint16_t* ccount  = cstart + CELLS;
     float*    s_h     = reinterpret_cast<float*>(ccount + CELLS);
     float*    s_v     = s_h + PB;
-    uint32_t* s_src   = reinterpret_cast<uint32_t*>(s_v + PB);
-    uint32_t* scratch = s_src + PB;
-    uint32_t* touched = scratch + 8;
-    uint32_t* prefix  = touched + CELLS / 32;
-    uint16_t* ustart  = reinterpret_cast<uint16_t*>(prefix + a.Bpad + 1);
+    uint32_t* s_src   = reinterpret_cast<uint32_t*>(s_v + PB);             // [PB] only when ATTR != 0
+    uint32_t* scratch = s_src + (ATTR ? PB : 0);
+    uint32_t* touched = scratch + 16;
+    uint32_t* kaddr   = reinterpret_cast<uint32_t*>(s_h);                  // [PB] arena addresses; dead once the records are in registers
 
     const int tid = (int)threadIdx.x;
     const int lane = lane_id();
@@ -243,12 +341,17 @@ __global__ __launch_bounds__(256) void k_fuse(FuseArgs a)
     const int row_base = tr << TS, col_base = tc << TS;
     const int L = a.L;
     const uint32_t* seg = a.seg + (size_t)tile * a.B_total;
+    const uint32_t epoch = a.epoch;
+    const uint64_t lt = lanemask_lt();
+    int dbg_k = 0;
+#define GEM_STAMP() do { if (a.dbg && tid == 0 && dbg_k < 16) a.dbg[(size_t)tile * 16 + dbg_k++] = (unsigned long long)__builtin_readcyclecounter(); } while (0)
+    GEM_STAMP();                                                         // 0: start
 
-    // ---- 0. does this tile receive any point at all? ---------------------------------------------
-    if (!a.dense) {
-        uint32_t any = 0;
-        for (int u = tid; u < a.B_total; u += 256) any |= seg[u] >> 16;
-        if (!__syncthreads_or((int)any)) return;
+    // ---- 0. batched call: does this tile receive any point at all? (single sweep: step 3 tells) ----
+    if (!a.dense && a.n_sweeps > 1) {
+        int any = 0;
+        for (int u = tid; u < a.B_total; u += NT) any |= (seg[u] >> kSegEpochShift) == epoch;
+        if (!__syncthreads_or(any)) return;
     }
 
     // ---- 1. the single read of the tile ---------------------------------------------------------
@@ -256,7 +359,7 @@ __global__ __launch_bounds__(256) void k_fuse(FuseArgs a)
     bool  owned[CPT];
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
-        const int c = tid + 256 * q;
+        const int c = tid + NT * q;
         const int row = row_base + (c >> TS), col = col_base + (c & (TE - 1));
         owned[q] = row < a.row1 && row >= a.row0 && col < L;
         ce[q] = kEmptyElevation; cs[q] = kInitVariance;
@@ -266,8 +369,9 @@ __global__ __launch_bounds__(256) void k_fuse(FuseArgs a)
         }
     }
 
+    GEM_STAMP();                                                         // 1: tile loads issued
     for (int sweep = 0; sweep < a.n_sweeps; ++sweep) {
-        const int ub = a.sweep_unit0 ? a.sweep_unit0[sweep] : 0;
+        const int ub = a.sweep_unit0 ? a.sweep_unit0[sweep] : 0;        // multiple of 4 (host pads sweeps)
         const int ue = a.sweep_unit0 ? a.sweep_unit0[sweep + 1] : a.B_total;
         const int B = ue - ub;
 
@@ -279,48 +383,133 @@ __global__ __launch_bounds__(256) void k_fuse(FuseArgs a)
             if (a.var_updates) { if (cs[q] != kInitVariance) cs[q] += a.var_updates[sweep]; }
         }
 
-        // ---- 3. which units feed this tile: exclusive scan of their counts ----------------------
-        const int UPT = (B + 255) / 256;
-        const int u0 = tid * UPT;
-        uint32_t local = 0;
-        for (int k = 0; k < UPT; ++k) { const int u = u0 + k; if (u < B) local += seg[ub + u] >> 16; }
-        uint32_t P;
-        uint32_t run = block_exclusive_scan_256(local, scratch, &P);
-        if (P != 0) {                                                   // block-uniform
-            for (int k = 0; k < UPT; ++k) {
-                const int u = u0 + k;
-                if (u < B) { const uint32_t s = seg[ub + u]; prefix[u] = run; ustart[u] = (uint16_t)(s & 0xffffu); run += s >> 16; }
+        // ---- 3/4. batches of PB points, in input order.  Each batch makes ONE vectorised pass over
+        //      the tile's descriptor row (4 units per thread and step), turning every unit's
+        //      (start, count) into the arena addresses of its records for k in [bbase, bbase + PB).
+        uint32_t P = 0;
+        bool first = true;
+        uint32_t* khead = reinterpret_cast<uint32_t*>(s_v);              // [PB] head markers (s_v is dead here)
+        constexpr int V = 2;                                             // uint4 descriptor loads per thread and chunk
+        for (uint32_t bbase = 0; first || bbase < P; bbase += PB) {
+            uint4 e[V];
+            {   // first chunk's loads fly while the LDS tables are cleared
+                const int u = tid * (4 * V);
+#pragma unroll
+                for (int x = 0; x < V; ++x) {
+                    e[x] = make_uint4(0, 0, 0, 0);
+                    if (u + 4 * x < B) e[x] = *reinterpret_cast<const uint4*>(seg + ub + u + 4 * x);   // rows are padded to 4 units
+                }
             }
-            if (tid == 255) prefix[B] = P;
-            if (tid < CELLS / 32) touched[tid] = 0;
+            for (int c = tid; c < PB; c += NT) khead[c] = 0;
+            {   // zero the per-wave cell counters (u16 pairs)
+                uint32_t* z = reinterpret_cast<uint32_t*>(wc);
+                for (int c = tid; c < NW * CELLS / 2; c += NT) z[c] = 0;
+            }
+            if (bbase == 0 && tid < CELLS / 32) touched[tid] = 0;
             __syncthreads();
-        }
-
-        // ---- 4. batches of PB points, in input order --------------------------------------------
-        for (uint32_t bbase = 0; bbase < P; bbase += PB) {
+            uint32_t carry = 0;
+            for (int ubase = 0; ubase < B; ubase += NT * 4 * V) {
+                const int u = ubase + tid * (4 * V);                     // thread owns 4*V consecutive units
+                if (ubase != 0) {
+#pragma unroll
+                    for (int x = 0; x < V; ++x) {
+                        e[x] = make_uint4(0, 0, 0, 0);
+                        if (u + 4 * x < B) e[x] = *reinterpret_cast<const uint4*>(seg + ub + u + 4 * x);
+                    }
+                }
+                uint32_t ev[4 * V], cnt[4 * V], local = 0;
+#pragma unroll
+                for (int x = 0; x < V; ++x) { ev[4 * x] = e[x].x; ev[4 * x + 1] = e[x].y; ev[4 * x + 2] = e[x].z; ev[4 * x + 3] = e[x].w; }
+#pragma unroll
+                for (int j = 0; j < 4 * V; ++j) {
+                    cnt[j] = ((ev[j] >> kSegEpochShift) == epoch && u + j < B) ? (ev[j] & kSegCountMask) : 0u;
+                    local += cnt[j];
+                }
+                uint32_t tot;
+                uint32_t run = carry + block_exclusive_scan<NT>(local, scratch, &tot);
+                carry += tot;
+                // mark where each non-empty unit's records start inside the window [bbase, bbase + PB):
+                // khead[pos] = pos + 1, kaddr[pos] = (arena address of the unit's first record) - k
+#pragma unroll
+                for (int j = 0; j < 4 * V; ++j) {
+                    if (cnt[j] != 0 && run + cnt[j] > bbase && run < bbase + PB) {
+                        const uint32_t addr0 = (uint32_t)(ub + u + j) * (uint32_t)a.U + ((ev[j] >> kSegCountBits) & kSegStartMask);
+                        const uint32_t pos = run > bbase ? run - bbase : 0u;
+                        khead[pos] = pos + 1u;
+                        kaddr[pos] = addr0 - run;                        // address(k) = kaddr[head] + k  (mod 2^32)
+                    }
+                    run += cnt[j];
+                }
+            }
+            P = carry;
+            first = false;
+            GEM_STAMP();                                                 // 2: descriptor row expanded
+            if (P == 0) break;                                           // block-uniform
             const uint32_t Pb = min((uint32_t)PB, P - bbase);
-            const uint32_t span = ((Pb + 255u) / 256u) * 64u;            // contiguous k-range per wave
+            const uint32_t span = ((Pb + NT - 1u) / NT) * 64u;          // contiguous k-range per wave
             const uint32_t nchunk = span / 64u;                          // <= R
 
-            for (int c = tid; c < 4 * CELLS; c += 256) wc[c] = 0;
+            __syncthreads();                                             // heads visible
+
+            // fill forward: every k of the batch learns its unit's head (max-scan over head positions)
+            {
+                const uint32_t I = (Pb + NT - 1u) / NT;                  // consecutive k per thread, <= R
+                const uint32_t k0 = (uint32_t)tid * I;
+                uint32_t hp[R], cur = 0;
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    hp[i] = 0;
+                    if ((uint32_t)i < I && k0 + i < Pb) { const uint32_t v = khead[k0 + i]; cur = v ? v : cur; hp[i] = cur; }
+                }
+                const uint32_t inc = wave_inclusive_max(cur);            // max-scan of the threads' last heads
+                if (lane == 63) scratch[w] = inc;
+                uint32_t before = wave_prev(inc);
+                __syncthreads();
+                for (int i = 0; i < w; ++i) before = max(before, scratch[i]);
+                uint32_t adr[R];
+#pragma unroll
+                for (int i = 0; i < R; ++i) {
+                    adr[i] = 0;
+                    if ((uint32_t)i < I && k0 + i < Pb) { const uint32_t hh = hp[i] ? hp[i] : before; adr[i] = kaddr[hh - 1u] + bbase + k0 + i; }
+                }
+                __syncthreads();                                         // all head deltas read before kaddr is overwritten
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+                    if ((uint32_t)i < I && k0 + i < Pb) kaddr[k0 + i] = adr[i];
+            }
             __syncthreads();
 
-            uint32_t cell[R], srcv[R]; float hh[R], vv[R];
+            // gather this thread's R records
+            bool act[R];
+            uint4 rr[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                cell[r] = 0xffffffffu; srcv[r] = 0; hh[r] = 0.0f; vv[r] = 0.0f;
                 const uint32_t kl = (uint32_t)w * span + (uint32_t)r * 64u + (uint32_t)lane;
-                if ((uint32_t)r < nchunk && kl < Pb) {
-                    const uint32_t k = bbase + kl;
-                    int lo = 0, hi = B;                                  // prefix[lo] <= k < prefix[hi]
-                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (prefix[mid] <= k) lo = mid; else hi = mid; }
-                    const size_t ridx = (size_t)(ub + lo) * a.U + ustart[lo] + (k - prefix[lo]);
-                    const uint4 rr = a.rec[ridx];
-                    cell[r] = rr.x; hh[r] = __uint_as_float(rr.y); vv[r] = __uint_as_float(rr.z); srcv[r] = rr.w;
-                    atomicAdd(&wc[w * CELLS + (rr.x & 0xffffu)], 1u);
+                act[r] = (uint32_t)r < nchunk && kl < Pb;
+                rr[r] = make_uint4(0, 0, 0, 0);
+                if (act[r]) rr[r] = a.rec[kaddr[kl]];
+            }
+            GEM_STAMP();                                                 // 3: record loads issued
+            // count per (wave, cell) and remember each record's offset inside its (wave, cell) run
+            uint32_t loff[R];
+            uint16_t* wcw = wc + w * CELLS;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                loff[r] = 0;
+                if ((uint32_t)r < nchunk) {                               // wave-uniform
+                    const uint32_t cell = rr[r].x & 0xffffu;
+                    const uint64_t peers = wave_peers(act[r], cell, 2 * TS);
+                    const uint32_t rank = (uint32_t)__popcll(peers & lt);
+                    if (act[r]) {
+                        const uint32_t old = wcw[cell];                   // same address within a group: broadcast
+                        if (rank == 0) wcw[cell] = (uint16_t)(old + (uint32_t)__popcll(peers));
+                        loff[r] = old + rank;
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): LDS update lands before the next chunk reads
                 }
             }
             __syncthreads();
+            GEM_STAMP();                                                 // 5: records loaded + counted
 
             // exclusive scan in (cell-major, wave-minor) order
             {
@@ -329,67 +518,81 @@ __global__ __launch_bounds__(256) void k_fuse(FuseArgs a)
 #pragma unroll
                 for (int q = 0; q < CPT; ++q)
 #pragma unroll
-                    for (int ww = 0; ww < 4; ++ww) loc += wc[ww * CELLS + c0 + q];
+                    for (int ww = 0; ww < NW; ++ww) loc += wc[ww * CELLS + c0 + q];
                 uint32_t tot;
-                uint32_t rn = block_exclusive_scan_256(loc, scratch, &tot);
+                uint32_t rn = block_exclusive_scan<NT>(loc, scratch, &tot);
 #pragma unroll
                 for (int q = 0; q < CPT; ++q) {
                     const int c = c0 + q;
                     const uint32_t st = rn;
 #pragma unroll
-                    for (int ww = 0; ww < 4; ++ww) { const uint32_t x = wc[ww * CELLS + c]; wc[ww * CELLS + c] = rn; rn += x; }
+                    for (int ww = 0; ww < NW; ++ww) { const uint32_t x = wc[ww * CELLS + c]; wc[ww * CELLS + c] = (uint16_t)rn; rn += x; }
                     cstart[c] = (uint16_t)st;
                     ccount[c] = (uint16_t)(rn - st);
                     if (a.counters && rn != st) atomicOr(&touched[c >> 5], 1u << (c & 31));
                 }
             }
             __syncthreads();
+            GEM_STAMP();                                                 // 6: cell scan done
 
-            // stable placement: each wave walks its chunks in order
+            // stable placement
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if ((uint32_t)r < nchunk) {                               // wave-uniform
-                    const bool valid = cell[r] != 0xffffffffu;
-                    const uint32_t pos = wave_stable_place(valid, cell[r] & 0xffffu, wc + w * CELLS);
-                    if (valid) {
-                        s_h[pos] = hh[r]; s_v[pos] = vv[r];
-                        if (ATTR) s_src[pos] = (srcv[r] & 0x7fffffffu) | (cell[r] & 0x80000000u);
-                    }
+                if (act[r]) {
+                    const uint32_t pos = (uint32_t)wcw[rr[r].x & 0xffffu] + loff[r];
+                    s_h[pos] = __uint_as_float(rr[r].y); s_v[pos] = __uint_as_float(rr[r].z);
+                    if (ATTR) s_src[pos] = (rr[r].w & 0x7fffffffu) | (rr[r].x & 0x80000000u);
                 }
             }
             __syncthreads();
+            GEM_STAMP();                                                 // 7: placed
 
-            // one lane per cell walks its points in input order (GPU:480-531)
+            // one lane per cell walks its points in input order (GPU:480-531); a thread's CPT cells are
+            // independent chains and advance together so their divisions overlap
+            {
+                uint32_t wcnt[CPT], wst[CPT], wlast[CPT], maxc = 0;
 #pragma unroll
-            for (int q = 0; q < CPT; ++q) {
-                const int c = tid + 256 * q;
-                const uint32_t cnt = ccount[c];
-                if (cnt) {
-                    float e = ce[q], s = cs[q];
-                    const uint32_t st = cstart[c];
-                    uint32_t last = 0xffffffffu;
-                    for (uint32_t p = st; p < st + cnt; ++p) {
-                        const bool taken = fuse_step(e, s, s_h[p], s_v[p], a.mahal, a.var_floor);
-                        if (ATTR) { const uint32_t sv = s_src[p]; if (taken && (sv & 0x80000000u)) last = sv & 0x7fffffffu; }
+                for (int q = 0; q < CPT; ++q) {
+                    const int c = tid + NT * q;
+                    wcnt[q] = ccount[c]; wst[q] = cstart[c]; wlast[q] = 0xffffffffu;
+                    maxc = max(maxc, wcnt[q]);
+                }
+                for (uint32_t p = 0; p < maxc; ++p) {
+#pragma unroll
+                    for (int q = 0; q < CPT; ++q) {
+                        if (p < wcnt[q]) {
+                            const uint32_t idx = wst[q] + p;
+                            const bool taken = fuse_step(ce[q], cs[q], s_h[idx], s_v[idx], a.mahal, a.var_floor);
+                            if (ATTR) { const uint32_t sv = s_src[idx]; if (taken && (sv & 0x80000000u)) wlast[q] = sv & 0x7fffffffu; }
+                        }
                     }
-                    ce[q] = e; cs[q] = s;
-                    if (ATTR && last != 0xffffffffu) {
-                        // colour / intensity of the last taken point with all four non-zero (GPU:487-494)
-                        const int row = row_base + (c >> TS), col = col_base + (c & (TE - 1));
-                        const size_t g = (size_t)row * L + col;
-                        if (ATTR == 1) {
-                            const uint32_t cc = a.rgb[last];
-                            a.intensity[g] = a.xyzi[last].w;
-                            a.colorR[g] = (int)((cc >> 16) & 0xff); a.colorG[g] = (int)((cc >> 8) & 0xff); a.colorB[g] = (int)(cc & 0xff);
-                        } else {
-                            a.intensity[g] = a.f_I[last];
-                            a.colorR[g] = a.f_R[last]; a.colorG[g] = a.f_G[last]; a.colorB[g] = a.f_B[last];
+                }
+                if (ATTR) {
+#pragma unroll
+                    for (int q = 0; q < CPT; ++q) {
+                        const uint32_t last = wlast[q];
+                        if (last != 0xffffffffu) {
+                            // colour / intensity of the last taken point with all four non-zero (GPU:487-494)
+                            const int c = tid + NT * q;
+                            const int row = row_base + (c >> TS), col = col_base + (c & (TE - 1));
+                            const size_t g = (size_t)row * L + col;
+                            if (ATTR == 1) {
+                                const uint32_t cc = a.rgb[last];
+                                a.intensity[g] = a.xyzi[last].w;
+                                a.colorR[g] = (int)((cc >> 16) & 0xff); a.colorG[g] = (int)((cc >> 8) & 0xff); a.colorB[g] = (int)(cc & 0xff);
+                            } else {
+                                a.intensity[g] = a.f_I[last];
+                                a.colorR[g] = a.f_R[last]; a.colorG[g] = a.f_G[last]; a.colorB[g] = a.f_B[last];
+                            }
                         }
                     }
                 }
             }
             __syncthreads();
+            GEM_STAMP();                                                 // 8: walked
         }
+
+        if (P == 0 && !a.dense && a.n_sweeps == 1) return;               // block-uniform: untouched tile, nothing to write
 
         // ---- 5. variance floor at the end of every Fuse (GPU:533-534), on every cell -------------
 #pragma unroll
@@ -408,12 +611,14 @@ __global__ __launch_bounds__(256) void k_fuse(FuseArgs a)
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
         if (owned[q]) {
-            const int c = tid + 256 * q;
+            const int c = tid + NT * q;
             const size_t g = (size_t)(row_base + (c >> TS)) * L + col_base + (c & (TE - 1));
             a.elevation[g] = ce[q];
             a.variance[g] = cs[q];
         }
     }
+    GEM_STAMP();                                                         // 9: stores issued
+#undef GEM_STAMP
 }
 
 // ------------------------------------------------------------------------------------------
@@ -489,17 +694,38 @@ hipError_t launch_project(hipStream_t st, const FrameConst& fc, int n, float* x,
     return hipGetLastError();
 }
 
+template <int SRC>
+static hipError_t launch_bin_wave(hipStream_t st, const BinArgs& a, int ts)
+{
+    const dim3 grid((a.B + 3) / 4), block(256);
+    const bool batch = a.n_sweeps > 1;
+    if (ts == 4) {
+        if (batch) hipLaunchKernelGGL((k_bin_wave<SRC, 4, true>),  grid, block, 0, st, a);
+        else       hipLaunchKernelGGL((k_bin_wave<SRC, 4, false>), grid, block, 0, st, a);
+    } else if (ts == 5) {
+        if (batch) hipLaunchKernelGGL((k_bin_wave<SRC, 5, true>),  grid, block, 0, st, a);
+        else       hipLaunchKernelGGL((k_bin_wave<SRC, 5, false>), grid, block, 0, st, a);
+    } else {
+        if (batch) hipLaunchKernelGGL((k_bin_wave<SRC, 6, true>),  grid, block, 0, st, a);
+        else       hipLaunchKernelGGL((k_bin_wave<SRC, 6, false>), grid, block, 0, st, a);
+    }
+    return hipGetLastError();
+}
+
 template <int IPT, int SRC>
-static hipError_t launch_bin_ts(hipStream_t st, const BinArgs& a, int ts)
+static hipError_t launch_bin_lds(hipStream_t st, const BinArgs& a, int ts)
 {
     const size_t lds = (size_t)a.T * sizeof(uint32_t);
     const bool batch = a.n_sweeps > 1;
-    if (ts == 5) {
-        if (batch) hipLaunchKernelGGL((k_bin<IPT, SRC, 5, true>),  dim3(a.B), dim3(64), lds, st, a);
-        else       hipLaunchKernelGGL((k_bin<IPT, SRC, 5, false>), dim3(a.B), dim3(64), lds, st, a);
+    if (ts == 4) {
+        if (batch) hipLaunchKernelGGL((k_bin_lds<IPT, SRC, 4, true>),  dim3(a.B), dim3(64), lds, st, a);
+        else       hipLaunchKernelGGL((k_bin_lds<IPT, SRC, 4, false>), dim3(a.B), dim3(64), lds, st, a);
+    } else if (ts == 5) {
+        if (batch) hipLaunchKernelGGL((k_bin_lds<IPT, SRC, 5, true>),  dim3(a.B), dim3(64), lds, st, a);
+        else       hipLaunchKernelGGL((k_bin_lds<IPT, SRC, 5, false>), dim3(a.B), dim3(64), lds, st, a);
     } else {
-        if (batch) hipLaunchKernelGGL((k_bin<IPT, SRC, 6, true>),  dim3(a.B), dim3(64), lds, st, a);
-        else       hipLaunchKernelGGL((k_bin<IPT, SRC, 6, false>), dim3(a.B), dim3(64), lds, st, a);
+        if (batch) hipLaunchKernelGGL((k_bin_lds<IPT, SRC, 6, true>),  dim3(a.B), dim3(64), lds, st, a);
+        else       hipLaunchKernelGGL((k_bin_lds<IPT, SRC, 6, false>), dim3(a.B), dim3(64), lds, st, a);
     }
     return hipGetLastError();
 }
@@ -509,54 +735,67 @@ hipError_t launch_bin(hipStream_t st, const BinArgs& a, int ipt, int src, int ts
     if (a.B <= 0) return hipSuccess;
     if (src == 0) {
         switch (ipt) {
-        case 1:  return launch_bin_ts<1, 0>(st, a, ts);
-        case 2:  return launch_bin_ts<2, 0>(st, a, ts);
-        default: return launch_bin_ts<4, 0>(st, a, ts);
+        case 1:  return launch_bin_wave<0>(st, a, ts);
+        case 2:  return launch_bin_lds<2, 0>(st, a, ts);
+        default: return launch_bin_lds<4, 0>(st, a, ts);
         }
     }
     switch (ipt) {
-    case 1:  return launch_bin_ts<1, 1>(st, a, ts);
-    case 2:  return launch_bin_ts<2, 1>(st, a, ts);
-    default: return launch_bin_ts<4, 1>(st, a, ts);
+    case 1:  return launch_bin_wave<1>(st, a, ts);
+    case 2:  return launch_bin_lds<2, 1>(st, a, ts);
+    default: return launch_bin_lds<4, 1>(st, a, ts);
     }
 }
 
-size_t fuse_lds_bytes(int ts, int r, int bpad)
+size_t fuse_lds_bytes(int ts, int nt, int r, int bpad, int attr)
 {
     const size_t cells = (size_t)1 << (2 * ts);
-    const size_t pb = 256 * (size_t)r;
-    size_t b = cells * 4 * 4            // wc
+    const size_t nw = nt / 64, pb = (size_t)nt * r;
+    size_t b = nw * cells * 2           // wc
              + cells * 2 * 2            // cstart, ccount
-             + pb * 4 * 3               // s_h, s_v, s_src
-             + 8 * 4                    // scratch
-             + cells / 32 * 4           // touched
-             + ((size_t)bpad + 1) * 4   // prefix
-             + (size_t)bpad * 2;        // ustart
+             + pb * 4 * (attr ? 3 : 2)  // s_h, s_v (, s_src)
+             + 16 * 4                   // scratch
+             + cells / 32 * 4;          // touched
+    (void)bpad;
     return (b + 15) & ~(size_t)15;
 }
 
-template <int TS, int R>
-static hipError_t launch_fuse_attr(hipStream_t st, const FuseArgs& a, int attr, size_t lds)
+template <int TS, int NT, int R>
+static hipError_t launch_fuse_attr(hipStream_t st, const FuseArgs& a, int attr)
 {
+    const size_t lds = fuse_lds_bytes(TS, NT, R, a.Bpad, attr);
     // more than 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel
     static size_t configured[3] = {0, 0, 0};
     if (lds > 64 * 1024 && lds > configured[attr]) {
-        const void* fn = attr == 0 ? (const void*)k_fuse<TS, R, 0> : attr == 1 ? (const void*)k_fuse<TS, R, 1> : (const void*)k_fuse<TS, R, 2>;
+        const void* fn = attr == 0 ? (const void*)k_fuse<TS, NT, R, 0> : attr == 1 ? (const void*)k_fuse<TS, NT, R, 1> : (const void*)k_fuse<TS, NT, R, 2>;
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured[attr] = lds;
     }
-    if (attr == 0)      hipLaunchKernelGGL((k_fuse<TS, R, 0>), dim3(a.T), dim3(256), lds, st, a);
-    else if (attr == 1) hipLaunchKernelGGL((k_fuse<TS, R, 1>), dim3(a.T), dim3(256), lds, st, a);
-    else                hipLaunchKernelGGL((k_fuse<TS, R, 2>), dim3(a.T), dim3(256), lds, st, a);
+    if (attr == 0)      hipLaunchKernelGGL((k_fuse<TS, NT, R, 0>), dim3(a.T), dim3(NT), lds, st, a);
+    else if (attr == 1) hipLaunchKernelGGL((k_fuse<TS, NT, R, 1>), dim3(a.T), dim3(NT), lds, st, a);
+    else                hipLaunchKernelGGL((k_fuse<TS, NT, R, 2>), dim3(a.T), dim3(NT), lds, st, a);
     return hipGetLastError();
 }
 
-hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr)
+// geometry of the fuse kernel for a tile shift: threads per tile and records per thread and batch
+void fuse_geometry(int ts, int variant, int* nt, int* r)
+{
+    if (ts == 4)      { *nt = 256; *r = 4; }
+    else if (ts == 5) { if (variant == 1) { *nt = 1024; *r = 4; } else if (variant == 2) { *nt = 256; *r = 8; } else { *nt = 512; *r = 8; } }
+    else              { *nt = 1024; *r = 4; }
+}
+
+hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr, int variant)
 {
     if (a.T <= 0) return hipSuccess;
-    if (ts == 5) return launch_fuse_attr<5, kFuseR32>(st, a, attr, fuse_lds_bytes(5, kFuseR32, a.Bpad));
-    return launch_fuse_attr<6, kFuseR64>(st, a, attr, fuse_lds_bytes(6, kFuseR64, a.Bpad));
+    if (ts == 4) return launch_fuse_attr<4, 256, 4>(st, a, attr);
+    if (ts == 5) {
+        if (variant == 1) return launch_fuse_attr<5, 1024, 4>(st, a, attr);
+        if (variant == 2) return launch_fuse_attr<5, 256, 8>(st, a, attr);
+        return launch_fuse_attr<5, 512, 8>(st, a, attr);
+    }
+    return launch_fuse_attr<6, 1024, 4>(st, a, attr);
 }
 
 hipError_t launch_init(hipStream_t st, const LayerPtrs& m, int cells, int clear_lowest)

@@ -5,9 +5,15 @@
 
 namespace gem {
 
-constexpr int kFuseR32 = 8;     // k_fuse batch = 256*R points per tile pass, 32x32-cell tiles
-constexpr int kFuseR64 = 16;    //                                           64x64-cell tiles
 constexpr int kMaxPending = 4;  // queued Mapvar_update increments folded into the next fuse
+
+// (tile, unit) descriptor word:  epoch << 17 | start << 9 | count   (units hold <= 256 records)
+constexpr int      kSegCountBits  = 9;
+constexpr int      kSegStartBits  = 8;
+constexpr int      kSegEpochShift = kSegCountBits + kSegStartBits;
+constexpr uint32_t kSegCountMask  = (1u << kSegCountBits) - 1u;
+constexpr uint32_t kSegStartMask  = (1u << kSegStartBits) - 1u;
+constexpr uint32_t kSegEpochMax   = (1u << (32 - kSegEpochShift)) - 1u;
 
 struct LayerPtrs {
     float *elevation, *variance, *intensity, *traver, *lowest;
@@ -33,6 +39,8 @@ struct BinArgs {
     const int*   f_R; const int* f_G; const int* f_B; const float* f_I;
     // tiling
     int T;                             // number of tiles
+    int tile_bits;                     // ceil(log2(T))
+    uint32_t epoch;                    // stamps the descriptor words of this pass
     int tiles_per_row;
     int B;                             // number of units (grid size)
     // outputs
@@ -44,6 +52,7 @@ struct BinArgs {
 struct FuseArgs {
     const uint4*    rec;
     const uint32_t* seg;               // [T][B_total]
+    uint32_t epoch;
     int   B_total;                     // row stride of seg
     int   U;                           // records per unit slot
     int   n_sweeps;
@@ -61,13 +70,15 @@ struct FuseArgs {
     const float4* xyzi; const uint32_t* rgb;
     const int* f_R; const int* f_G; const int* f_B; const float* f_I;
     unsigned long long* counters;      // optional: [1] += distinct touched cells (per sweep)
+    unsigned long long* dbg;           // optional: [T][16] cycle-counter stamps of thread 0 (profiling aid)
 };
 
 hipError_t launch_project(hipStream_t st, const FrameConst& fc, int n, float* x, float* y, float* z, const int* orig,
                           int write_back, int* map_idx, float* var, float* xt, float* yt, float* zt);
 hipError_t launch_bin(hipStream_t st, const BinArgs& a, int ipt, int src, int ts);
-hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr);
-size_t     fuse_lds_bytes(int ts, int r, int bpad);
+hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr, int variant);
+void       fuse_geometry(int ts, int variant, int* nt, int* r);
+size_t     fuse_lds_bytes(int ts, int nt, int r, int bpad, int attr);
 hipError_t launch_init(hipStream_t st, const LayerPtrs& m, int cells, int clear_lowest);
 hipError_t launch_clear_strip(hipStream_t st, const LayerPtrs& m, int L, int start, int count, int is_row);
 hipError_t launch_dense_variance(hipStream_t st, float* variance, int cells, int n_pending, const float* pending,

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Profiling aid: per-phase cycle stamps of k_fuse (thread 0 of every tile) on the C2 workload."""
+import ctypes as C
+import sys
+from pathlib import Path
+import numpy as np
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+from gem_amd import ElevationMap, synth, _lib
+
+wl = synth.config_c4(n_sweeps=4)
+m = ElevationMap(wl.length, wl.resolution)
+lib = _lib.load()
+lib.gem_debug_fuse_stamps.restype = C.c_int
+lib.gem_debug_fuse_stamps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+d = [torch.from_numpy(c).cuda() for c in wl.clouds]
+for k in range(3):
+    m.add(wl.frames[k], d[k])
+lib.gem_debug_fuse_stamps(m._h, 1, None, 0)
+m.add(wl.frames[3], d[3])
+T = 4096
+buf = np.zeros((T, 16), np.uint64)
+n = lib.gem_debug_fuse_stamps(m._h, 0, buf.ctypes.data_as(C.c_void_p), T)
+st = buf[:n].astype(np.int64)
+names = ["start", "tile_ld", "heads", "filled+rec_issue", "rec+count", "cellscan", "placed", "walked", "stores", "x"]
+t0 = st[:, 0].min()
+nb = (st > 0).sum(1)
+tot = np.array([st[i, nb[i] - 1] - st[i, 0] for i in range(n)])
+print("tiles", n, "stamps/tile hist", np.bincount(nb))
+print("kernel span (cycles): first start -> last end:", st.max() - t0)
+order = np.argsort(-tot)
+for label, idx in (("slowest", order[:3]), ("median", order[len(order) // 2: len(order) // 2 + 2])):
+    for i in idx:
+        s = st[i, :nb[i]]
+        print(label, "tile", i, "stamps", nb[i], "total", tot[i], "start@", s[0] - t0, "deltas", list(np.diff(s)))
+full = nb == 10
+if full.any():
+    dd = np.diff(st[full, :10], axis=1)
+    print("mean deltas over single-batch tiles:", dict(zip(names[1:], dd.mean(0).astype(int))))
+    print("max  deltas over single-batch tiles:", dict(zip(names[1:], dd.max(0).astype(int))))
