@@ -1,0 +1,142 @@
+// gem_compat_eigen.hpp -- re-creates, on top of libgem_hip.so's C ABI, the C++-linkage free functions
+// that the reference's callers forward-declare and link from libgpu.so:
+//
+//   Init_GPU_elevationmap, Move, Fuse, Map_feature, Raytracing, Map_optmove, Map_closeloop
+//        (forward-declared at elevation_mapping/src/ElevationMapping.cpp:44-50)
+//   Process_points    (src/sensor_processors/SensorProcessorBase.cpp:34)
+//   Mapvar_update     (src/RobotMotionMapUpdater.cpp:18 -- declared `int` there, defined `void` in
+//                      gpu_process.cu:1146; the mangled name carries no return type, so one definition serves)
+//
+// Compile ONE translation unit that includes this header into the catkin package in place of
+// cuda/gpu_process.cu: the ROS node itself stays unchanged.  Needs Eigen
+// (by-value Matrix4f / Matrix3f / RowVector3f arguments), which exists in the ROS workspace but not in
+// this repository's build container -- tests/cpp compiles it against a minimal stand-in.
+//
+// Hot-path symbols are complete.  Map_feature / Raytracing / Map_optmove / Map_closeloop belong to the
+// post-processing stages that are outside the hot path (SURVEY.md 8f "next" rows); they are provided so the
+// node links, with the behaviour documented on each.
+#pragma once
+
+#include <Eigen/Core>
+
+#include "../gem_hip.h"
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace gem_compat {
+
+inline gem_handle*& handle() { static gem_handle* h = nullptr; return h; }
+inline gem_reject_filter& reject_filter()
+{
+    static gem_reject_filter f{1, 1.5f, 1.5f, 1.0f, 0.0f};       // gpu_process.cu:393, on like the reference
+    return f;
+}
+inline void report(int rc, const char* what)
+{
+    // the reference prints CUDA errors to stderr and carries on (gpu_process.cu:987-992, 1127-1132)
+    if (rc != GEM_OK) std::fprintf(stderr, "%s failed (%d): %s\n", what, rc, gem_last_error(handle()));
+}
+
+} // namespace gem_compat
+
+// gpu_process.cu:940-994
+void Init_GPU_elevationmap(int length, float resolution, float h_mahalanobisDistanceThreshold_, float h_obstacle_threshold)
+{
+    (void)h_mahalanobisDistanceThreshold_;      // uploaded but never read by the reference; G_fuse uses the literal 5 (gpu_process.cu:504)
+    if (gem_compat::handle()) { gem_destroy(gem_compat::handle()); gem_compat::handle() = nullptr; }
+    gem_map_config cfg{};
+    cfg.length = length; cfg.resolution = resolution;
+    cfg.mahalanobis_threshold = 5.0f; cfg.variance_floor = 0.0001f;
+    cfg.obstacle_threshold = h_obstacle_threshold; cfg.device = -1;
+    const int rc = gem_create(&cfg, &gem_compat::handle());
+    if (rc != GEM_OK) std::fprintf(stderr, "Init_GPU_elevationmap failed (%d): %s\n", rc, gem_last_error(nullptr));
+}
+
+// gpu_process.cu:1004-1083
+void Move(float* current_Position, float resolution, int length, float* Central_coordinate, int* Start_indice, float* alignedPositionShift)
+{
+    (void)resolution; (void)length;
+    gem_compat::report(gem_move(gem_compat::handle(), current_Position, Central_coordinate, Start_indice, alignedPositionShift), "Move");
+}
+
+// gpu_process.cu:1085-1144
+int Process_points(int* map_index, float* point_x, float* point_y, float* point_z, float* point_var,
+                   float* point_x_ts, float* point_y_ts, float* point_z_ts, Eigen::Matrix4f transform, int point_num,
+                   double relativeLowerThreshold, double relativeUpperThreshold, float min_r, float beam_a, float beam_c,
+                   Eigen::RowVector3f sensorJacobian, Eigen::Matrix3f rotationVariance, Eigen::Matrix3f C_SB_transpose,
+                   Eigen::RowVector3f P_mul_C_BM_transpose, Eigen::Matrix3f B_r_BS_skew)
+{
+    gem_frame_params p{};
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) p.T[i * 4 + j] = transform(i, j);
+    p.lower = relativeLowerThreshold; p.upper = relativeUpperThreshold;
+    p.sensor_model = GEM_MODEL_LASER;
+    p.sensor_params[0] = min_r; p.sensor_params[1] = beam_a; p.sensor_params[2] = beam_c;
+    for (int j = 0; j < 3; ++j) { p.sensor_jacobian[j] = sensorJacobian(0, j); p.P_mul_C_BM_T[j] = P_mul_C_BM_transpose(0, j); }
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        p.rotation_variance[i * 3 + j] = rotationVariance(i, j);
+        p.C_SB_T[i * 3 + j] = C_SB_transpose(i, j);
+        p.B_r_BS_skew[i * 3 + j] = B_r_BS_skew(i, j);
+    }
+    p.filter = gem_compat::reject_filter();
+    // the reference overwrites its DEVICE copies of x,y,z for rejected points, never the host arrays
+    // (gpu_process.cu:443-446, no D2H of dev_x/y/z): write_back_xyz = 0
+    gem_compat::report(gem_process_points(gem_compat::handle(), &p, point_num, point_x, point_y, point_z, nullptr, 0,
+                                          map_index, point_var, point_x_ts, point_y_ts, point_z_ts), "Process_points");
+    return 0;
+}
+
+// gpu_process.cu:1154-1193.  point_num must be the number of VALID entries: the reference passes the
+// pre-cleaning cloud size here (ElevationMapping.cpp:259,280) and so reads an uninitialised tail.
+void Fuse(int length, int point_num, int* point_index, int* point_colorR, int* point_colorG, int* point_colorB,
+          float* point_intensity, float* point_height, float* point_var)
+{
+    (void)length;
+    gem_compat::report(gem_fuse(gem_compat::handle(), point_num, point_index, point_colorR, point_colorG, point_colorB,
+                                point_intensity, point_height, point_var), "Fuse");
+}
+
+// gpu_process.cu:1146-1152
+void Mapvar_update(int length, float var_update)
+{
+    (void)length;
+    gem_compat::report(gem_mapvar_update(gem_compat::handle(), var_update), "Mapvar_update");
+}
+
+// gpu_process.cu:1256-1302 -- traversability stage, OUTSIDE the hot path.  Copies the fused
+// layers out exactly as the reference does (9 D2H copies, gpu_process.cu:1283-1291); rough / slope / traver
+// are not computed here and are returned as -10 ("no information", the value G_Init_map gives map_traver).
+void Map_feature(int length, float* elevation, float* var, int* colorR, int* colorG, int* colorB,
+                 float* rough, float* slope, float* traver, float* intensity)
+{
+    gem_handle* h = gem_compat::handle();
+    gem_compat::report(gem_get_layer(h, GEM_LAYER_ELEVATION, GEM_LAYOUT_STORAGE_ROWMAJOR, elevation), "Map_feature");
+    gem_compat::report(gem_get_layer(h, GEM_LAYER_VARIANCE, GEM_LAYOUT_STORAGE_ROWMAJOR, var), "Map_feature");
+    gem_compat::report(gem_get_layer(h, GEM_LAYER_COLOR_R, GEM_LAYOUT_STORAGE_ROWMAJOR, colorR), "Map_feature");
+    gem_compat::report(gem_get_layer(h, GEM_LAYER_COLOR_G, GEM_LAYOUT_STORAGE_ROWMAJOR, colorG), "Map_feature");
+    gem_compat::report(gem_get_layer(h, GEM_LAYER_COLOR_B, GEM_LAYOUT_STORAGE_ROWMAJOR, colorB), "Map_feature");
+    gem_compat::report(gem_get_layer(h, GEM_LAYER_INTENSITY, GEM_LAYOUT_STORAGE_ROWMAJOR, intensity), "Map_feature");
+    const size_t n = static_cast<size_t>(length) * length;
+    for (size_t i = 0; i < n; ++i) { rough[i] = -10.0f; slope[i] = -10.0f; traver[i] = -10.0f; }
+}
+
+// gpu_process.cu:1304-1318 -- visibility clean-up, outside the hot path: no-op.
+void Raytracing(int length) { (void)length; }
+
+// gpu_process.cu:1215-1233 -- loop-closure shift, outside the hot path: recentres the map;
+// the height offset of G_update_mapheight is not applied.
+void Map_optmove(float* opt_p, float height_update, float resolution, int length, float* opt_alignedPosition)
+{
+    (void)height_update; (void)resolution; (void)length;
+    float pos[3] = {opt_p[0], opt_p[1], 0.0f};
+    float center[2]; int start[2]; float shift[2];
+    gem_compat::report(gem_move(gem_compat::handle(), pos, center, start, shift), "Map_optmove");
+    opt_alignedPosition[0] = center[0]; opt_alignedPosition[1] = center[1];
+}
+
+// gpu_process.cu:1235-1254 -- declared by the node (ElevationMapping.cpp:46) but never called.
+void Map_closeloop(float* update_position, float height_update, int length, float resolution)
+{
+    (void)update_position; (void)height_update; (void)length; (void)resolution;
+}
