@@ -140,23 +140,20 @@ hipEvent_t get_event(gem_handle* h)
     return e;
 }
 
+// Optional per-kernel timing: the dispatch is time-stamped through a (start, stop) event pair
+// handed to hipExtLaunchKernelGGL, so the figure is the kernel's own duration on its stream.
 struct Timed {
-    gem_handle* h; int kind; EventPair ep{};
+    gem_handle* h; EventPair ep{};
     bool on;
-    Timed(gem_handle* hh, int k) : h(hh), kind(k), on(hh->timing)
+    Timed(gem_handle* hh, int kind) : h(hh), on(hh->timing)
     {
         if (!on) return;
         if (!h->pool.empty()) { ep = h->pool.back(); h->pool.pop_back(); }
         else { ep.a = get_event(h); ep.b = get_event(h); }
         ep.kind = kind;
-        hipEventRecord(ep.a, h->stream);
     }
-    ~Timed()
-    {
-        if (!on) return;
-        hipEventRecord(ep.b, h->stream);
-        h->events.push_back(ep);
-    }
+    LaunchEvents events() const { LaunchEvents e; if (on) { e.start = ep.a; e.stop = ep.b; } return e; }
+    ~Timed() { if (on) h->events.push_back(ep); }
 };
 
 void fold_events(gem_handle* h)
@@ -309,8 +306,8 @@ int run_pipeline(gem_handle* h, const PassInput& in)
     }
 
     if (h->counting) GEM_HIP(h, hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
-    { Timed t(h, 0); GEM_HIP(h, launch_bin(h->stream, ba, ipt, in.src, h->ts)); }
-    { Timed t(h, 1); GEM_HIP(h, launch_fuse(h->stream, fa, h->ts, attr, h->fuse_variant)); }
+    { Timed t(h, 0); GEM_HIP(h, launch_bin(h->stream, ba, ipt, in.src, h->ts, t.events())); }
+    { Timed t(h, 1); GEM_HIP(h, launch_fuse(h->stream, fa, h->ts, attr, h->fuse_variant, t.events())); }
     h->n_pending = 0;
     h->floor_dirty = false;
     h->stats.points_in = in.n;

@@ -20,6 +20,8 @@
 // Built with -ffp-contract=off (see gem_device.hpp).
 #include "gem_kernels.hpp"
 
+#include <hip/hip_ext.h>
+
 namespace gem {
 
 // ------------------------------------------------------------------------------------------
@@ -678,6 +680,14 @@ __global__ __launch_bounds__(256) void k_export_gridmap(const void* __restrict__
 // ------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------
+// Launch `k`; with a (start, stop) event pair the dispatch itself is time-stamped (hipExtLaunchKernelGGL),
+// which measures the kernel alone -- no launch gap, no event-record overhead.
+#define GEM_LAUNCH(k, grid, block, lds, st, ev, ...)                                              \
+    do {                                                                                           \
+        if ((ev).start) hipExtLaunchKernelGGL(k, grid, block, (uint32_t)(lds), st, (ev).start, (ev).stop, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(k, grid, block, lds, st, __VA_ARGS__);                             \
+    } while (0)
+
 static inline int grid_for(long long work, int block, int cap = 2048)
 {
     long long g = (work + block - 1) / block;
@@ -695,55 +705,55 @@ hipError_t launch_project(hipStream_t st, const FrameConst& fc, int n, float* x,
 }
 
 template <int SRC>
-static hipError_t launch_bin_wave(hipStream_t st, const BinArgs& a, int ts)
+static hipError_t launch_bin_wave(hipStream_t st, const BinArgs& a, int ts, LaunchEvents ev)
 {
     const dim3 grid((a.B + 3) / 4), block(256);
     const bool batch = a.n_sweeps > 1;
     if (ts == 4) {
-        if (batch) hipLaunchKernelGGL((k_bin_wave<SRC, 4, true>),  grid, block, 0, st, a);
-        else       hipLaunchKernelGGL((k_bin_wave<SRC, 4, false>), grid, block, 0, st, a);
+        if (batch) GEM_LAUNCH((k_bin_wave<SRC, 4, true>), grid, block, 0, st, ev, a);
+        else       GEM_LAUNCH((k_bin_wave<SRC, 4, false>), grid, block, 0, st, ev, a);
     } else if (ts == 5) {
-        if (batch) hipLaunchKernelGGL((k_bin_wave<SRC, 5, true>),  grid, block, 0, st, a);
-        else       hipLaunchKernelGGL((k_bin_wave<SRC, 5, false>), grid, block, 0, st, a);
+        if (batch) GEM_LAUNCH((k_bin_wave<SRC, 5, true>), grid, block, 0, st, ev, a);
+        else       GEM_LAUNCH((k_bin_wave<SRC, 5, false>), grid, block, 0, st, ev, a);
     } else {
-        if (batch) hipLaunchKernelGGL((k_bin_wave<SRC, 6, true>),  grid, block, 0, st, a);
-        else       hipLaunchKernelGGL((k_bin_wave<SRC, 6, false>), grid, block, 0, st, a);
+        if (batch) GEM_LAUNCH((k_bin_wave<SRC, 6, true>), grid, block, 0, st, ev, a);
+        else       GEM_LAUNCH((k_bin_wave<SRC, 6, false>), grid, block, 0, st, ev, a);
     }
     return hipGetLastError();
 }
 
 template <int IPT, int SRC>
-static hipError_t launch_bin_lds(hipStream_t st, const BinArgs& a, int ts)
+static hipError_t launch_bin_lds(hipStream_t st, const BinArgs& a, int ts, LaunchEvents ev)
 {
     const size_t lds = (size_t)a.T * sizeof(uint32_t);
     const bool batch = a.n_sweeps > 1;
     if (ts == 4) {
-        if (batch) hipLaunchKernelGGL((k_bin_lds<IPT, SRC, 4, true>),  dim3(a.B), dim3(64), lds, st, a);
-        else       hipLaunchKernelGGL((k_bin_lds<IPT, SRC, 4, false>), dim3(a.B), dim3(64), lds, st, a);
+        if (batch) GEM_LAUNCH((k_bin_lds<IPT, SRC, 4, true>), dim3(a.B), dim3(64), lds, st, ev, a);
+        else       GEM_LAUNCH((k_bin_lds<IPT, SRC, 4, false>), dim3(a.B), dim3(64), lds, st, ev, a);
     } else if (ts == 5) {
-        if (batch) hipLaunchKernelGGL((k_bin_lds<IPT, SRC, 5, true>),  dim3(a.B), dim3(64), lds, st, a);
-        else       hipLaunchKernelGGL((k_bin_lds<IPT, SRC, 5, false>), dim3(a.B), dim3(64), lds, st, a);
+        if (batch) GEM_LAUNCH((k_bin_lds<IPT, SRC, 5, true>), dim3(a.B), dim3(64), lds, st, ev, a);
+        else       GEM_LAUNCH((k_bin_lds<IPT, SRC, 5, false>), dim3(a.B), dim3(64), lds, st, ev, a);
     } else {
-        if (batch) hipLaunchKernelGGL((k_bin_lds<IPT, SRC, 6, true>),  dim3(a.B), dim3(64), lds, st, a);
-        else       hipLaunchKernelGGL((k_bin_lds<IPT, SRC, 6, false>), dim3(a.B), dim3(64), lds, st, a);
+        if (batch) GEM_LAUNCH((k_bin_lds<IPT, SRC, 6, true>), dim3(a.B), dim3(64), lds, st, ev, a);
+        else       GEM_LAUNCH((k_bin_lds<IPT, SRC, 6, false>), dim3(a.B), dim3(64), lds, st, ev, a);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_bin(hipStream_t st, const BinArgs& a, int ipt, int src, int ts)
+hipError_t launch_bin(hipStream_t st, const BinArgs& a, int ipt, int src, int ts, LaunchEvents ev)
 {
     if (a.B <= 0) return hipSuccess;
     if (src == 0) {
         switch (ipt) {
-        case 1:  return launch_bin_wave<0>(st, a, ts);
-        case 2:  return launch_bin_lds<2, 0>(st, a, ts);
-        default: return launch_bin_lds<4, 0>(st, a, ts);
+        case 1:  return launch_bin_wave<0>(st, a, ts, ev);
+        case 2:  return launch_bin_lds<2, 0>(st, a, ts, ev);
+        default: return launch_bin_lds<4, 0>(st, a, ts, ev);
         }
     }
     switch (ipt) {
-    case 1:  return launch_bin_wave<1>(st, a, ts);
-    case 2:  return launch_bin_lds<2, 1>(st, a, ts);
-    default: return launch_bin_lds<4, 1>(st, a, ts);
+    case 1:  return launch_bin_wave<1>(st, a, ts, ev);
+    case 2:  return launch_bin_lds<2, 1>(st, a, ts, ev);
+    default: return launch_bin_lds<4, 1>(st, a, ts, ev);
     }
 }
 
@@ -761,7 +771,7 @@ size_t fuse_lds_bytes(int ts, int nt, int r, int bpad, int attr)
 }
 
 template <int TS, int NT, int R>
-static hipError_t launch_fuse_attr(hipStream_t st, const FuseArgs& a, int attr)
+static hipError_t launch_fuse_attr(hipStream_t st, const FuseArgs& a, int attr, LaunchEvents ev)
 {
     const size_t lds = fuse_lds_bytes(TS, NT, R, a.Bpad, attr);
     // more than 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel
@@ -772,9 +782,9 @@ static hipError_t launch_fuse_attr(hipStream_t st, const FuseArgs& a, int attr)
         if (e != hipSuccess) return e;
         configured[attr] = lds;
     }
-    if (attr == 0)      hipLaunchKernelGGL((k_fuse<TS, NT, R, 0>), dim3(a.T), dim3(NT), lds, st, a);
-    else if (attr == 1) hipLaunchKernelGGL((k_fuse<TS, NT, R, 1>), dim3(a.T), dim3(NT), lds, st, a);
-    else                hipLaunchKernelGGL((k_fuse<TS, NT, R, 2>), dim3(a.T), dim3(NT), lds, st, a);
+    if (attr == 0)      GEM_LAUNCH((k_fuse<TS, NT, R, 0>), dim3(a.T), dim3(NT), lds, st, ev, a);
+    else if (attr == 1) GEM_LAUNCH((k_fuse<TS, NT, R, 1>), dim3(a.T), dim3(NT), lds, st, ev, a);
+    else                GEM_LAUNCH((k_fuse<TS, NT, R, 2>), dim3(a.T), dim3(NT), lds, st, ev, a);
     return hipGetLastError();
 }
 
@@ -786,16 +796,16 @@ void fuse_geometry(int ts, int variant, int* nt, int* r)
     else              { *nt = 1024; *r = 4; }
 }
 
-hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr, int variant)
+hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr, int variant, LaunchEvents ev)
 {
     if (a.T <= 0) return hipSuccess;
-    if (ts == 4) return launch_fuse_attr<4, 256, 4>(st, a, attr);
+    if (ts == 4) return launch_fuse_attr<4, 256, 4>(st, a, attr, ev);
     if (ts == 5) {
-        if (variant == 1) return launch_fuse_attr<5, 1024, 4>(st, a, attr);
-        if (variant == 2) return launch_fuse_attr<5, 256, 8>(st, a, attr);
-        return launch_fuse_attr<5, 512, 8>(st, a, attr);
+        if (variant == 1) return launch_fuse_attr<5, 1024, 4>(st, a, attr, ev);
+        if (variant == 2) return launch_fuse_attr<5, 256, 8>(st, a, attr, ev);
+        return launch_fuse_attr<5, 512, 8>(st, a, attr, ev);
     }
-    return launch_fuse_attr<6, 1024, 4>(st, a, attr);
+    return launch_fuse_attr<6, 1024, 4>(st, a, attr, ev);
 }
 
 hipError_t launch_init(hipStream_t st, const LayerPtrs& m, int cells, int clear_lowest)

@@ -75,8 +75,10 @@ struct FuseArgs {
 
 hipError_t launch_project(hipStream_t st, const FrameConst& fc, int n, float* x, float* y, float* z, const int* orig,
                           int write_back, int* map_idx, float* var, float* xt, float* yt, float* zt);
-hipError_t launch_bin(hipStream_t st, const BinArgs& a, int ipt, int src, int ts);
-hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr, int variant);
+struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };   // optional dispatch time-stamps
+
+hipError_t launch_bin(hipStream_t st, const BinArgs& a, int ipt, int src, int ts, LaunchEvents ev);
+hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr, int variant, LaunchEvents ev);
 void       fuse_geometry(int ts, int variant, int* nt, int* r);
 size_t     fuse_lds_bytes(int ts, int nt, int r, int bpad, int attr);
 hipError_t launch_init(hipStream_t st, const LayerPtrs& m, int cells, int clear_lowest);
