@@ -17,8 +17,8 @@ def main(path):
     for n, c, s, a, mn, mx, g, wg, lds, vg, sg in rows:
         print(f"{n[:70]:70s} {c:7d} {s/1e3:11.1f} {a/1e3:9.2f} {mn/1e3:9.2f} {mx/1e3:9.2f} {100*s/tot:6.1f} {g:8d} {wg:5d} {lds:7d} {vg:5d} {sg:5d}")
     try:
-        pm = cur.execute("select k.name, p.counter_name, count(*), sum(p.value), avg(p.value) from pmc_events p "
-                         "join kernels k on k.dispatch_id = p.dispatch_id group by k.name, p.counter_name").fetchall()
+        pm = cur.execute("select name, counter_name, count(*), sum(counter_value), avg(counter_value) from pmc_events "
+                         "group by name, counter_name order by sum(counter_value) desc").fetchall()
         if pm:
             print("\n# PMC counters (per kernel: counter, dispatches, sum, avg per dispatch)")
             for n, cn, c, s, a in pm:
