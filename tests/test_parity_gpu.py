@@ -278,3 +278,38 @@ def test_row_strips_compose(oracle_mod):
         pe = part.layer("elevation"); pe[r0:r1] = -10
         assert np.all(pe == -10)                     # nothing outside the owned strip is written
     assert np.array_equal(e, ref.layer("elevation")) and np.array_equal(v, ref.layer("variance"))
+
+
+# ---- multi-GPU plumbing on one device --------------------------------------------------------------------------------
+def test_rccl_single_rank_allgather(oracle_mod):
+    from gem_amd.tiling import TiledElevationMap
+    wl = synth.config_c1()
+    uid = ElevationMap.comm_unique_id()
+    assert len(uid) == 128
+    tm = TiledElevationMap(wl.length, wl.resolution, 0, 1, exchange="rccl", unique_id=uid)
+    ref = oracle_mod.OracleMap(wl.length, wl.resolution)
+    tm.add(wl.frames[0], wl.clouds[0]); ref.add(wl.frames[0], wl.clouds[0])
+    tm.allgather(with_attributes=True)
+    assert np.array_equal(tm.layer("elevation"), ref.layer("elevation"))
+    assert np.array_equal(tm.layer("variance"), ref.layer("variance"))
+
+
+def test_torch_exchange_aliases_device_layers(oracle_mod):
+    import os
+    import torch
+    import torch.distributed as dist
+    from gem_amd.tiling import TiledElevationMap
+    wl = synth.config_c1()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29631")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        tm = TiledElevationMap(wl.length, wl.resolution, 0, 1, exchange="torch")
+        ref = oracle_mod.OracleMap(wl.length, wl.resolution)
+        tm.add(wl.frames[0], wl.clouds[0]); ref.add(wl.frames[0], wl.clouds[0])
+        tm.allgather()
+        e, v = tm.layer_tensors()
+        torch.cuda.synchronize()
+        assert e.is_cuda and e.data_ptr() == tm.map.layer_device_ptr("elevation")      # zero-copy alias
+        assert np.array_equal(e.cpu().numpy(), ref.layer("elevation")) and np.array_equal(v.cpu().numpy(), ref.layer("variance"))
+    finally:
+        dist.destroy_process_group()
