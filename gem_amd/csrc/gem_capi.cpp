@@ -48,11 +48,22 @@ struct gem_handle {
     int   start[2] = {0, 0};
     float sensor_z = 0.f;
     int   row0 = 0, row1 = 0;
-    int   ts = 5, tiles_per_row = 0, T = 0;
+    int   ts = 0, T = 0;           // tile shift (0 = per pass), tiles of the last pass
 
     Arena stage;        // staging of host-pointer inputs / outputs
-    Arena rec, seg;     // pipeline intermediates
-    Arena tables;       // batched-call tables (frames, sweep_unit0, sweep_first, var_updates)
+    // Pipeline intermediates, double-buffered: k_bin of pass p+1 runs on `bin_stream` while k_fuse of
+    // pass p runs on `stream` (binning does not depend on the map, only on the cloud and the pose).
+    struct PassBuffers {
+        Arena rec, seg, flag;          // records, descriptor table, per-(sweep, tile) touched stamps
+        Arena tables;                  // batched-call tables (frames, sweep_unit0, sweep_first, var_updates)
+        hipEvent_t bin_done = nullptr, fuse_done = nullptr;
+        bool fuse_recorded = false;
+        uint32_t epoch = 0;            // descriptor-table epoch of the last pass (0 = table holds no live words)
+    } pb[2];
+    unsigned pass = 0;
+    hipStream_t bin_stream = nullptr;
+    bool overlap = true;
+    long long overlap_min_points = 1000000;
     Arena scratch;      // layer export
     unsigned long long* d_counters = nullptr;
 
@@ -72,8 +83,7 @@ struct gem_handle {
     Arena dbg;          // optional k_fuse phase stamps
     bool  dbg_on = false;
     int ipt_override = 0;
-    int fuse_variant = 0;
-    uint32_t epoch = 0;                // descriptor-table epoch of the last pass (0 = table holds no live words)
+    int fuse_variant = 11;
 };
 
 namespace {
@@ -95,6 +105,7 @@ int ensure(gem_handle* h, Arena& a, size_t bytes)
     if (bytes <= a.cap) return GEM_OK;
     // arenas may still be in use by enqueued work
     GEM_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->bin_stream) GEM_HIP(h, hipStreamSynchronize(h->bin_stream));
     if (a.p) GEM_HIP(h, hipFree(a.p));
     a.p = nullptr; a.cap = 0;
     size_t want = bytes + bytes / 4 + 4096;
@@ -233,22 +244,52 @@ int run_pipeline(gem_handle* h, const PassInput& in)
     int attr = 0;
     if (in.src == 0 && in.rgb) attr = 1;
     if (in.src == 1 && in.f_R && in.f_G && in.f_B && in.f_I) attr = 2;
+    // tile size of this pass: 16x16 cells (more, lighter workgroups: better balance and latency hiding)
+    // unless the (tile x unit) descriptor table would get too big, then 32x32
+    int ts = h->ts;
+    if (ts == 0) {
+        const long long tpr4 = (h->L + 15) / 16;
+        ts = (tpr4 * tpr4 * (long long)B * 4 <= (1ll << 30)) ? 4 : 5;
+    }
+    const int te = 1 << ts;
+    const int tiles_per_row = (h->L + te - 1) / te;
+    const int T = tiles_per_row * tiles_per_row;
+    h->T = T;
     int nt, rr;
-    fuse_geometry(h->ts, h->fuse_variant, &nt, &rr);
-    if (fuse_lds_bytes(h->ts, nt, rr, bpad, attr) > 160 * 1024)
-        return fail(h, GEM_ERR_INVALID, "too many units per sweep for one pass");
+    fuse_geometry(ts, h->fuse_variant, &nt, &rr);
+    if ((h->fuse_variant >= 10 ? fuse_list_lds_bytes(ts, h->fuse_variant, attr) : fuse_lds_bytes(ts, nt, rr, bpad, attr)) > 160 * 1024)
+        return fail(h, GEM_ERR_INVALID, "fuse kernel geometry exceeds the LDS");
 
+    // k_bin of this pass may run on its own stream, concurrently with the k_fuse of the previous pass
+    // (it depends on the cloud and the pose, not on the map).  Only with the handle's own stream:
+    // a caller-provided stream keeps everything in order on that stream.  Device-resident inputs
+    // must be complete when the call is made (they are not ordered against the handle's streams).
+    // The cross-stream event pair costs ~3 us per pass (measured), so it only pays for big passes
+    // (batches / aggregated clouds: C4 379 -> 313 us); single sweeps stay on one stream.
+    const bool overlap = h->overlap && in.n >= h->overlap_min_points && h->stream == h->own_stream && h->bin_stream &&
+                         !h->counting && !h->dbg_on;
+    gem_handle::PassBuffers& pb = h->pb[overlap ? (h->pass++ & 1u) : 0u];
+    hipStream_t sbin = overlap ? h->bin_stream : h->stream;
+    if (!overlap && h->pb[0].fuse_recorded && h->stream != h->own_stream) {
+        // switching from overlapped passes to a caller stream: order it behind everything enqueued so far
+        for (auto& b : h->pb) if (b.fuse_recorded) GEM_HIP(h, hipStreamWaitEvent(h->stream, b.fuse_done, 0));
+    }
     int rc;
-    if ((rc = ensure(h, h->rec, (size_t)B * U * sizeof(uint4)))) return rc;
+    if ((rc = ensure(h, pb.rec, (size_t)B * U * sizeof(uint4)))) return rc;
+    if (overlap && pb.fuse_recorded) GEM_HIP(h, hipStreamWaitEvent(sbin, pb.fuse_done, 0));   // k_fuse of pass p-2 has read these buffers
     {   // descriptor table: words are stamped with an epoch instead of being cleared every pass
-        const size_t need = (size_t)h->T * B * sizeof(uint32_t);
-        const bool grow = need > h->seg.cap;
-        if ((rc = ensure(h, h->seg, need))) return rc;
-        if (grow || h->epoch >= kSegEpochMax) {
-            GEM_HIP(h, hipMemsetAsync(h->seg.p, 0, h->seg.cap, h->stream));
-            h->epoch = 0;
+        const size_t need = (size_t)T * B * sizeof(uint32_t);
+        const bool grow = need > pb.seg.cap;
+        if ((rc = ensure(h, pb.seg, need))) return rc;
+        const size_t need_flag = (size_t)T * in.n_sweeps * sizeof(uint32_t);
+        const bool grow_flag = need_flag > pb.flag.cap;
+        if ((rc = ensure(h, pb.flag, need_flag))) return rc;
+        if (grow || grow_flag || pb.epoch >= kSegEpochMax) {
+            GEM_HIP(h, hipMemsetAsync(pb.seg.p, 0, pb.seg.cap, sbin));
+            GEM_HIP(h, hipMemsetAsync(pb.flag.p, 0, pb.flag.cap, sbin));
+            pb.epoch = 0;
         }
-        ++h->epoch;
+        ++pb.epoch;
     }
 
     BinArgs ba{};
@@ -260,15 +301,15 @@ int run_pipeline(gem_handle* h, const PassInput& in)
         const size_t o_first = (o_unit0 + sizeof(int) * (in.n_sweeps + 1) + 15) & ~(size_t)15;
         const size_t o_var = o_first + sizeof(long long) * (in.n_sweeps + 1);
         const size_t total = o_var + sizeof(float) * in.n_sweeps;
-        if ((rc = ensure(h, h->tables, total))) return rc;
+        if ((rc = ensure(h, pb.tables, total))) return rc;
         std::vector<unsigned char> host(total, 0);
         for (int s = 0; s < in.n_sweeps; ++s) fill_frame(h, &in.params[s], reinterpret_cast<FrameConst*>(host.data() + o_frames)[s]);
         memcpy(host.data() + o_unit0, unit0.data(), sizeof(int) * (in.n_sweeps + 1));
         memcpy(host.data() + o_first, in.offsets, sizeof(long long) * (in.n_sweeps + 1));
         if (in.var_updates) memcpy(host.data() + o_var, in.var_updates, sizeof(float) * in.n_sweeps);
-        GEM_HIP(h, hipMemcpyAsync(h->tables.p, host.data(), total, hipMemcpyHostToDevice, h->stream));
-        GEM_HIP(h, hipStreamSynchronize(h->stream));      // `host` is a local
-        unsigned char* d = static_cast<unsigned char*>(h->tables.p);
+        GEM_HIP(h, hipMemcpyAsync(pb.tables.p, host.data(), total, hipMemcpyHostToDevice, sbin));
+        GEM_HIP(h, hipStreamSynchronize(sbin));           // `host` is a local
+        unsigned char* d = static_cast<unsigned char*>(pb.tables.p);
         ba.frames = reinterpret_cast<const FrameConst*>(d + o_frames);
         ba.sweep_unit0 = reinterpret_cast<const int*>(d + o_unit0);
         ba.sweep_first = reinterpret_cast<const long long*>(d + o_first);
@@ -281,15 +322,15 @@ int run_pipeline(gem_handle* h, const PassInput& in)
     ba.xyzi = in.xyzi; ba.rgb = in.rgb; ba.orig = in.orig;
     ba.f_index = in.f_index; ba.f_height = in.f_height; ba.f_var = in.f_var;
     ba.f_R = in.f_R; ba.f_G = in.f_G; ba.f_B = in.f_B; ba.f_I = in.f_I;
-    ba.T = h->T; ba.tiles_per_row = h->tiles_per_row; ba.B = B;
-    ba.tile_bits = 0; while ((1 << ba.tile_bits) < h->T) ++ba.tile_bits;
-    ba.epoch = h->epoch;
-    ba.rec = static_cast<uint4*>(h->rec.p); ba.seg = static_cast<uint32_t*>(h->seg.p);
+    ba.T = T; ba.tiles_per_row = tiles_per_row; ba.B = B;
+    ba.tile_bits = 0; while ((1 << ba.tile_bits) < T) ++ba.tile_bits;
+    ba.epoch = pb.epoch;
+    ba.rec = static_cast<uint4*>(pb.rec.p); ba.seg = static_cast<uint32_t*>(pb.seg.p); ba.flag = static_cast<uint32_t*>(pb.flag.p);
     ba.counters = h->counting ? h->d_counters : nullptr;
 
-    fa.epoch = h->epoch;
-    fa.rec = ba.rec; fa.seg = ba.seg; fa.B_total = B; fa.U = U; fa.n_sweeps = in.n_sweeps; fa.Bpad = bpad;
-    fa.T = h->T; fa.tiles_per_row = h->tiles_per_row; fa.L = h->L; fa.row0 = h->row0; fa.row1 = h->row1;
+    fa.epoch = pb.epoch;
+    fa.rec = ba.rec; fa.seg = ba.seg; fa.flag = ba.flag; fa.B_total = B; fa.U = U; fa.n_sweeps = in.n_sweeps; fa.Bpad = bpad;
+    fa.T = T; fa.tiles_per_row = tiles_per_row; fa.L = h->L; fa.row0 = h->row0; fa.row1 = h->row1;
     fa.mahal = h->cfg.mahalanobis_threshold; fa.var_floor = h->cfg.variance_floor;
     fa.dense = dense ? 1 : 0;
     fa.n_pending = h->n_pending;
@@ -300,14 +341,19 @@ int run_pipeline(gem_handle* h, const PassInput& in)
     fa.counters = ba.counters;
     fa.dbg = nullptr;
     if (h->dbg_on) {
-        if ((rc = ensure(h, h->dbg, (size_t)h->T * 16 * 8))) return rc;
-        GEM_HIP(h, hipMemsetAsync(h->dbg.p, 0, (size_t)h->T * 16 * 8, h->stream));
+        if ((rc = ensure(h, h->dbg, (size_t)T * 16 * 8))) return rc;
+        GEM_HIP(h, hipMemsetAsync(h->dbg.p, 0, (size_t)T * 16 * 8, h->stream));
         fa.dbg = static_cast<unsigned long long*>(h->dbg.p);
     }
 
     if (h->counting) GEM_HIP(h, hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
-    { Timed t(h, 0); GEM_HIP(h, launch_bin(h->stream, ba, ipt, in.src, h->ts, t.events())); }
-    { Timed t(h, 1); GEM_HIP(h, launch_fuse(h->stream, fa, h->ts, attr, h->fuse_variant, t.events())); }
+    { Timed t(h, 0); GEM_HIP(h, launch_bin(sbin, ba, ipt, in.src, ts, t.events())); }
+    if (overlap) {
+        GEM_HIP(h, hipEventRecord(pb.bin_done, sbin));
+        GEM_HIP(h, hipStreamWaitEvent(h->stream, pb.bin_done, 0));
+    }
+    { Timed t(h, 1); GEM_HIP(h, launch_fuse(h->stream, fa, ts, attr, h->fuse_variant, t.events())); }
+    if (overlap) { GEM_HIP(h, hipEventRecord(pb.fuse_done, h->stream)); pb.fuse_recorded = true; }
     h->n_pending = 0;
     h->floor_dirty = false;
     h->stats.points_in = in.n;
@@ -349,18 +395,23 @@ int gem_create(const gem_map_config* cfg, gem_handle** out)
         if (cfg->strip_row0 < 0 || cfg->strip_row0 + cfg->strip_rows > h->L) { delete h; return fail(nullptr, GEM_ERR_INVALID, "gem_create: bad strip"); }
         h->row0 = cfg->strip_row0; h->row1 = cfg->strip_row0 + cfg->strip_rows;
     }
-    h->ts = h->L <= 1024 ? 5 : 6;
-    if (const char* s = getenv("GEM_TILE_SHIFT")) { int v = atoi(s); if (v >= 4 && v <= 6) h->ts = v; }
+    h->fuse_variant = 11;                       // k_fuse_list (10: 256 threads per 32x32 tile, 11: 512); < 10: k_fuse
     if (const char* s = getenv("GEM_FUSE_VARIANT")) h->fuse_variant = atoi(s);
+    h->ts = 0;                                  // 0: chosen per pass (run_pipeline)
+    if (h->fuse_variant < 10) h->ts = h->L > 1024 ? 6 : 5;
+    if (const char* s = getenv("GEM_TILE_SHIFT")) { int v = atoi(s); if (v >= 4 && v <= (h->fuse_variant >= 10 ? 5 : 6)) h->ts = v; }
     if (const char* s = getenv("GEM_IPT")) h->ipt_override = atoi(s);
-    const int te = 1 << h->ts;
-    h->tiles_per_row = (h->L + te - 1) / te;
-    h->T = h->tiles_per_row * h->tiles_per_row;
 
     auto bail = [&](const char* what, hipError_t err) { int rc = fail(nullptr, GEM_ERR_HIP, what, err); gem_destroy(h); return rc; };
     if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     h->stream = h->own_stream;
     if ((e = hipEventCreateWithFlags(&h->copy_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipStreamCreateWithFlags(&h->bin_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    for (auto& b : h->pb) {
+        if ((e = hipEventCreateWithFlags(&b.bin_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreateWithFlags(&b.fuse_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    }
+    if (const char* s = getenv("GEM_OVERLAP")) { h->overlap = atoi(s) != 0; if (atoi(s) > 1) h->overlap_min_points = 0; }
     // one allocation for the 8 layers (gpu_process.cu:954-961 uses 8 cudaMalloc)
     void* base = nullptr;
     const size_t layer_bytes = ((size_t)h->cells * 4 + 255) & ~(size_t)255;
@@ -387,12 +438,19 @@ void gem_destroy(gem_handle* h)
     if (!h) return;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->bin_stream) hipStreamSynchronize(h->bin_stream);
     if (h->comm) ncclCommDestroy(h->comm);
     fold_events(h);
     for (auto& ep : h->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
     if (h->layers.elevation) hipFree(h->layers.elevation);      // base of the single layer allocation
     if (h->d_counters) hipFree(h->d_counters);
-    for (Arena* a : {&h->stage, &h->rec, &h->seg, &h->tables, &h->scratch, &h->dbg}) if (a->p) hipFree(a->p);
+    for (Arena* a : {&h->stage, &h->scratch, &h->dbg}) if (a->p) hipFree(a->p);
+    for (auto& b : h->pb) {
+        for (Arena* a : {&b.rec, &b.seg, &b.flag, &b.tables}) if (a->p) hipFree(a->p);
+        if (b.bin_done) hipEventDestroy(b.bin_done);
+        if (b.fuse_done) hipEventDestroy(b.fuse_done);
+    }
+    if (h->bin_stream) hipStreamDestroy(h->bin_stream);
     if (h->copy_done) hipEventDestroy(h->copy_done);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
@@ -404,6 +462,7 @@ int gem_set_stream(gem_handle* h, void* hip_stream)
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
     GEM_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->bin_stream) GEM_HIP(h, hipStreamSynchronize(h->bin_stream));
     h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
     return GEM_OK;
 }

@@ -184,7 +184,10 @@ __global__ __launch_bounds__(256) void k_bin_wave(BinArgs a)
     const int my_leader = valid ? (__ffsll((unsigned long long)peers) - 1) : lane;
     const uint32_t start = (uint32_t)__shfl((int)start_leader, my_leader, 64);
     if (valid) a.rec[(size_t)unit * U + start + rank] = make_uint4(cl, __float_as_uint(hh), __float_as_uint(vv), src);
-    if (leader) a.seg[(size_t)tile * a.B + unit] = (a.epoch << kSegEpochShift) | (start << kSegCountBits) | cnt;
+    if (leader) {
+        a.seg[(size_t)tile * a.B + unit] = (a.epoch << kSegEpochShift) | (start << kSegCountBits) | cnt;
+        a.flag[(size_t)sweep * a.T + tile] = a.epoch;              // "tile touched in this sweep" (same value from every writer)
+    }
 
     if (a.counters) {
         const uint32_t nb = (uint32_t)__popcll(__ballot(valid));
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(64) void k_bin_lds(BinArgs a)
         if (t < T) {
             const uint32_t c = lds_cnt[t];
             lds_cnt[t] = run;                                       // becomes the running base of tile t
-            if (c) seg[(size_t)t * a.B + unit] = (a.epoch << kSegEpochShift) | (run << kSegCountBits) | c;
+            if (c) { seg[(size_t)t * a.B + unit] = (a.epoch << kSegEpochShift) | (run << kSegCountBits) | c; a.flag[(size_t)sweep * a.T + t] = a.epoch; }
             run += c;
         }
     }
@@ -624,6 +627,449 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 6 : 4)) void k_fuse(FuseArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
+// k_fuse_list : one workgroup of NT threads per tile -- the lean fuse.
+// ------------------------------------------------------------------------------------------
+// No counting sort and no scan over cells.  Per sweep and per chunk of kChunkUnits units:
+//   1. every thread reads UPT words of the tile's descriptor row; ONE packed block scan gives the
+//      ORDERED compaction of the live descriptors (unit order == input order) and their record
+//      prefix, so every record gets a deterministic LDS slot that is monotone in input order;
+//   2. batches of <= PB records: the batch's descriptors are split into NW contiguous ranges, one
+//      per wave; lanes < count gather the records (16 B / lane) into LDS, next loads in flight;
+//   3a. FAST PATH (at most kRankMax records per cell and batch -- every LiDAR case): an LDS atomic
+//      on the cell's row {slot[0..6], count} hands out arrival ranks; the cell's owner sorts its
+//      <= 7 slot numbers with a register sorting network (slot order == input order) and runs the
+//      reference's recurrence (GPU:480-531) from registers;
+//   3b. GENERIC PATH (some cell got more): every wave appends its share of the batch, in order, to
+//      its own per-cell linked list in LDS (head/tail[cell][wave], next[slot]; equal cells inside
+//      one wave instruction are chained by a ballot match), and the owner walks list(wave 0),
+//      list(wave 1), ... -- input order by construction, any multiplicity.
+// The tile's elevation / variance are read once and written once.  LDS is sized by the tile:
+// 16x16 tiles with PB = 1024 need ~26 KB (6 workgroups per CU, so the latencies of one tile's
+// phases hide behind other tiles), 32x32 tiles with PB = 4096 ~ 88 KB.
+constexpr int kChunkUnits = 2048;        // descriptor words scanned per block pass
+constexpr int kRankMax    = 7;           // fast path: records per cell and batch
+constexpr int fuse_list_max_batches(int pb) { return kChunkUnits * 256 / (pb - 256) + 2; }
+
+#define GEM_CSWAP(a, b) do { const uint32_t lo_ = min(a, b), hi_ = max(a, b); a = lo_; b = hi_; } while (0)
+
+template <int TS, int NT, int PB, int ATTR>
+__global__ __launch_bounds__(NT, (TS == 4 ? 4 : 2)) void k_fuse_list(FuseArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr int TE = 1 << TS;
+    constexpr int CELLS = TE * TE;
+    constexpr int NW = NT / 64;
+    constexpr int CPT = CELLS / NT;
+    constexpr int UPT = kChunkUnits / NT;            // descriptor words per thread and chunk (4 or 8)
+    constexpr int DCAP = PB < kChunkUnits ? PB : kChunkUnits;      // a batch has at most one descriptor per record
+    constexpr int MAXB = fuse_list_max_batches(PB);
+    constexpr uint32_t Q = PB - 256;                 // batch b = descriptors whose record prefix lies in [b*Q, (b+1)*Q)
+    constexpr uint32_t NIL = 0xffffu;
+    constexpr int XBYTES = CELLS * NW * 4 > CELLS * 16 ? CELLS * NW * 4 : CELLS * 16;
+    static_assert(CELLS % NT == 0 && UPT % 4 == 0 && (NW == 4 || NW == 8) && PB >= 512 && PB <= 4096, "geometry");
+
+    // region X: fast path rows[CELLS] of 8 u16 {slot 0..6, count}; generic path head / tail[CELLS][NW]
+    uint16_t* rowp    = reinterpret_cast<uint16_t*>(lds_raw);
+    uint16_t* head    = rowp;
+    uint16_t* tail    = head + CELLS * NW;
+    uint16_t* nxt     = reinterpret_cast<uint16_t*>(lds_raw + XBYTES);     // [PB]
+    float*    s_h     = reinterpret_cast<float*>(nxt + PB);                // [PB]
+    float*    s_v     = s_h + PB;                                          // [PB]
+    uint32_t* s_src   = reinterpret_cast<uint32_t*>(s_v + PB);             // [PB] only when ATTR != 0
+    uint32_t* dl_addr = s_src + (ATTR ? PB : 0);                           // [DCAP] arena index of the first record
+    uint32_t* dl_rc   = dl_addr + DCAP;                                    // [DCAP] record prefix << 9 | count
+    uint32_t* bstart  = dl_rc + DCAP;                                      // [MAXB + 1] first descriptor of each batch
+    uint32_t* scratch = bstart + MAXB + 1;                                 // [16]
+    uint32_t* misc    = scratch + 16;                                      // [0] touched cells of the sweep, [1] fast-path overflow
+
+    const int tid = (int)threadIdx.x;
+    const int lane = lane_id();
+    const int w = tid >> 6;
+    const int tile = (int)blockIdx.x;
+    const int tr = tile / a.tiles_per_row, tc = tile - tr * a.tiles_per_row;
+    const int row_base = tr << TS, col_base = tc << TS;
+    const int L = a.L;
+    const uint32_t* seg = a.seg + (size_t)tile * a.B_total;
+    const uint32_t epoch = a.epoch;
+    const uint64_t lt = lanemask_lt();
+    int dbg_k = 0;
+#define GEM_STAMP() do { if (a.dbg && tid == 0 && dbg_k < 16) a.dbg[(size_t)tile * 16 + dbg_k++] = (unsigned long long)__builtin_readcyclecounter(); } while (0)
+    GEM_STAMP();                                                         // 0: start
+
+    // descriptor words of the first chunk of sweep 0: issued before anything else so that their
+    // latency overlaps the flag test and the tile read
+    uint32_t ev[UPT];
+    {
+        const int B0 = a.sweep_unit0 ? a.sweep_unit0[1] - a.sweep_unit0[0] : a.B_total;
+        const int ub0 = a.sweep_unit0 ? a.sweep_unit0[0] : 0;
+        const int u0 = tid * UPT;
+#pragma unroll
+        for (int x = 0; x < UPT / 4; ++x) {
+            uint4 e = make_uint4(0, 0, 0, 0);
+            if (u0 + 4 * x < B0) e = *reinterpret_cast<const uint4*>(seg + ub0 + u0 + 4 * x);     // rows are padded to 4 units
+            ev[4 * x] = e.x; ev[4 * x + 1] = e.y; ev[4 * x + 2] = e.z; ev[4 * x + 3] = e.w;
+        }
+    }
+
+    // ---- the single read of the tile (issued before the flag test: one memory latency, not two) ----
+    float ce[CPT], cs[CPT];
+    bool  owned[CPT];
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const int c = tid + NT * q;
+        const int row = row_base + (c >> TS), col = col_base + (c & (TE - 1));
+        owned[q] = row < a.row1 && row >= a.row0 && col < L;
+        ce[q] = kEmptyElevation; cs[q] = kInitVariance;
+        if (owned[q]) {
+            const size_t g = (size_t)row * L + col;
+            ce[q] = a.elevation[g]; cs[q] = a.variance[g];
+        }
+    }
+
+    // does this tile receive any point of this pass?  (k_bin stamps flag[sweep][tile] with the epoch)
+    bool any_touched = false;
+    for (int s = 0; s < a.n_sweeps; ++s) any_touched |= a.flag[(size_t)s * a.T + tile] == epoch;   // block-uniform scalar loads
+    if (!any_touched && !a.dense) return;
+
+    {   // fast-path rows start with count 0; the owner leaves every row it consumed at count 0 again
+        uint4* z = reinterpret_cast<uint4*>(rowp);
+        for (int c = tid; c < CELLS; c += NT) z[c] = make_uint4(0, 0, 0, 0);
+        if (tid == 0) misc[1] = 0;
+    }
+    GEM_STAMP();                                                         // 1: tile loads issued
+
+    for (int sweep = 0; sweep < a.n_sweeps; ++sweep) {
+        const int ub = a.sweep_unit0 ? a.sweep_unit0[sweep] : 0;        // multiple of 4 (host pads sweeps)
+        const int ue = a.sweep_unit0 ? a.sweep_unit0[sweep + 1] : a.B_total;
+        const int B = ue - ub;
+
+        // ---- Mapvar_update increments queued before this sweep (GPU:540-547) ----------------------
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            if (sweep == 0)
+                for (int k = 0; k < a.n_pending; ++k) if (cs[q] != kInitVariance) cs[q] += a.pending[k];
+            if (a.var_updates) { if (cs[q] != kInitVariance) cs[q] += a.var_updates[sweep]; }
+        }
+        if (a.counters && tid == 0) misc[0] = 0;
+        uint32_t tmask = 0;                                              // cells of this thread touched in this sweep
+
+        const bool touched_sweep = a.flag[(size_t)sweep * a.T + tile] == epoch;      // block-uniform
+        for (int cbase = 0; touched_sweep && cbase < B; cbase += kChunkUnits) {
+            // ---- 1. ordered compaction of the chunk's live descriptors ----------------------------
+            const int u0 = cbase + tid * UPT;
+            if (sweep != 0 || cbase != 0) {
+#pragma unroll
+                for (int x = 0; x < UPT / 4; ++x) {
+                    uint4 e = make_uint4(0, 0, 0, 0);
+                    if (u0 + 4 * x < B) e = *reinterpret_cast<const uint4*>(seg + ub + u0 + 4 * x);
+                    ev[4 * x] = e.x; ev[4 * x + 1] = e.y; ev[4 * x + 2] = e.z; ev[4 * x + 3] = e.w;
+                }
+            }
+            uint32_t packed = 0;                                         // live descriptors << 20 | records
+#pragma unroll
+            for (int j = 0; j < UPT; ++j) {
+                const bool live = (ev[j] >> kSegEpochShift) == epoch && u0 + j < B && (ev[j] & kSegCountMask) != 0;
+                if (!live) ev[j] = 0;
+                packed += live ? ((1u << 20) | (ev[j] & kSegCountMask)) : 0u;
+            }
+            if (a.dbg) { asm volatile("" :: "v"(packed)); GEM_STAMP(); }                      // 2: descriptor words arrived
+            uint32_t tot;
+            const uint32_t run = block_exclusive_scan<NT>(packed, scratch, &tot);
+            const uint32_t nd = tot >> 20, P = tot & 0xfffffu;
+            if (P == 0) continue;                                        // block-uniform
+            const uint32_t nb = (P - 1u) / Q + 1u;                       // every batch is non-empty (a descriptor holds < Q records)
+            if (nb > 1) {
+                for (uint32_t i = tid; i < nb; i += NT) bstart[i] = 0xffffffffu;
+                if (tid == 0) bstart[nb] = nd;
+                __syncthreads();
+                uint32_t d = run >> 20, rs = run & 0xfffffu;
+#pragma unroll
+                for (int j = 0; j < UPT; ++j)
+                    if (ev[j] != 0) { atomicMin(&bstart[rs / Q], d); ++d; rs += ev[j] & kSegCountMask; }
+                __syncthreads();
+            }
+
+            for (uint32_t b = 0; b < nb; ++b) {
+                const uint32_t d_lo = nb > 1 ? bstart[b] : 0u, d_hi = nb > 1 ? bstart[b + 1] : nd, m = d_hi - d_lo;
+                const uint32_t slot0 = b * Q;
+                {   // this batch's descriptors, in order
+                    uint32_t d = run >> 20, rs = run & 0xfffffu;
+#pragma unroll
+                    for (int j = 0; j < UPT; ++j) {
+                        if (ev[j] != 0) {
+                            const uint32_t cnt = ev[j] & kSegCountMask;
+                            if (d >= d_lo && d < d_hi) {
+                                dl_addr[d - d_lo] = (uint32_t)(ub + u0 + j) * (uint32_t)a.U + ((ev[j] >> kSegCountBits) & kSegStartMask);
+                                dl_rc[d - d_lo] = (rs << 9) | cnt;
+                            }
+                            ++d; rs += cnt;
+                        }
+                    }
+                }
+                __syncthreads();
+                GEM_STAMP();                                             // 3: descriptor list built
+
+                // ---- 2 + 3a. gather into LDS in input order (record k -> slot k - slot0) and take an
+                //      arrival rank per cell for the fast path.  Wave w takes the w-th contiguous share of
+                //      the batch's descriptors, one descriptor per step (lanes < count), with the loads of
+                //      the next PF descriptors in flight while the current PF are being filed.
+                const uint32_t dw0 = (m * (uint32_t)w) / NW, dw1 = (m * (uint32_t)(w + 1)) / NW;
+                constexpr int PF = TS == 4 ? 2 : 4;
+                uint4 rA[PF], rB[PF]; uint32_t sA[PF], sB[PF];           // slot == ~0: lane inactive
+                auto fetch = [&](uint32_t dd, uint4 (&rr)[PF], uint32_t (&sl)[PF]) {
+#pragma unroll
+                    for (int x = 0; x < PF; ++x) {
+                        sl[x] = 0xffffffffu; rr[x] = make_uint4(0, 0, 0, 0);
+                        if (dd + x < dw1) {                              // wave-uniform
+                            const uint32_t rc = dl_rc[dd + x];
+                            if ((uint32_t)lane < (rc & 0x1ffu)) {
+                                sl[x] = (rc >> 9) - slot0 + (uint32_t)lane;
+                                rr[x] = a.rec[dl_addr[dd + x] + (uint32_t)lane];
+                            }
+                        }
+                    }
+                };
+                auto file_one = [&](const uint4& r, uint32_t sl) {
+                    const uint32_t cell = r.x & 0xffffu;
+                    s_h[sl] = __uint_as_float(r.y); s_v[sl] = __uint_as_float(r.z);
+                    if (ATTR) s_src[sl] = (r.w & 0x7fffffffu) | (r.x & 0x80000000u);
+                    nxt[sl] = (uint16_t)cell;                            // the generic path reads the cell from here
+                    const uint32_t old = atomicAdd(reinterpret_cast<uint32_t*>(rowp) + cell * 4 + 3, 0x10000u);
+                    const uint32_t rk = old >> 16;
+                    if (rk < (uint32_t)kRankMax) rowp[cell * 8 + rk] = (uint16_t)sl;
+                    else misc[1] = 1u;
+                };
+                auto file = [&](uint32_t dd, const uint4 (&rr)[PF], const uint32_t (&sl)[PF]) {
+#pragma unroll
+                    for (int x = 0; x < PF; ++x) {
+                        if (sl[x] != 0xffffffffu) file_one(rr[x], sl[x]);
+                        if (dd + x < dw1) {                              // wave-uniform; units of more than 64 points only
+                            const uint32_t rc = dl_rc[dd + x], cnt = rc & 0x1ffu;
+                            for (uint32_t o = 64; o < cnt; o += 64) {
+                                if (o + (uint32_t)lane < cnt) file_one(a.rec[dl_addr[dd + x] + o + (uint32_t)lane], (rc >> 9) - slot0 + o + (uint32_t)lane);
+                            }
+                        }
+                    }
+                };
+                if (dw0 < dw1) {
+                    fetch(dw0, rA, sA);
+                    for (uint32_t dd = dw0; dd < dw1; dd += 2 * PF) {   // wave-uniform
+                        fetch(dd + PF, rB, sB);
+                        file(dd, rA, sA);
+                        fetch(dd + 2 * PF, rA, sA);
+                        file(dd + PF, rB, sB);
+                    }
+                }
+                __syncthreads();
+                GEM_STAMP();                                             // 4: records in LDS, ranked
+
+                if (misc[1] == 0) {
+                    // ---- 3a. owner: sort <= 7 slot numbers, run the chains from registers.  The CPT cells
+                    //      of a thread are independent chains: everything is straight-line with selects so
+                    //      that their sorting networks and IEEE divisions interleave.
+                    uint4 row[CPT]; uint32_t n[CPT], nmax = 0;
+#pragma unroll
+                    for (int q = 0; q < CPT; ++q) row[q] = *reinterpret_cast<const uint4*>(rowp + (tid + NT * q) * 8);
+                    uint32_t ps[CPT][kRankMax];
+#pragma unroll
+                    for (int q = 0; q < CPT; ++q) {
+                        n[q] = row[q].w >> 16;
+                        nmax = max(nmax, n[q]);
+                        if (n[q] != 0) { reinterpret_cast<uint32_t*>(rowp + (tid + NT * q) * 8)[3] = 0u; tmask |= 1u << q; }
+                        uint32_t p0 = row[q].x & 0xffffu, p1 = row[q].x >> 16, p2 = row[q].y & 0xffffu, p3 = row[q].y >> 16,
+                                 p4 = row[q].z & 0xffffu, p5 = row[q].z >> 16, p6 = row[q].w & 0xffffu, p7 = NIL;
+                        if (n[q] < 1) p0 = NIL; if (n[q] < 2) p1 = NIL; if (n[q] < 3) p2 = NIL; if (n[q] < 4) p3 = NIL;
+                        if (n[q] < 5) p4 = NIL; if (n[q] < 6) p5 = NIL; if (n[q] < 7) p6 = NIL;
+                        GEM_CSWAP(p0, p1); GEM_CSWAP(p2, p3); GEM_CSWAP(p4, p5); GEM_CSWAP(p6, p7);
+                        GEM_CSWAP(p0, p2); GEM_CSWAP(p1, p3); GEM_CSWAP(p4, p6); GEM_CSWAP(p5, p7);
+                        GEM_CSWAP(p1, p2); GEM_CSWAP(p5, p6); GEM_CSWAP(p0, p4); GEM_CSWAP(p3, p7);
+                        GEM_CSWAP(p1, p5); GEM_CSWAP(p2, p6);
+                        GEM_CSWAP(p1, p4); GEM_CSWAP(p3, p6);
+                        GEM_CSWAP(p2, p4); GEM_CSWAP(p3, p5);
+                        GEM_CSWAP(p3, p4);
+                        ps[q][0] = p0; ps[q][1] = p1; ps[q][2] = p2; ps[q][3] = p3; ps[q][4] = p4; ps[q][5] = p5; ps[q][6] = p6;
+                    }
+                    float hh[CPT][kRankMax], vv[CPT][kRankMax]; uint32_t sv[CPT][kRankMax];
+#pragma unroll
+                    for (int i = 0; i < kRankMax; ++i) {
+                        if (__ballot((uint32_t)i < nmax) == 0) break;    // wave-uniform
+#pragma unroll
+                        for (int q = 0; q < CPT; ++q) {
+                            const uint32_t sl = (uint32_t)i < n[q] ? ps[q][i] : 0u;       // slot 0 is always a valid address
+                            hh[q][i] = s_h[sl]; vv[q][i] = s_v[sl];
+                            if (ATTR) sv[q][i] = s_src[sl];
+                        }
+                    }
+                    uint32_t wlast[CPT];
+#pragma unroll
+                    for (int q = 0; q < CPT; ++q) wlast[q] = 0xffffffffu;
+#pragma unroll
+                    for (int i = 0; i < kRankMax; ++i) {
+                        if (__ballot((uint32_t)i < nmax) == 0) break;    // wave-uniform
+#pragma unroll
+                        for (int q = 0; q < CPT; ++q) {
+                            float e2 = ce[q], s2 = cs[q];
+                            const bool taken = fuse_step(e2, s2, hh[q][i], vv[q][i], a.mahal, a.var_floor);
+                            const bool live = (uint32_t)i < n[q];
+                            ce[q] = live ? e2 : ce[q]; cs[q] = live ? s2 : cs[q];
+                            if (ATTR) { if (live && taken && (sv[q][i] & 0x80000000u)) wlast[q] = sv[q][i] & 0x7fffffffu; }
+                        }
+                    }
+                    if (ATTR) {
+#pragma unroll
+                        for (int q = 0; q < CPT; ++q) {
+                            if (wlast[q] != 0xffffffffu) {
+                                // colour / intensity of the last taken point with all four non-zero (GPU:487-494)
+                                const int c = tid + NT * q;
+                                const int row_g = row_base + (c >> TS), col_g = col_base + (c & (TE - 1));
+                                const size_t g = (size_t)row_g * L + col_g;
+                                const uint32_t last = wlast[q];
+                                if (ATTR == 1) {
+                                    const uint32_t cc = a.rgb[last];
+                                    a.intensity[g] = a.xyzi[last].w;
+                                    a.colorR[g] = (int)((cc >> 16) & 0xff); a.colorG[g] = (int)((cc >> 8) & 0xff); a.colorB[g] = (int)(cc & 0xff);
+                                } else {
+                                    a.intensity[g] = a.f_I[last];
+                                    a.colorR[g] = a.f_R[last]; a.colorG[g] = a.f_G[last]; a.colorB[g] = a.f_B[last];
+                                }
+                            }
+                        }
+                    }
+                } else {
+                    // ---- 3b. generic path: per-wave in-order linked lists --------------------------
+                    const uint32_t k_lo = dl_rc[0] >> 9;
+                    const uint32_t Pb = (dl_rc[m - 1] >> 9) + (dl_rc[m - 1] & 0x1ffu) - k_lo;      // records of this batch
+                    {
+                        uint4* z = reinterpret_cast<uint4*>(head);
+                        for (int c = tid; c < CELLS * NW / 8; c += NT) z[c] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+                    }
+                    __syncthreads();
+                    if (tid == 0) misc[1] = 0u;
+                    {   // wave w appends records [w * per, (w + 1) * per) of the batch, 64 consecutive records per step
+                        const uint32_t per = ((Pb + NW * 64u - 1u) / (NW * 64u)) * 64u;
+                        const uint32_t kbeg = (uint32_t)w * per, kend = min(Pb, kbeg + per);
+                        for (uint32_t kc = kbeg; kc < kend; kc += 64) {   // wave-uniform
+                            const bool on = kc + (uint32_t)lane < kend;
+                            const uint32_t sl = k_lo - slot0 + kc + (uint32_t)lane;
+                            const uint32_t cell = on ? (uint32_t)nxt[sl] : 0u;
+                            const uint64_t peers = wave_peers(on, cell, 2 * TS);
+                            const uint64_t above = lane == 63 ? 0ull : (peers & (~0ull << (lane + 1)));
+                            if (on) {
+                                nxt[sl] = above ? (uint16_t)(sl + (uint32_t)(__ffsll((unsigned long long)above) - 1 - lane)) : (uint16_t)NIL;
+                                const uint32_t hi = cell * NW + (uint32_t)w;
+                                if ((peers & lt) == 0) {                  // first of its group: link behind the wave's list of this cell
+                                    if (head[hi] == NIL) head[hi] = (uint16_t)sl;
+                                    else nxt[tail[hi]] = (uint16_t)sl;
+                                }
+                                if (above == 0) tail[hi] = (uint16_t)sl;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    // walk: the CPT cells of a thread advance together (independent chains), one node per
+                    // cell and iteration, through list(wave 0), list(wave 1), ...
+                    {
+                        uint32_t cur[CPT], wwq[CPT], wl[CPT], hdp[CPT][NW];
+                        bool more = false;
+#pragma unroll
+                        for (int q = 0; q < CPT; ++q) {
+                            const int c = tid + NT * q;
+                            if constexpr (NW == 4) {
+                                const uint2 hv = *reinterpret_cast<const uint2*>(head + c * NW);
+                                hdp[q][0] = hv.x & 0xffffu; hdp[q][1] = hv.x >> 16; hdp[q][2] = hv.y & 0xffffu; hdp[q][3] = hv.y >> 16;
+                            } else {
+                                const uint4 hv = *reinterpret_cast<const uint4*>(head + c * NW);
+                                hdp[q][0] = hv.x & 0xffffu; hdp[q][1] = hv.x >> 16; hdp[q][2] = hv.y & 0xffffu; hdp[q][3] = hv.y >> 16;
+                                hdp[q][4] = hv.z & 0xffffu; hdp[q][5] = hv.z >> 16; hdp[q][6] = hv.w & 0xffffu; hdp[q][7] = hv.w >> 16;
+                            }
+                            // chain the wave lists of the cell: cur = first non-empty head, and each list's
+                            // successor is the next non-empty head (resolved when its NIL end is reached)
+                            cur[q] = NIL; wwq[q] = NW; wl[q] = 0xffffffffu;
+#pragma unroll
+                            for (int ww = NW - 1; ww >= 0; --ww) if (hdp[q][ww] != NIL) { cur[q] = hdp[q][ww]; wwq[q] = (uint32_t)ww; }
+                            if (cur[q] != NIL) { tmask |= 1u << q; more = true; }
+                        }
+                        while (__ballot(more) != 0) {                    // wave-uniform
+                            more = false;
+#pragma unroll
+                            for (int q = 0; q < CPT; ++q) {
+                                const bool live = cur[q] != NIL;
+                                const uint32_t sl = live ? cur[q] : 0u;
+                                const float h = s_h[sl], v = s_v[sl];
+                                uint32_t nx = nxt[sl];
+                                float e2 = ce[q], s2 = cs[q];
+                                const bool taken = fuse_step(e2, s2, h, v, a.mahal, a.var_floor);
+                                ce[q] = live ? e2 : ce[q]; cs[q] = live ? s2 : cs[q];
+                                if (ATTR) { const uint32_t sv = s_src[sl]; if (live && taken && (sv & 0x80000000u)) wl[q] = sv & 0x7fffffffu; }
+                                if (live && nx == NIL) {                 // end of this wave's list: continue with the next non-empty one
+                                    uint32_t nw_ = NW;
+#pragma unroll
+                                    for (int ww = NW - 1; ww >= 0; --ww) if ((uint32_t)ww > wwq[q] && hdp[q][ww] != NIL) { nx = hdp[q][ww]; nw_ = (uint32_t)ww; }
+                                    wwq[q] = nw_;
+                                }
+                                cur[q] = live ? nx : NIL;
+                                more |= cur[q] != NIL;
+                            }
+                        }
+                        if (ATTR) {
+#pragma unroll
+                            for (int q = 0; q < CPT; ++q) {
+                                if (wl[q] != 0xffffffffu) {
+                                    const int c = tid + NT * q;
+                                    const int row_g = row_base + (c >> TS), col_g = col_base + (c & (TE - 1));
+                                    const size_t g = (size_t)row_g * L + col_g;
+                                    const uint32_t last = wl[q];
+                                    if (ATTR == 1) {
+                                        const uint32_t cc = a.rgb[last];
+                                        a.intensity[g] = a.xyzi[last].w;
+                                        a.colorR[g] = (int)((cc >> 16) & 0xff); a.colorG[g] = (int)((cc >> 8) & 0xff); a.colorB[g] = (int)(cc & 0xff);
+                                    } else {
+                                        a.intensity[g] = a.f_I[last];
+                                        a.colorR[g] = a.f_R[last]; a.colorG[g] = a.f_G[last]; a.colorB[g] = a.f_B[last];
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    {   // back to the fast path's invariant: every row has count 0
+                        uint4* z = reinterpret_cast<uint4*>(rowp);
+                        for (int c = tid; c < CELLS; c += NT) z[c] = make_uint4(0, 0, 0, 0);
+                    }
+                }
+                __syncthreads();
+                GEM_STAMP();                                             // 5: walked
+            }
+        }
+
+        // ---- variance floor at the end of every Fuse (GPU:533-534), on every cell -----------------
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) if (cs[q] < a.var_floor) cs[q] = a.var_floor;
+
+        if (a.counters) {
+            __syncthreads();
+            if (tmask) atomicAdd(&misc[0], (uint32_t)__popc(tmask));
+            __syncthreads();
+            if (tid == 0 && misc[0]) atomicAdd(&a.counters[1], (unsigned long long)misc[0]);
+            __syncthreads();
+        }
+    }
+
+    // ---- the single write-back of the tile ---------------------------------------------------------
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        if (owned[q]) {
+            const int c = tid + NT * q;
+            const size_t g = (size_t)(row_base + (c >> TS)) * L + col_base + (c & (TE - 1));
+            a.elevation[g] = ce[q];
+            a.variance[g] = cs[q];
+        }
+    }
+    GEM_STAMP();                                                         // 6: stores issued
+#undef GEM_STAMP
+}
+
+// ------------------------------------------------------------------------------------------
 // dense / state kernels
 // ------------------------------------------------------------------------------------------
 // G_Init_map (GPU:198-214) and G_Clear_allmap (GPU:216-230; does not touch map_lowest)
@@ -788,17 +1234,68 @@ static hipError_t launch_fuse_attr(hipStream_t st, const FuseArgs& a, int attr, 
     return hipGetLastError();
 }
 
+// ---- k_fuse_list -------------------------------------------------------------------------------------
+static size_t fuse_list_lds(int cells, int nw, int pb, int attr)
+{
+    const size_t x = (size_t)cells * nw * 4 > (size_t)cells * 16 ? (size_t)cells * nw * 4 : (size_t)cells * 16;   // head + tail | rank rows
+    const size_t dcap = pb < kChunkUnits ? pb : kChunkUnits;
+    size_t b = x
+             + (size_t)pb * 2                          // nxt
+             + (size_t)pb * 4 * (attr ? 3 : 2)         // s_h, s_v (, s_src)
+             + dcap * 4 * 2                            // dl_addr, dl_rc
+             + (size_t)(fuse_list_max_batches(pb) + 1) * 4
+             + 16 * 4 + 16;                            // scratch, misc
+    return (b + 15) & ~(size_t)15;
+}
+
+// (tile shift, variant) -> threads per tile and records per LDS batch
+static void fuse_list_geometry(int ts, int variant, int* nt, int* pb)
+{
+    if (ts == 4) { *nt = 256; *pb = 1024; }
+    else         { *nt = variant == 10 ? 256 : 512; *pb = 4096; }
+}
+
+size_t fuse_list_lds_bytes(int ts, int variant, int attr)
+{
+    int nt, pb; fuse_list_geometry(ts, variant, &nt, &pb);
+    return fuse_list_lds((1 << (2 * ts)), nt / 64, pb, attr);
+}
+
+template <int TS, int NT, int PB>
+static hipError_t launch_fuse_list(hipStream_t st, const FuseArgs& a, int attr, LaunchEvents ev)
+{
+    const size_t lds = fuse_list_lds(1 << (2 * TS), NT / 64, PB, attr);
+    static size_t configured[3] = {0, 0, 0};
+    if (lds > 64 * 1024 && lds > configured[attr]) {
+        const void* fn = attr == 0 ? (const void*)k_fuse_list<TS, NT, PB, 0> : attr == 1 ? (const void*)k_fuse_list<TS, NT, PB, 1> : (const void*)k_fuse_list<TS, NT, PB, 2>;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured[attr] = lds;
+    }
+    if (attr == 0)      GEM_LAUNCH((k_fuse_list<TS, NT, PB, 0>), dim3(a.T), dim3(NT), lds, st, ev, a);
+    else if (attr == 1) GEM_LAUNCH((k_fuse_list<TS, NT, PB, 1>), dim3(a.T), dim3(NT), lds, st, ev, a);
+    else                GEM_LAUNCH((k_fuse_list<TS, NT, PB, 2>), dim3(a.T), dim3(NT), lds, st, ev, a);
+    return hipGetLastError();
+}
+
 // geometry of the fuse kernel for a tile shift: threads per tile and records per thread and batch
+// (variants 0..2: k_fuse, the LDS counting-sort kernel; variants >= 10: k_fuse_list)
 void fuse_geometry(int ts, int variant, int* nt, int* r)
 {
-    if (ts == 4)      { *nt = 256; *r = 4; }
-    else if (ts == 5) { if (variant == 1) { *nt = 1024; *r = 4; } else if (variant == 2) { *nt = 256; *r = 8; } else { *nt = 512; *r = 8; } }
-    else              { *nt = 1024; *r = 4; }
+    if (variant >= 10)  { int pb; fuse_list_geometry(ts, variant, nt, &pb); *r = 0; }
+    else if (ts == 4)   { *nt = 256; *r = 4; }
+    else if (ts == 5)   { if (variant == 1) { *nt = 1024; *r = 4; } else if (variant == 2) { *nt = 256; *r = 8; } else { *nt = 512; *r = 8; } }
+    else                { *nt = 1024; *r = 4; }
 }
 
 hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr, int variant, LaunchEvents ev)
 {
     if (a.T <= 0) return hipSuccess;
+    if (variant >= 10) {
+        if (ts == 4) return launch_fuse_list<4, 256, 1024>(st, a, attr, ev);
+        if (variant == 10) return launch_fuse_list<5, 256, 4096>(st, a, attr, ev);
+        return launch_fuse_list<5, 512, 4096>(st, a, attr, ev);
+    }
     if (ts == 4) return launch_fuse_attr<4, 256, 4>(st, a, attr, ev);
     if (ts == 5) {
         if (variant == 1) return launch_fuse_attr<5, 1024, 4>(st, a, attr, ev);

@@ -45,13 +45,15 @@ struct BinArgs {
     int B;                             // number of units (grid size)
     // outputs
     uint4*    rec;                     // [B * U]
-    uint32_t* seg;                     // [T][B]  start | count << 16
+    uint32_t* seg;                     // [T][B]  descriptor words
+    uint32_t* flag;                    // [n_sweeps][T]  == epoch when the sweep put a record into the tile
     unsigned long long* counters;      // optional: [0] += binned points
 };
 
 struct FuseArgs {
     const uint4*    rec;
     const uint32_t* seg;               // [T][B_total]
+    const uint32_t* flag;              // [n_sweeps][T]
     uint32_t epoch;
     int   B_total;                     // row stride of seg
     int   U;                           // records per unit slot
@@ -81,6 +83,7 @@ hipError_t launch_bin(hipStream_t st, const BinArgs& a, int ipt, int src, int ts
 hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr, int variant, LaunchEvents ev);
 void       fuse_geometry(int ts, int variant, int* nt, int* r);
 size_t     fuse_lds_bytes(int ts, int nt, int r, int bpad, int attr);
+size_t     fuse_list_lds_bytes(int ts, int variant, int attr);
 hipError_t launch_init(hipStream_t st, const LayerPtrs& m, int cells, int clear_lowest);
 hipError_t launch_clear_strip(hipStream_t st, const LayerPtrs& m, int L, int start, int count, int is_row);
 hipError_t launch_dense_variance(hipStream_t st, float* variance, int cells, int n_pending, const float* pending,

@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Throughput of every BASELINE.json configuration on one MI355X (inputs resident in HBM).
+
+    python tools/bench_configs.py [--reps R] [--configs c2,c3,c4,c5]
+
+Per config: wall time per call (stream-synchronised loop), per-kernel dispatch times (gem_set_timing),
+points/s and algorithmic GB/s  B_alg = 16 N + 16 C_touched (+ 8 L^2 per dense variance pass), SURVEY 8d.
+bench.py stays the contract line (C2); this tool gives the other rows of DESIGN.md section 6.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch  # noqa: E402
+from gem_amd import ElevationMap, synth  # noqa: E402
+
+
+def timed(emap, fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    emap.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    emap.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    emap.set_timing(True); emap.stats(reset=True)
+    for _ in range(reps):
+        fn()
+    st = emap.stats(); emap.set_timing(False)
+    return wall, 1e3 * st["ms_bin"] / reps, 1e3 * st["ms_fuse"] / reps
+
+
+def touched(emap, fn):
+    emap.set_counting(True)
+    fn()
+    c = emap.stats()["cells_touched"]
+    emap.set_counting(False)
+    return c
+
+
+def report(name, n_pts, cells, dense_passes, L, wall, us_bin, us_fuse):
+    alg = 16.0 * n_pts + 16.0 * cells + 8.0 * L * L * dense_passes
+    out = {"config": name, "points": n_pts, "cells_touched": int(cells), "dense_passes": dense_passes,
+           "wall_us": wall * 1e6, "us_bin": us_bin, "us_fuse": us_fuse,
+           "points_per_s": n_pts / wall, "alg_MB": alg / 1e6, "alg_GBps_wall": alg / wall / 1e9,
+           "frac_of_8TBps": alg / wall / 8e12}
+    print(json.dumps(out), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--configs", default="c2,c3,c4,c5")
+    ap.add_argument("--c5-points", type=int, default=10_000_000)
+    args = ap.parse_args()
+    want = args.configs.split(",")
+    dev = torch.device("cuda", 0)
+
+    if "c2" in want:
+        wl = synth.config_c4(n_sweeps=8)
+        d = [torch.from_numpy(c).to(dev) for c in wl.clouds]
+        m = ElevationMap(wl.length, wl.resolution)
+        k = [0]
+        def f():
+            m.add(wl.frames[k[0] % 8], d[k[0] % 8]); k[0] += 1
+        for _ in range(16): f()
+        wall, ub, uf = timed(m, f, args.reps * 4)
+        report("C2 single sweep", d[0].shape[0], touched(m, f), 0, wl.length, wall, ub, uf)
+        m.close()
+
+    if "c3" in want:
+        wl = synth.config_c3()
+        d = torch.from_numpy(wl.clouds[0]).to(dev)
+        m = ElevationMap(wl.length, wl.resolution)
+        m.move(wl.map_position)
+        def f():
+            m.add(wl.frames[0], d)
+        wall, ub, uf = timed(m, f, args.reps)
+        report("C3 depth 640x480", d.shape[0], touched(m, f), 0, wl.length, wall, ub, uf)
+        m.close()
+
+    if "c4" in want:
+        wl = synth.config_c4(n_sweeps=32)
+        cat = torch.from_numpy(np.concatenate(wl.clouds)).to(dev)
+        off = np.concatenate([[0], np.cumsum([c.shape[0] for c in wl.clouds])])
+        m = ElevationMap(wl.length, wl.resolution)
+        def f():
+            m.add_batch(wl.frames, cat, off, wl.var_updates)
+        wall, ub, uf = timed(m, f, max(args.reps // 5, 5))
+        report("C4 batch of 32 sweeps + var updates", cat.shape[0], touched(m, f), 32, wl.length, wall, ub, uf)
+        m.close()
+
+    if "c5" in want:
+        wl = synth.config_c5(n_points=args.c5_points)
+        cat = torch.from_numpy(np.concatenate(wl.clouds)).to(dev)
+        off = np.concatenate([[0], np.cumsum([c.shape[0] for c in wl.clouds])])
+        m = ElevationMap(wl.length, wl.resolution)
+        def f():
+            m.add_batch(wl.frames, cat, off, None)
+        wall, ub, uf = timed(m, f, max(args.reps // 10, 3), warm=1)
+        report(f"C5 aggregated {cat.shape[0]} pts -> {wl.length}^2 (one GPU)", cat.shape[0], touched(m, f), 0, wl.length, wall, ub, uf)
+        m.close()
+
+
+if __name__ == "__main__":
+    main()
