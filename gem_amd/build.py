@@ -22,7 +22,7 @@ HEADERS = [CSRC / "gem_device.hpp", CSRC / "gem_kernels.hpp", ROOT.parent / "inc
 # -ffp-contract=off: cell indices must be bit-exact with the reference arithmetic, so no product+sum
 # may be contracted into an FMA (see csrc/gem_device.hpp).  hipcc's default IEEE divide/sqrt stay on.
 FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+    "--offload-arch=gfx950", "-O3", *(["-g"] if os.environ.get("GEM_DEBUG_BUILD") else []), "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
     "-Wno-unused-value",
 ]
 

@@ -83,7 +83,7 @@ struct gem_handle {
     Arena dbg;          // optional k_fuse phase stamps
     bool  dbg_on = false;
     int ipt_override = 0;
-    int fuse_variant = 11;
+    int fuse_variant = 12;
 };
 
 namespace {
@@ -395,7 +395,7 @@ int gem_create(const gem_map_config* cfg, gem_handle** out)
         if (cfg->strip_row0 < 0 || cfg->strip_row0 + cfg->strip_rows > h->L) { delete h; return fail(nullptr, GEM_ERR_INVALID, "gem_create: bad strip"); }
         h->row0 = cfg->strip_row0; h->row1 = cfg->strip_row0 + cfg->strip_rows;
     }
-    h->fuse_variant = 11;                       // k_fuse_list (10: 256 threads per 32x32 tile, 11: 512); < 10: k_fuse
+    h->fuse_variant = 12;                       // k_fuse_list on 32x32 tiles: 10 = 256 threads, 11 = 512, 12 = 512 with 2048-record batches (2 per CU); < 10: k_fuse
     if (const char* s = getenv("GEM_FUSE_VARIANT")) h->fuse_variant = atoi(s);
     h->ts = 0;                                  // 0: chosen per pass (run_pipeline)
     if (h->fuse_variant < 10) h->ts = h->L > 1024 ? 6 : 5;

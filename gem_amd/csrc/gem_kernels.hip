@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void k_bin_wave(BinArgs a)
     if (valid) a.rec[(size_t)unit * U + start + rank] = make_uint4(cl, __float_as_uint(hh), __float_as_uint(vv), src);
     if (leader) {
         a.seg[(size_t)tile * a.B + unit] = (a.epoch << kSegEpochShift) | (start << kSegCountBits) | cnt;
-        a.flag[(size_t)sweep * a.T + tile] = a.epoch;              // "tile touched in this sweep" (same value from every writer)
+        a.flag[(size_t)tile * a.n_sweeps + sweep] = a.epoch;       // "tile touched in this sweep" (same value from every writer)
     }
 
     if (a.counters) {
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(64) void k_bin_lds(BinArgs a)
         if (t < T) {
             const uint32_t c = lds_cnt[t];
             lds_cnt[t] = run;                                       // becomes the running base of tile t
-            if (c) { seg[(size_t)t * a.B + unit] = (a.epoch << kSegEpochShift) | (run << kSegCountBits) | c; a.flag[(size_t)sweep * a.T + t] = a.epoch; }
+            if (c) { seg[(size_t)t * a.B + unit] = (a.epoch << kSegEpochShift) | (run << kSegCountBits) | c; a.flag[(size_t)t * a.n_sweeps + sweep] = a.epoch; }
             run += c;
         }
     }
@@ -653,7 +653,7 @@ constexpr int fuse_list_max_batches(int pb) { return kChunkUnits * 256 / (pb - 2
 #define GEM_CSWAP(a, b) do { const uint32_t lo_ = min(a, b), hi_ = max(a, b); a = lo_; b = hi_; } while (0)
 
 template <int TS, int NT, int PB, int ATTR>
-__global__ __launch_bounds__(NT, (TS == 4 ? 4 : 2)) void k_fuse_list(FuseArgs a)
+__global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_list(FuseArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr int TE = 1 << TS;
@@ -696,20 +696,29 @@ __global__ __launch_bounds__(NT, (TS == 4 ? 4 : 2)) void k_fuse_list(FuseArgs a)
 #define GEM_STAMP() do { if (a.dbg && tid == 0 && dbg_k < 16) a.dbg[(size_t)tile * 16 + dbg_k++] = (unsigned long long)__builtin_readcyclecounter(); } while (0)
     GEM_STAMP();                                                         // 0: start
 
-    // descriptor words of the first chunk of sweep 0: issued before anything else so that their
-    // latency overlaps the flag test and the tile read
-    uint32_t ev[UPT];
-    {
-        const int B0 = a.sweep_unit0 ? a.sweep_unit0[1] - a.sweep_unit0[0] : a.B_total;
-        const int ub0 = a.sweep_unit0 ? a.sweep_unit0[0] : 0;
-        const int u0 = tid * UPT;
+    // which sweeps put a record into this tile?  flag[tile][sweep] == epoch (stamped by k_bin): one
+    // coalesced load per 64 sweeps, turned into a wave-uniform bit mask
+    const uint32_t* flagrow = a.flag + (size_t)tile * a.n_sweeps;
+    auto sweep_mask = [&](int sbase) -> uint64_t {
+        const int sidx = sbase + lane;
+        return __ballot(sidx < a.n_sweeps && flagrow[sidx] == epoch);
+    };
+    auto load_row = [&](int sweep, int cbase, uint32_t (&e4)[UPT]) {
+        const int ubx = a.sweep_unit0 ? a.sweep_unit0[sweep] : 0;
+        const int Bx = (a.sweep_unit0 ? a.sweep_unit0[sweep + 1] : a.B_total) - ubx;
+        const int u0 = cbase + tid * UPT;
 #pragma unroll
         for (int x = 0; x < UPT / 4; ++x) {
             uint4 e = make_uint4(0, 0, 0, 0);
-            if (u0 + 4 * x < B0) e = *reinterpret_cast<const uint4*>(seg + ub0 + u0 + 4 * x);     // rows are padded to 4 units
-            ev[4 * x] = e.x; ev[4 * x + 1] = e.y; ev[4 * x + 2] = e.z; ev[4 * x + 3] = e.w;
+            if (u0 + 4 * x < Bx) e = *reinterpret_cast<const uint4*>(seg + ubx + u0 + 4 * x);    // rows are padded to 4 units
+            e4[4 * x] = e.x; e4[4 * x + 1] = e.y; e4[4 * x + 2] = e.z; e4[4 * x + 3] = e.w;
         }
-    }
+    };
+    // descriptor words of the first chunk of sweep 0: issued before anything else so that their
+    // latency overlaps the flag test and the tile read
+    uint32_t ev[UPT], evn[UPT];
+    load_row(0, 0, ev);
+    int prefetched = 0;                                                  // sweep whose first chunk sits in ev (sweep 0) / evn
 
     // ---- the single read of the tile (issued before the flag test: one memory latency, not two) ----
     float ce[CPT], cs[CPT];
@@ -726,10 +735,13 @@ __global__ __launch_bounds__(NT, (TS == 4 ? 4 : 2)) void k_fuse_list(FuseArgs a)
         }
     }
 
-    // does this tile receive any point of this pass?  (k_bin stamps flag[sweep][tile] with the epoch)
-    bool any_touched = false;
-    for (int s = 0; s < a.n_sweeps; ++s) any_touched |= a.flag[(size_t)s * a.T + tile] == epoch;   // block-uniform scalar loads
-    if (!any_touched && !a.dense) return;
+    // does this tile receive any point of this pass?
+    uint64_t smask = sweep_mask(0);
+    {
+        bool any_touched = smask != 0;
+        for (int sb = 64; sb < a.n_sweeps && !any_touched; sb += 64) any_touched = sweep_mask(sb) != 0;
+        if (!any_touched && !a.dense) return;
+    }
 
     {   // fast-path rows start with count 0; the owner leaves every row it consumed at count 0 again
         uint4* z = reinterpret_cast<uint4*>(rowp);
@@ -739,6 +751,11 @@ __global__ __launch_bounds__(NT, (TS == 4 ? 4 : 2)) void k_fuse_list(FuseArgs a)
     GEM_STAMP();                                                         // 1: tile loads issued
 
     for (int sweep = 0; sweep < a.n_sweeps; ++sweep) {
+        if (sweep != 0 && (sweep & 63) == 0) smask = sweep_mask(sweep);
+        const bool touched_sweep = (smask >> (sweep & 63)) & 1ull;       // block-uniform
+        // a sweep that neither reaches this tile nor carries a variance increment changes nothing
+        // (the floor below is idempotent and has been applied by an earlier sweep or is applied by a later one)
+        if (!touched_sweep && !a.var_updates && sweep != 0 && sweep != a.n_sweeps - 1) continue;
         const int ub = a.sweep_unit0 ? a.sweep_unit0[sweep] : 0;        // multiple of 4 (host pads sweeps)
         const int ue = a.sweep_unit0 ? a.sweep_unit0[sweep + 1] : a.B_total;
         const int B = ue - ub;
@@ -753,16 +770,20 @@ __global__ __launch_bounds__(NT, (TS == 4 ? 4 : 2)) void k_fuse_list(FuseArgs a)
         if (a.counters && tid == 0) misc[0] = 0;
         uint32_t tmask = 0;                                              // cells of this thread touched in this sweep
 
-        const bool touched_sweep = a.flag[(size_t)sweep * a.T + tile] == epoch;      // block-uniform
         for (int cbase = 0; touched_sweep && cbase < B; cbase += kChunkUnits) {
             // ---- 1. ordered compaction of the chunk's live descriptors ----------------------------
             const int u0 = cbase + tid * UPT;
-            if (sweep != 0 || cbase != 0) {
+            if (cbase == 0 && sweep != 0 && prefetched == sweep) {
 #pragma unroll
-                for (int x = 0; x < UPT / 4; ++x) {
-                    uint4 e = make_uint4(0, 0, 0, 0);
-                    if (u0 + 4 * x < B) e = *reinterpret_cast<const uint4*>(seg + ub + u0 + 4 * x);
-                    ev[4 * x] = e.x; ev[4 * x + 1] = e.y; ev[4 * x + 2] = e.z; ev[4 * x + 3] = e.w;
+                for (int j = 0; j < UPT; ++j) ev[j] = evn[j];
+            } else if (sweep != 0 || cbase != 0) {
+                load_row(sweep, cbase, ev);
+            }
+            if (cbase == 0) {                                            // next touched sweep of this 64-block: its row starts flying now
+                const uint64_t later = (sweep & 63) == 63 ? 0ull : (smask >> ((sweep & 63) + 1));
+                if (later != 0) {
+                    prefetched = sweep + 1 + (__ffsll((unsigned long long)later) - 1);
+                    load_row(prefetched, 0, evn);
                 }
             }
             uint32_t packed = 0;                                         // live descriptors << 20 | records
@@ -777,7 +798,7 @@ __global__ __launch_bounds__(NT, (TS == 4 ? 4 : 2)) void k_fuse_list(FuseArgs a)
             const uint32_t run = block_exclusive_scan<NT>(packed, scratch, &tot);
             const uint32_t nd = tot >> 20, P = tot & 0xfffffu;
             if (P == 0) continue;                                        // block-uniform
-            const uint32_t nb = (P - 1u) / Q + 1u;                       // every batch is non-empty (a descriptor holds < Q records)
+            const uint32_t nb = (P - 1u) / Q + 1u;                       // batches 0 .. nb-2 are non-empty (a descriptor holds < Q records)
             if (nb > 1) {
                 for (uint32_t i = tid; i < nb; i += NT) bstart[i] = 0xffffffffu;
                 if (tid == 0) bstart[nb] = nd;
@@ -790,7 +811,10 @@ __global__ __launch_bounds__(NT, (TS == 4 ? 4 : 2)) void k_fuse_list(FuseArgs a)
             }
 
             for (uint32_t b = 0; b < nb; ++b) {
-                const uint32_t d_lo = nb > 1 ? bstart[b] : 0u, d_hi = nb > 1 ? bstart[b + 1] : nd, m = d_hi - d_lo;
+                // (the last batch is empty when the final descriptor merely extends past a multiple of Q)
+                const uint32_t d_lo = nb > 1 ? bstart[b] : 0u;
+                if (d_lo == 0xffffffffu) break;                          // block-uniform
+                const uint32_t d_hi = nb > 1 ? min(bstart[b + 1], nd) : nd, m = d_hi - d_lo;
                 const uint32_t slot0 = b * Q;
                 {   // this batch's descriptors, in order
                     uint32_t d = run >> 20, rs = run & 0xfffffu;
@@ -1252,7 +1276,7 @@ static size_t fuse_list_lds(int cells, int nw, int pb, int attr)
 static void fuse_list_geometry(int ts, int variant, int* nt, int* pb)
 {
     if (ts == 4) { *nt = 256; *pb = 1024; }
-    else         { *nt = variant == 10 ? 256 : 512; *pb = 4096; }
+    else         { *nt = variant == 10 ? 256 : 512; *pb = variant == 12 ? 2048 : 4096; }
 }
 
 size_t fuse_list_lds_bytes(int ts, int variant, int attr)
@@ -1294,6 +1318,7 @@ hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr, int 
     if (variant >= 10) {
         if (ts == 4) return launch_fuse_list<4, 256, 1024>(st, a, attr, ev);
         if (variant == 10) return launch_fuse_list<5, 256, 4096>(st, a, attr, ev);
+        if (variant == 12) return launch_fuse_list<5, 512, 2048>(st, a, attr, ev);
         return launch_fuse_list<5, 512, 4096>(st, a, attr, ev);
     }
     if (ts == 4) return launch_fuse_attr<4, 256, 4>(st, a, attr, ev);

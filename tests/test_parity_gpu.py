@@ -313,3 +313,69 @@ def test_torch_exchange_aliases_device_layers(oracle_mod):
         assert np.array_equal(e.cpu().numpy(), ref.layer("elevation")) and np.array_equal(v.cpu().numpy(), ref.layer("variance"))
     finally:
         dist.destroy_process_group()
+
+
+# ---- kernel variants: every fuse kernel / tile size must give the same bits ---------------------------------------------
+@pytest.mark.parametrize("variant,ts", [(12, 4), (12, 5), (11, 5), (10, 5), (0, 5), (0, 4)])
+def test_fuse_kernel_variants(oracle_mod, monkeypatch, variant, ts):
+    monkeypatch.setenv("GEM_FUSE_VARIANT", str(variant))
+    monkeypatch.setenv("GEM_TILE_SHIFT", str(ts))
+    wl = synth.config_c4(n_sweeps=2)
+    gpu, ref = make_pair(oracle_mod, wl.length, wl.resolution)
+    for k in range(2):                                  # LiDAR: the rank-row fast path
+        gpu.mapvar_update(wl.var_updates[k]); ref.mapvar_update(wl.var_updates[k])
+        gpu.add(wl.frames[k], wl.clouds[k]); ref.add(wl.frames[k], wl.clouds[k])
+    assert_maps_match(gpu, ref)
+    gpu, ref = make_pair(oracle_mod, 40, 0.1)           # > 7 points per cell and batch: the generic path, several batches
+    c = synth.random_cloud(22, 60_000, 2.2, z_sigma=0.05)
+    f = synth._frame_for(np.eye(4), SensorModel.velodyne())
+    gpu.add(f, c); ref.add(f, c)
+    assert_maps_match(gpu, ref)
+
+
+def test_mixed_fast_and_generic_batches(oracle_mod):
+    # a sparse cloud (fast path) with one dense cluster (generic path) in the same tile, twice
+    gpu, ref = make_pair(oracle_mod, 64, 0.1)
+    rng = np.random.default_rng(9)
+    sparse = synth.random_cloud(31, 3000, 3.0, dup_fraction=0.0)
+    dense = np.zeros((500, 4), F32); dense[:, 0] = 0.52 + rng.uniform(0, 0.2, 500); dense[:, 1] = -0.33 + rng.uniform(0, 0.2, 500)
+    dense[:, 2] = rng.normal(0, 0.03, 500)
+    c = np.concatenate([sparse[:1500], dense, sparse[1500:]], 0)
+    f = synth._frame_for(np.eye(4), SensorModel.velodyne())
+    for _ in range(2):
+        gpu.add(f, c); ref.add(f, c)
+        assert_maps_match(gpu, ref)
+
+
+# ---- aggregated cloud into the big map (BASELINE config 5, reduced) -----------------------------------------------------
+def test_c5_aggregated_batch_parity(oracle_mod):
+    import torch
+    wl = synth.config_c5(n_points=600_000)
+    gpu, ref = make_pair(oracle_mod, wl.length, wl.resolution)
+    off = np.concatenate([[0], np.cumsum([c.shape[0] for c in wl.clouds])])
+    d = torch.from_numpy(np.concatenate(wl.clouds, 0)).to("cuda:0")
+    gpu.add_batch(wl.frames, d, off, None)
+    for fr, c in zip(wl.frames, wl.clouds):
+        ref.add(fr, c)
+    assert_maps_match(gpu, ref)
+    # one of eight row strips (rank 3 of the 8-GPU tiling) equals the same rows of the full map
+    L = wl.length
+    part = ElevationMap(L, wl.resolution, strip=(900, 300))
+    part.add_batch(wl.frames, d, off, None)
+    assert np.array_equal(part.layer("elevation")[900:1200], ref.layer("elevation")[900:1200])
+    assert np.array_equal(part.layer("variance")[900:1200], ref.layer("variance")[900:1200])
+
+
+def test_batch_tail_descriptor_crossing_a_batch_boundary(oracle_mod, monkeypatch):
+    # regression: a tile whose last descriptor merely extends past a multiple of the batch quantum
+    # (an empty trailing batch) -- met by sweep 7 of the C4 series with 2048-record batches
+    import torch
+    monkeypatch.setenv("GEM_FUSE_VARIANT", "12"); monkeypatch.setenv("GEM_TILE_SHIFT", "5")
+    wl = synth.config_c4(n_sweeps=8)
+    gpu, ref = make_pair(oracle_mod, wl.length, wl.resolution)
+    off = np.concatenate([[0], np.cumsum([c.shape[0] for c in wl.clouds])])
+    d = torch.from_numpy(np.concatenate(wl.clouds, 0)).to("cuda:0")
+    gpu.add_batch(wl.frames, d, off, wl.var_updates)
+    for k in range(8):
+        ref.mapvar_update(wl.var_updates[k]); ref.add(wl.frames[k], wl.clouds[k])
+    assert_maps_match(gpu, ref)

@@ -105,7 +105,7 @@ def main():
         m = ElevationMap(wl.length, wl.resolution)
         def f():
             m.add_batch(wl.frames, cat, off, None)
-        wall, ub, uf = timed(m, f, max(args.reps // 10, 3), warm=1)
+        wall, ub, uf = timed(m, f, max(args.reps // 10, 3), warm=3)
         report(f"C5 aggregated {cat.shape[0]} pts -> {wl.length}^2 (one GPU)", cat.shape[0], touched(m, f), 0, wl.length, wall, ub, uf)
         m.close()
 
