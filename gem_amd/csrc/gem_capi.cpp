@@ -249,7 +249,7 @@ int run_pipeline(gem_handle* h, const PassInput& in)
     int ts = h->ts;
     if (ts == 0) {
         const long long tpr4 = (h->L + 15) / 16;
-        ts = (tpr4 * tpr4 * (long long)B * 4 <= (1ll << 30)) ? 4 : 5;
+        ts = (tpr4 * tpr4 * (long long)bpad * in.n_sweeps * 4 <= (1ll << 30)) ? 4 : 5;
     }
     const int te = 1 << ts;
     const int tiles_per_row = (h->L + te - 1) / te;
@@ -278,7 +278,7 @@ int run_pipeline(gem_handle* h, const PassInput& in)
     if ((rc = ensure(h, pb.rec, (size_t)B * U * sizeof(uint4)))) return rc;
     if (overlap && pb.fuse_recorded) GEM_HIP(h, hipStreamWaitEvent(sbin, pb.fuse_done, 0));   // k_fuse of pass p-2 has read these buffers
     {   // descriptor table: words are stamped with an epoch instead of being cleared every pass
-        const size_t need = (size_t)T * B * sizeof(uint32_t);
+        const size_t need = (size_t)in.n_sweeps * T * bpad * sizeof(uint32_t);        // [sweep][tile][unit in sweep]
         const bool grow = need > pb.seg.cap;
         if ((rc = ensure(h, pb.seg, need))) return rc;
         const size_t need_flag = (size_t)T * in.n_sweeps * sizeof(uint32_t);
@@ -322,7 +322,7 @@ int run_pipeline(gem_handle* h, const PassInput& in)
     ba.xyzi = in.xyzi; ba.rgb = in.rgb; ba.orig = in.orig;
     ba.f_index = in.f_index; ba.f_height = in.f_height; ba.f_var = in.f_var;
     ba.f_R = in.f_R; ba.f_G = in.f_G; ba.f_B = in.f_B; ba.f_I = in.f_I;
-    ba.T = T; ba.tiles_per_row = tiles_per_row; ba.B = B;
+    ba.T = T; ba.tiles_per_row = tiles_per_row; ba.B = B; ba.Bpad = bpad;
     ba.tile_bits = 0; while ((1 << ba.tile_bits) < T) ++ba.tile_bits;
     ba.epoch = pb.epoch;
     ba.rec = static_cast<uint4*>(pb.rec.p); ba.seg = static_cast<uint32_t*>(pb.seg.p); ba.flag = static_cast<uint32_t*>(pb.flag.p);

@@ -44,7 +44,8 @@ struct FrameConst {
 
 struct Projected {
     float h, var, xt, yt;
-    int   cell;              // storage index, -1 if outside the map (or the point was rejected)
+    int   row, col;          // storage row / column, -1 if outside the map (or the point was rejected)
+    int   cell;              // row * L + col, -1 if outside
     bool  accepted;          // passed the reject filter and the height window (GPU:397)
 };
 
@@ -68,17 +69,26 @@ __device__ __forceinline__ int axis_index(int L, float res, float shift)
     }
 }
 
-// GPU:332-358 (PointsToMapIndex)
-__device__ __forceinline__ int map_index(const FrameConst& f, float px, float py)
+// GPU:332-358 (PointsToMapIndex): storage (circular-buffer) row / column of a map-frame point.
+// 0 <= ix < L and 0 <= start < L, so (ix + start) % L is one conditional subtraction.
+__device__ __forceinline__ bool map_row_col(const FrameConst& f, float px, float py, int& row, int& col)
 {
     const float shx = px - f.cx, shy = py - f.cy;
     const int ix = axis_index(f.L, f.res, shx), iy = axis_index(f.L, f.res, shy);
     if (ix >= 0 && ix < f.L && iy >= 0 && iy < f.L) {
-        const int stx = (ix + f.sx) % f.L;
-        const int sty = (iy + f.sy) % f.L;
-        return stx * f.L + sty;
+        const int stx = ix + f.sx, sty = iy + f.sy;
+        row = stx >= f.L ? stx - f.L : stx;
+        col = sty >= f.L ? sty - f.L : sty;
+        return true;
     }
-    return -1;
+    row = -1; col = -1;
+    return false;
+}
+
+__device__ __forceinline__ int map_index(const FrameConst& f, float px, float py)
+{
+    int row, col;
+    return map_row_col(f, px, py, row, col) ? row * f.L + col : -1;
 }
 
 __device__ __forceinline__ void sensor_variances(const FrameConst& f, float x, float y, float z, int orig,
@@ -156,10 +166,10 @@ __device__ __forceinline__ Projected project_point(const FrameConst& f, float x,
         r.yt = f.T[4] * x + f.T[5] * y + f.T[6] * z + f.T[7];                      // GPU:400
         r.h = h;
         r.var = height_variance(f, x, y, z, orig);
-        r.cell = map_index(f, r.xt, r.yt);                                         // GPU:431
+        r.cell = map_row_col(f, r.xt, r.yt, r.row, r.col) ? r.row * f.L + r.col : -1;   // GPU:431
         r.accepted = true;
     } else {                                                                       // GPU:441-451
-        r.xt = -1.0f; r.yt = -1.0f; r.h = -1.0f; r.var = -1.0f; r.cell = -1; r.accepted = false;
+        r.xt = -1.0f; r.yt = -1.0f; r.h = -1.0f; r.var = -1.0f; r.cell = -1; r.row = -1; r.col = -1; r.accepted = false;
     }
     return r;
 }

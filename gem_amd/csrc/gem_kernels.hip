@@ -130,14 +130,14 @@ __global__ __launch_bounds__(256) void k_bin_wave(BinArgs a)
     const int unit = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (unit >= a.B) return;                               // whole wave leaves together
 
-    int sweep = 0;
+    int sweep = 0, unit_first = 0;
     long long base, sweep_begin = 0, sweep_end = a.n;
     if (BATCH) {
         int lo = 0, hi = a.n_sweeps;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.sweep_unit0[mid] <= unit) lo = mid; else hi = mid; }
-        sweep = lo;
+        sweep = lo; unit_first = a.sweep_unit0[sweep];
         sweep_begin = a.sweep_first[sweep]; sweep_end = a.sweep_first[sweep + 1];
-        base = sweep_begin + (long long)(unit - a.sweep_unit0[sweep]) * U;
+        base = sweep_begin + (long long)(unit - unit_first) * U;
     } else {
         base = (long long)unit * U;
     }
@@ -147,29 +147,27 @@ __global__ __launch_bounds__(256) void k_bin_wave(BinArgs a)
     bool valid = false;
     uint32_t tile = 0, cl = 0, src = 0; float hh = 0.0f, vv = 0.0f;
     if (i < sweep_end) {
-        int cell; float h, v; bool colour_ok = false;
+        int row, col; float h, v; bool colour_ok = false;
         if (SRC == 0) {
             const float4 p = a.xyzi[i];
             const Projected r = project_point(fc, p.x, p.y, p.z, a.orig ? a.orig[i] : (int)(i - sweep_begin));
-            cell = r.cell; h = r.h; v = r.var;
+            row = r.row; col = r.col; h = r.h; v = r.var;
             if (a.rgb) {
                 const uint32_t c = a.rgb[i];
                 colour_ok = ((c >> 16) & 0xff) != 0 && ((c >> 8) & 0xff) != 0 && (c & 0xff) != 0 && p.w != 0.0f;
             }
         } else {
-            cell = a.f_index[i]; h = a.f_height[i]; v = a.f_var[i];
-            if (cell >= fc.L * fc.L) cell = -1;
+            const int cell = a.f_index[i]; h = a.f_height[i]; v = a.f_var[i];
+            row = -1; col = -1;
+            if (cell >= 0 && cell < fc.L * fc.L) { row = cell / fc.L; col = cell - row * fc.L; }
             if (a.f_R) colour_ok = a.f_R[i] != 0 && a.f_G[i] != 0 && a.f_B[i] != 0 && a.f_I[i] != 0.0f;
         }
         // GPU:482: "point_index[i] != map_index || points_h[i] == -1" -> the point is skipped
-        if (cell >= 0 && h != -1.0f) {
-            const int row = cell / fc.L, col = cell - row * fc.L;
-            if (row >= fc.row0 && row < fc.row1) {
-                valid = true;
-                tile = (uint32_t)((row >> TS) * a.tiles_per_row + (col >> TS));
-                cl = (uint32_t)(((row & (TE - 1)) << TS) | (col & (TE - 1))) | (colour_ok ? 0x80000000u : 0u);
-                hh = h; vv = v; src = (uint32_t)i;
-            }
+        if (row >= fc.row0 && row < fc.row1 && h != -1.0f) {
+            valid = true;
+            tile = (uint32_t)((row >> TS) * a.tiles_per_row + (col >> TS));
+            cl = (uint32_t)(((row & (TE - 1)) << TS) | (col & (TE - 1))) | (colour_ok ? 0x80000000u : 0u);
+            hh = h; vv = v; src = (uint32_t)i;
         }
     }
 
@@ -185,7 +183,8 @@ __global__ __launch_bounds__(256) void k_bin_wave(BinArgs a)
     const uint32_t start = (uint32_t)__shfl((int)start_leader, my_leader, 64);
     if (valid) a.rec[(size_t)unit * U + start + rank] = make_uint4(cl, __float_as_uint(hh), __float_as_uint(vv), src);
     if (leader) {
-        a.seg[(size_t)tile * a.B + unit] = (a.epoch << kSegEpochShift) | (start << kSegCountBits) | cnt;
+        // table layout [sweep][tile][unit in sweep]: the words one sweep writes stay within T * Bpad * 4 bytes
+        a.seg[((size_t)sweep * a.T + tile) * a.Bpad + (unit - unit_first)] = (a.epoch << kSegEpochShift) | (start << kSegCountBits) | cnt;
         a.flag[(size_t)tile * a.n_sweeps + sweep] = a.epoch;       // "tile touched in this sweep" (same value from every writer)
     }
 
@@ -210,14 +209,14 @@ __global__ __launch_bounds__(64) void k_bin_lds(BinArgs a)
     const int unit = (int)blockIdx.x;
     const int T = a.T;
 
-    int sweep = 0;
+    int sweep = 0, unit_first = 0;
     long long base, sweep_begin = 0, sweep_end = a.n;
     if (BATCH) {
         int lo = 0, hi = a.n_sweeps;                 // sweep_unit0[lo] <= unit < sweep_unit0[hi]
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.sweep_unit0[mid] <= unit) lo = mid; else hi = mid; }
-        sweep = lo;
+        sweep = lo; unit_first = a.sweep_unit0[sweep];
         sweep_begin = a.sweep_first[sweep]; sweep_end = a.sweep_first[sweep + 1];
-        base = sweep_begin + (long long)(unit - a.sweep_unit0[sweep]) * U;
+        base = sweep_begin + (long long)(unit - unit_first) * U;
     } else {
         base = (long long)unit * U;
     }
@@ -238,29 +237,27 @@ __global__ __launch_bounds__(64) void k_bin_lds(BinArgs a)
         tile[j] = (uint32_t)kInvalidTile; cl[j] = 0; hh[j] = 0.0f; vv[j] = 0.0f; src[j] = 0;
         if (o < npts) {
             const long long i = base + o;
-            int cell; float h, v; bool colour_ok = false;
+            int row, col; float h, v; bool colour_ok = false;
             if (SRC == 0) {
                 const float4 p = a.xyzi[i];
                 const Projected r = project_point(fc, p.x, p.y, p.z, a.orig ? a.orig[i] : (int)(i - sweep_begin));
-                cell = r.cell; h = r.h; v = r.var;
+                row = r.row; col = r.col; h = r.h; v = r.var;
                 if (a.rgb) {
                     const uint32_t c = a.rgb[i];
                     colour_ok = ((c >> 16) & 0xff) != 0 && ((c >> 8) & 0xff) != 0 && (c & 0xff) != 0 && p.w != 0.0f;
                 }
             } else {
-                cell = a.f_index[i]; h = a.f_height[i]; v = a.f_var[i];
-                if (cell >= fc.L * fc.L) cell = -1;
+                const int cell = a.f_index[i]; h = a.f_height[i]; v = a.f_var[i];
+                row = -1; col = -1;
+                if (cell >= 0 && cell < fc.L * fc.L) { row = cell / fc.L; col = cell - row * fc.L; }
                 if (a.f_R) colour_ok = a.f_R[i] != 0 && a.f_G[i] != 0 && a.f_B[i] != 0 && a.f_I[i] != 0.0f;
             }
-            if (cell >= 0 && h != -1.0f) {                       // GPU:482
-                const int row = cell / fc.L, col = cell - row * fc.L;
-                if (row >= fc.row0 && row < fc.row1) {
-                    tile[j] = (uint32_t)((row >> TS) * a.tiles_per_row + (col >> TS));
-                    cl[j] = (uint32_t)(((row & (TE - 1)) << TS) | (col & (TE - 1))) | (colour_ok ? 0x80000000u : 0u);
-                    hh[j] = h; vv[j] = v; src[j] = (uint32_t)i;
-                    atomicAdd(&lds_cnt[tile[j]], 1u);
-                    ++n_binned;
-                }
+            if (row >= fc.row0 && row < fc.row1 && h != -1.0f) {     // GPU:482
+                tile[j] = (uint32_t)((row >> TS) * a.tiles_per_row + (col >> TS));
+                cl[j] = (uint32_t)(((row & (TE - 1)) << TS) | (col & (TE - 1))) | (colour_ok ? 0x80000000u : 0u);
+                hh[j] = h; vv[j] = v; src[j] = (uint32_t)i;
+                atomicAdd(&lds_cnt[tile[j]], 1u);
+                ++n_binned;
             }
         }
     }
@@ -278,7 +275,7 @@ __global__ __launch_bounds__(64) void k_bin_lds(BinArgs a)
         if (t < T) {
             const uint32_t c = lds_cnt[t];
             lds_cnt[t] = run;                                       // becomes the running base of tile t
-            if (c) { seg[(size_t)t * a.B + unit] = (a.epoch << kSegEpochShift) | (run << kSegCountBits) | c; a.flag[(size_t)t * a.n_sweeps + sweep] = a.epoch; }
+            if (c) { seg[((size_t)sweep * a.T + t) * a.Bpad + (unit - unit_first)] = (a.epoch << kSegEpochShift) | (run << kSegCountBits) | c; a.flag[(size_t)t * a.n_sweeps + sweep] = a.epoch; }
             run += c;
         }
     }
@@ -345,7 +342,6 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 6 : 4)) void k_fuse(FuseArgs a)
     const int tr = tile / a.tiles_per_row, tc = tile - tr * a.tiles_per_row;
     const int row_base = tr << TS, col_base = tc << TS;
     const int L = a.L;
-    const uint32_t* seg = a.seg + (size_t)tile * a.B_total;
     const uint32_t epoch = a.epoch;
     const uint64_t lt = lanemask_lt();
     int dbg_k = 0;
@@ -355,7 +351,11 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 6 : 4)) void k_fuse(FuseArgs a)
     // ---- 0. batched call: does this tile receive any point at all? (single sweep: step 3 tells) ----
     if (!a.dense && a.n_sweeps > 1) {
         int any = 0;
-        for (int u = tid; u < a.B_total; u += NT) any |= (seg[u] >> kSegEpochShift) == epoch;
+        for (int sw = 0; sw < a.n_sweeps; ++sw) {
+            const uint32_t* row = a.seg + ((size_t)sw * a.T + tile) * a.Bpad;
+            const int Bs = a.sweep_unit0[sw + 1] - a.sweep_unit0[sw];
+            for (int u = tid; u < Bs; u += NT) any |= (row[u] >> kSegEpochShift) == epoch;
+        }
         if (!__syncthreads_or(any)) return;
     }
 
@@ -379,6 +379,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 6 : 4)) void k_fuse(FuseArgs a)
         const int ub = a.sweep_unit0 ? a.sweep_unit0[sweep] : 0;        // multiple of 4 (host pads sweeps)
         const int ue = a.sweep_unit0 ? a.sweep_unit0[sweep + 1] : a.B_total;
         const int B = ue - ub;
+        const uint32_t* seg = a.seg + ((size_t)sweep * a.T + tile) * a.Bpad;    // this sweep's descriptor row of the tile
 
         // ---- 2. Mapvar_update increments queued before this sweep (GPU:540-547) ------------------
 #pragma unroll
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 6 : 4)) void k_fuse(FuseArgs a)
 #pragma unroll
                 for (int x = 0; x < V; ++x) {
                     e[x] = make_uint4(0, 0, 0, 0);
-                    if (u + 4 * x < B) e[x] = *reinterpret_cast<const uint4*>(seg + ub + u + 4 * x);   // rows are padded to 4 units
+                    if (u + 4 * x < B) e[x] = *reinterpret_cast<const uint4*>(seg + u + 4 * x);   // rows are padded to 4 units
                 }
             }
             for (int c = tid; c < PB; c += NT) khead[c] = 0;
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 6 : 4)) void k_fuse(FuseArgs a)
 #pragma unroll
                     for (int x = 0; x < V; ++x) {
                         e[x] = make_uint4(0, 0, 0, 0);
-                        if (u + 4 * x < B) e[x] = *reinterpret_cast<const uint4*>(seg + ub + u + 4 * x);
+                        if (u + 4 * x < B) e[x] = *reinterpret_cast<const uint4*>(seg + u + 4 * x);
                     }
                 }
                 uint32_t ev[4 * V], cnt[4 * V], local = 0;
@@ -689,7 +690,6 @@ __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_
     const int tr = tile / a.tiles_per_row, tc = tile - tr * a.tiles_per_row;
     const int row_base = tr << TS, col_base = tc << TS;
     const int L = a.L;
-    const uint32_t* seg = a.seg + (size_t)tile * a.B_total;
     const uint32_t epoch = a.epoch;
     const uint64_t lt = lanemask_lt();
     int dbg_k = 0;
@@ -706,11 +706,12 @@ __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_
     auto load_row = [&](int sweep, int cbase, uint32_t (&e4)[UPT]) {
         const int ubx = a.sweep_unit0 ? a.sweep_unit0[sweep] : 0;
         const int Bx = (a.sweep_unit0 ? a.sweep_unit0[sweep + 1] : a.B_total) - ubx;
+        const uint32_t* segx = a.seg + ((size_t)sweep * a.T + tile) * a.Bpad;   // table layout [sweep][tile][unit in sweep]
         const int u0 = cbase + tid * UPT;
 #pragma unroll
         for (int x = 0; x < UPT / 4; ++x) {
             uint4 e = make_uint4(0, 0, 0, 0);
-            if (u0 + 4 * x < Bx) e = *reinterpret_cast<const uint4*>(seg + ubx + u0 + 4 * x);    // rows are padded to 4 units
+            if (u0 + 4 * x < Bx) e = *reinterpret_cast<const uint4*>(segx + u0 + 4 * x);         // rows are padded to 4 units
             e4[4 * x] = e.x; e4[4 * x + 1] = e.y; e4[4 * x + 2] = e.z; e4[4 * x + 3] = e.w;
         }
     };

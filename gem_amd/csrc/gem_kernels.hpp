@@ -43,23 +43,24 @@ struct BinArgs {
     uint32_t epoch;                    // stamps the descriptor words of this pass
     int tiles_per_row;
     int B;                             // number of units (grid size)
+    int Bpad;                          // units of the longest sweep, multiple of 4: row length of the descriptor table
     // outputs
     uint4*    rec;                     // [B * U]
-    uint32_t* seg;                     // [T][B]  descriptor words
+    uint32_t* seg;                     // [n_sweeps][T][Bpad]  descriptor words
     uint32_t* flag;                    // [n_sweeps][T]  == epoch when the sweep put a record into the tile
     unsigned long long* counters;      // optional: [0] += binned points
 };
 
 struct FuseArgs {
     const uint4*    rec;
-    const uint32_t* seg;               // [T][B_total]
+    const uint32_t* seg;               // [n_sweeps][T][Bpad]
     const uint32_t* flag;              // [n_sweeps][T]
     uint32_t epoch;
-    int   B_total;                     // row stride of seg
+    int   B_total;                     // all units of the pass
     int   U;                           // records per unit slot
     int   n_sweeps;
     const int* sweep_unit0;            // [n_sweeps+1] (NULL when n_sweeps == 1: units [0, B_total))
-    int   Bpad;                        // max units of one sweep (sizes the LDS prefix table)
+    int   Bpad;                        // units of the longest sweep: row length of seg
     int   T, tiles_per_row, L;
     int   row0, row1;                  // owned storage rows
     float mahal, var_floor;
