@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-oracle baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary (batched C4) measurement")
     return ap.parse_args()
 
 
@@ -68,6 +69,47 @@ def cpu_baseline(wl, seconds: float):
     return {"value": pts / dt, "unit": "points/s", "cores": 1, "kind": "port",
             "sample": f"{k} sweeps x 131072 pts of the same workload ({dt:.1f} s), oracle/gem_oracle.c gemo_add, 1 thread, "
                       f"host has {os.cpu_count()} cores"}
+
+
+def pmc_traffic(kernel_prefix: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (same command,
+    profiles/), corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes (FETCH_SIZE doubled)."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob("r*_c2_bench.json")):
+        try:
+            c = json.loads(f.read_text()).get("counters", {})
+        except Exception:
+            continue
+        for k, v in c.items():
+            if k.split("<")[0].endswith(kernel_prefix) and "hbm_bytes_high" in v:
+                best = (f.name, v)
+    return best
+
+
+def batched_c4(emap_cls, dev, torch, reps: int = 10):
+    """Secondary figure: BASELINE configs[3] -- 32 consecutive sweeps with a variance increment before each,
+    one gem_add_batch_device call (the regime in which the path is bandwidth- rather than launch-bound)."""
+    from gem_amd import synth
+    wl = synth.config_c4(n_sweeps=32)
+    cat = torch.from_numpy(np.concatenate(wl.clouds)).to(dev)
+    off = np.concatenate([[0], np.cumsum([c.shape[0] for c in wl.clouds])])
+    m = emap_cls(wl.length, wl.resolution, device=dev.index)
+    for _ in range(3):
+        m.add_batch(wl.frames, cat, off, wl.var_updates)
+    m.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        m.add_batch(wl.frames, cat, off, wl.var_updates)
+    m.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    m.set_counting(True)
+    m.add_batch(wl.frames, cat, off, wl.var_updates)
+    cells = m.stats()["cells_touched"]
+    m.close()
+    alg = 16.0 * cat.shape[0] + 16.0 * cells + 8.0 * wl.length * wl.length * 32
+    return {"workload": "C4: 32 consecutive 131072-pt sweeps + Mapvar_update before each, one batched call, 600x600 map",
+            "value": cat.shape[0] / dt, "unit": "points/s", "us_per_batch": dt * 1e6,
+            "algorithmic_bytes": alg, "achieved_GBps": alg / dt / 1e9, "frac_of_hbm_peak": alg / dt / 1e9 / HBM_PEAK_GBS}
 
 
 def main():
@@ -149,19 +191,26 @@ def main():
     us_fuse = 1e3 * st["ms_fuse"] / max(st["launches_fuse"], 1)
     # algorithmic bytes per launch (B_alg = 16 N + 16 C_touched): k_bin reads one 16-byte
     # XYZI record per point; k_fuse reads + writes elevation and variance once per touched cell.
-    alg_bin = 16.0 * n_per
-    alg_fuse = 16.0 * cells
+    alg_bin = 16.0 * n_per * sweeps_per_step
+    alg_fuse = 16.0 * cells * sweeps_per_step
     if us_fuse >= us_bin:
-        dom, dom_us, dom_bytes = "k_fuse", us_fuse, alg_fuse
+        dom, dom_us, dom_bytes = "k_fuse_list", us_fuse, alg_fuse
     else:
-        dom, dom_us, dom_bytes = "k_bin", us_bin, alg_bin
+        dom, dom_us, dom_bytes = "k_bin_wave", us_bin, alg_bin
     achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
+    traffic, traffic_note = None, "no committed PMC summary found under profiles/"
+    pm = pmc_traffic(dom) if not distributed else None
+    if pm:
+        traffic = pm[1]["hbm_bytes_high"]
+        traffic_note = (f"profiles/{pm[0]}: FETCH_SIZE {pm[1]['FETCH_SIZE']:.0f} KB (doubled per the guide) + WRITE_SIZE {pm[1]['WRITE_SIZE']:.0f} KB "
+                        f"per launch; uncorrected {pm[1]['hbm_bytes_low']:.0f} B")
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "us_per_launch": {"k_bin": us_bin, "k_fuse": us_fuse},
-                "algorithmic_bytes_per_launch": {"k_bin": alg_bin, "k_fuse": alg_fuse},
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                "us_per_launch": {"k_bin_wave": us_bin, "k_fuse_list": us_fuse},
+                "algorithmic_bytes_per_launch": {"k_bin_wave": alg_bin, "k_fuse_list": alg_fuse},
                 "pipeline_GBps": (alg_bin + alg_fuse) / ((us_bin + us_fuse) * 1e-6) / 1e9 if us_bin + us_fuse > 0 else 0.0,
-                "note": "frame is ~3 MB: both kernels are launch/latency bound, see DESIGN.md"}
+                "note": "one sweep is ~3 MB of algorithmic traffic (0.5 us at the HBM rate): both kernels are launch/latency "
+                        "bound on this workload, see DESIGN.md section 6; `batched_c4` is the bandwidth-regime figure"}
 
     out = {
         "metric": "fused points/sec into 600x600 grid; achieved HBM GB/s vs roofline",
@@ -175,6 +224,8 @@ def main():
                    "cells_touched_per_sweep": cells},
         "roofline": roofline,
     }
+    if rank == 0 and not distributed and not args.no_extras:
+        out["batched_c4"] = batched_c4(ElevationMap, dev, torch)
     if rank == 0 and not distributed and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
     if rank == 0:
