@@ -58,7 +58,7 @@ struct gem_handle {
         Arena tables;                  // batched-call tables (frames, sweep_unit0, sweep_first, var_updates)
         hipEvent_t bin_done = nullptr, fuse_done = nullptr;
         bool fuse_recorded = false;
-        uint32_t epoch = 0;            // descriptor-table epoch of the last pass (0 = table holds no live words)
+        uint32_t epoch = 0;            // touched-flag stamp of the last pass (0 = the flag table holds no live stamps)
     } pb[2];
     unsigned pass = 0;
     hipStream_t bin_stream = nullptr;
@@ -82,7 +82,6 @@ struct gem_handle {
 
     Arena dbg;          // optional k_fuse phase stamps
     bool  dbg_on = false;
-    int ipt_override = 0;
     int fuse_variant = 12;
 };
 
@@ -133,14 +132,6 @@ void fill_frame(const gem_handle* h, const gem_frame_params* p, FrameConst& f)
     f.sx = h->start[0];  f.sy = h->start[1];
     f.L = h->L; f.res = h->res;
     f.row0 = h->row0; f.row1 = h->row1;
-}
-
-int choose_ipt(const gem_handle* h, long long n)
-{
-    if (h->ipt_override == 1 || h->ipt_override == 2 || h->ipt_override == 4) return h->ipt_override;
-    if (n <= 524288) return 1;         // 64-point wave units (k_bin_wave)
-    if (n <= 1048576) return 2;
-    return 4;
 }
 
 hipEvent_t get_event(gem_handle* h)
@@ -210,13 +201,29 @@ struct PassInput {
     const int* f_R = nullptr; const int* f_G = nullptr; const int* f_B = nullptr; const float* f_I = nullptr;
 };
 
-int run_pipeline(gem_handle* h, const PassInput& in)
+constexpr int       kUnit = 64;                      // points per unit (one wave of k_bin_wave)
+constexpr long long kSweepPoints = 2048ll * kUnit;   // a single cloud longer than this is processed as a batch of sweeps of this size
+
+int run_pipeline(gem_handle* h, const PassInput& in0)
 {
+    // A big single cloud becomes a batch of sweeps with one frame: every tile then only reads the descriptor
+    // rows of the sweeps that reach it (flag[tile][sweep]) instead of one row over all units.  The
+    // recurrence is unchanged: the per-sweep variance floor is idempotent with the floor at the start of every
+    // step (GPU:500-501), and no variance increment is applied between these sweeps.
+    PassInput in = in0;
+    std::vector<gem_frame_params> cut_params;
+    std::vector<long long> cut_offsets;
+    std::vector<int> orig0;
+    if (in.n_sweeps == 1 && in.src == 0 && in.n > kSweepPoints) {
+        const int ns = (int)((in.n + kSweepPoints - 1) / kSweepPoints);
+        cut_params.assign(ns, *in.params);
+        cut_offsets.resize(ns + 1); orig0.resize(ns);
+        for (int s = 0; s <= ns; ++s) cut_offsets[s] = std::min<long long>(in.n, (long long)s * kSweepPoints);
+        for (int s = 0; s < ns; ++s) orig0[s] = (int)cut_offsets[s];
+        in.n_sweeps = ns; in.params = cut_params.data(); in.offsets = cut_offsets.data(); in.var_updates = nullptr;
+    }
     const bool batched = in.n_sweeps > 1;
-    long long max_sweep = in.n;
-    if (batched) { max_sweep = 0; for (int s = 0; s < in.n_sweeps; ++s) max_sweep = std::max(max_sweep, in.offsets[s + 1] - in.offsets[s]); }
-    const int ipt = choose_ipt(h, max_sweep);
-    const int U = 64 * ipt;
+    const int U = kUnit;
 
     // units per sweep
     std::vector<int> unit0(in.n_sweeps + 1, 0);
@@ -224,7 +231,7 @@ int run_pipeline(gem_handle* h, const PassInput& in)
     for (int s = 0; s < in.n_sweeps; ++s) {
         const long long cnt = batched ? in.offsets[s + 1] - in.offsets[s] : in.n;
         long long units = (cnt + U - 1) / U;
-        units = (units + 3) & ~3ll;                 // descriptor rows are read 4 units (16 B) at a time
+        units = (units + 7) & ~7ll;                 // descriptor rows are read 8 units (16 B) at a time
         if (units > 0x3fffffff) return fail(h, GEM_ERR_INVALID, "cloud too large");
         unit0[s + 1] = unit0[s] + (int)units;
         bpad = std::max(bpad, (int)units);
@@ -245,20 +252,17 @@ int run_pipeline(gem_handle* h, const PassInput& in)
     if (in.src == 0 && in.rgb) attr = 1;
     if (in.src == 1 && in.f_R && in.f_G && in.f_B && in.f_I) attr = 2;
     // tile size of this pass: 16x16 cells (more, lighter workgroups: better balance and latency hiding)
-    // unless the (tile x unit) descriptor table would get too big, then 32x32
+    // unless the [sweep][tile][unit] descriptor table would get too big, then 32x32
     int ts = h->ts;
     if (ts == 0) {
         const long long tpr4 = (h->L + 15) / 16;
-        ts = (tpr4 * tpr4 * (long long)bpad * in.n_sweeps * 4 <= (1ll << 30)) ? 4 : 5;
+        ts = (tpr4 * tpr4 * (long long)bpad * in.n_sweeps * (long long)sizeof(uint16_t) <= (1ll << 29)) ? 4 : 5;
     }
     const int te = 1 << ts;
     const int tiles_per_row = (h->L + te - 1) / te;
     const int T = tiles_per_row * tiles_per_row;
     h->T = T;
-    int nt, rr;
-    fuse_geometry(ts, h->fuse_variant, &nt, &rr);
-    if ((h->fuse_variant >= 10 ? fuse_list_lds_bytes(ts, h->fuse_variant, attr) : fuse_lds_bytes(ts, nt, rr, bpad, attr)) > 160 * 1024)
-        return fail(h, GEM_ERR_INVALID, "fuse kernel geometry exceeds the LDS");
+    if (fuse_lds_bytes(ts, h->fuse_variant, attr) > 160 * 1024) return fail(h, GEM_ERR_INVALID, "fuse kernel geometry exceeds the LDS");
 
     // k_bin of this pass may run on its own stream, concurrently with the k_fuse of the previous pass
     // (it depends on the cloud and the pose, not on the map).  Only with the handle's own stream:
@@ -270,22 +274,21 @@ int run_pipeline(gem_handle* h, const PassInput& in)
                          !h->counting && !h->dbg_on;
     gem_handle::PassBuffers& pb = h->pb[overlap ? (h->pass++ & 1u) : 0u];
     hipStream_t sbin = overlap ? h->bin_stream : h->stream;
-    if (!overlap && h->pb[0].fuse_recorded && h->stream != h->own_stream) {
-        // switching from overlapped passes to a caller stream: order it behind everything enqueued so far
-        for (auto& b : h->pb) if (b.fuse_recorded) GEM_HIP(h, hipStreamWaitEvent(h->stream, b.fuse_done, 0));
-    }
     int rc;
     if ((rc = ensure(h, pb.rec, (size_t)B * U * sizeof(uint4)))) return rc;
     if (overlap && pb.fuse_recorded) GEM_HIP(h, hipStreamWaitEvent(sbin, pb.fuse_done, 0));   // k_fuse of pass p-2 has read these buffers
-    {   // descriptor table: words are stamped with an epoch instead of being cleared every pass
-        const size_t need = (size_t)in.n_sweeps * T * bpad * sizeof(uint32_t);        // [sweep][tile][unit in sweep]
-        const bool grow = need > pb.seg.cap;
-        if ((rc = ensure(h, pb.seg, need))) return rc;
+    {   // descriptor table [sweep][tile][unit in sweep]: k_fuse_list zeroes what it consumes, so the table only
+        // has to be cleared when it is (re)allocated
+        const size_t need = (size_t)in.n_sweeps * T * bpad * sizeof(uint16_t);
+        if (need > pb.seg.cap) {
+            if ((rc = ensure(h, pb.seg, need))) return rc;
+            GEM_HIP(h, hipMemsetAsync(pb.seg.p, 0, pb.seg.cap, sbin));
+        }
+        // touched flags [tile][sweep]: stamped with the pass's epoch instead of being cleared
         const size_t need_flag = (size_t)T * in.n_sweeps * sizeof(uint32_t);
         const bool grow_flag = need_flag > pb.flag.cap;
         if ((rc = ensure(h, pb.flag, need_flag))) return rc;
-        if (grow || grow_flag || pb.epoch >= kSegEpochMax) {
-            GEM_HIP(h, hipMemsetAsync(pb.seg.p, 0, pb.seg.cap, sbin));
+        if (grow_flag || pb.epoch >= kFlagEpochMax) {
             GEM_HIP(h, hipMemsetAsync(pb.flag.p, 0, pb.flag.cap, sbin));
             pb.epoch = 0;
         }
@@ -295,17 +298,19 @@ int run_pipeline(gem_handle* h, const PassInput& in)
     BinArgs ba{};
     FuseArgs fa{};
     if (batched) {
-        // tables: frames | unit0 | first | var_updates
+        // tables: frames | unit0 | first | orig0 | var_updates
         const size_t o_frames = 0;
         const size_t o_unit0 = o_frames + sizeof(FrameConst) * in.n_sweeps;
         const size_t o_first = (o_unit0 + sizeof(int) * (in.n_sweeps + 1) + 15) & ~(size_t)15;
-        const size_t o_var = o_first + sizeof(long long) * (in.n_sweeps + 1);
+        const size_t o_orig = o_first + sizeof(long long) * (in.n_sweeps + 1);
+        const size_t o_var = o_orig + sizeof(int) * in.n_sweeps;
         const size_t total = o_var + sizeof(float) * in.n_sweeps;
         if ((rc = ensure(h, pb.tables, total))) return rc;
         std::vector<unsigned char> host(total, 0);
         for (int s = 0; s < in.n_sweeps; ++s) fill_frame(h, &in.params[s], reinterpret_cast<FrameConst*>(host.data() + o_frames)[s]);
         memcpy(host.data() + o_unit0, unit0.data(), sizeof(int) * (in.n_sweeps + 1));
         memcpy(host.data() + o_first, in.offsets, sizeof(long long) * (in.n_sweeps + 1));
+        if (!orig0.empty()) memcpy(host.data() + o_orig, orig0.data(), sizeof(int) * in.n_sweeps);
         if (in.var_updates) memcpy(host.data() + o_var, in.var_updates, sizeof(float) * in.n_sweeps);
         GEM_HIP(h, hipMemcpyAsync(pb.tables.p, host.data(), total, hipMemcpyHostToDevice, sbin));
         GEM_HIP(h, hipStreamSynchronize(sbin));           // `host` is a local
@@ -313,6 +318,7 @@ int run_pipeline(gem_handle* h, const PassInput& in)
         ba.frames = reinterpret_cast<const FrameConst*>(d + o_frames);
         ba.sweep_unit0 = reinterpret_cast<const int*>(d + o_unit0);
         ba.sweep_first = reinterpret_cast<const long long*>(d + o_first);
+        ba.sweep_orig0 = orig0.empty() ? nullptr : reinterpret_cast<const int*>(d + o_orig);
         fa.sweep_unit0 = ba.sweep_unit0;
         fa.var_updates = in.var_updates ? reinterpret_cast<const float*>(d + o_var) : nullptr;
     } else {
@@ -325,7 +331,7 @@ int run_pipeline(gem_handle* h, const PassInput& in)
     ba.T = T; ba.tiles_per_row = tiles_per_row; ba.B = B; ba.Bpad = bpad;
     ba.tile_bits = 0; while ((1 << ba.tile_bits) < T) ++ba.tile_bits;
     ba.epoch = pb.epoch;
-    ba.rec = static_cast<uint4*>(pb.rec.p); ba.seg = static_cast<uint32_t*>(pb.seg.p); ba.flag = static_cast<uint32_t*>(pb.flag.p);
+    ba.rec = static_cast<uint4*>(pb.rec.p); ba.seg = static_cast<uint16_t*>(pb.seg.p); ba.flag = static_cast<uint32_t*>(pb.flag.p);
     ba.counters = h->counting ? h->d_counters : nullptr;
 
     fa.epoch = pb.epoch;
@@ -339,6 +345,7 @@ int run_pipeline(gem_handle* h, const PassInput& in)
     fa.intensity = h->layers.intensity; fa.colorR = h->layers.colorR; fa.colorG = h->layers.colorG; fa.colorB = h->layers.colorB;
     fa.xyzi = in.xyzi; fa.rgb = in.rgb; fa.f_R = in.f_R; fa.f_G = in.f_G; fa.f_B = in.f_B; fa.f_I = in.f_I;
     fa.counters = ba.counters;
+    fa.count_per_pass = orig0.empty() ? 0 : 1;
     fa.dbg = nullptr;
     if (h->dbg_on) {
         if ((rc = ensure(h, h->dbg, (size_t)T * 16 * 8))) return rc;
@@ -347,7 +354,7 @@ int run_pipeline(gem_handle* h, const PassInput& in)
     }
 
     if (h->counting) GEM_HIP(h, hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
-    { Timed t(h, 0); GEM_HIP(h, launch_bin(sbin, ba, ipt, in.src, ts, t.events())); }
+    { Timed t(h, 0); GEM_HIP(h, launch_bin(sbin, ba, in.src, ts, t.events())); }
     if (overlap) {
         GEM_HIP(h, hipEventRecord(pb.bin_done, sbin));
         GEM_HIP(h, hipStreamWaitEvent(h->stream, pb.bin_done, 0));
@@ -395,12 +402,10 @@ int gem_create(const gem_map_config* cfg, gem_handle** out)
         if (cfg->strip_row0 < 0 || cfg->strip_row0 + cfg->strip_rows > h->L) { delete h; return fail(nullptr, GEM_ERR_INVALID, "gem_create: bad strip"); }
         h->row0 = cfg->strip_row0; h->row1 = cfg->strip_row0 + cfg->strip_rows;
     }
-    h->fuse_variant = 12;                       // k_fuse_list on 32x32 tiles: 10 = 256 threads, 11 = 512, 12 = 512 with 2048-record batches (2 per CU); < 10: k_fuse
-    if (const char* s = getenv("GEM_FUSE_VARIANT")) h->fuse_variant = atoi(s);
+    h->fuse_variant = 12;                       // k_fuse_list geometry on 32x32 tiles: 10 = 256 threads, 11 = 512, 12 = 512 with 2048-record batches (2 per CU)
+    if (const char* s = getenv("GEM_FUSE_VARIANT")) { const int v = atoi(s); if (v >= 10 && v <= 12) h->fuse_variant = v; }
     h->ts = 0;                                  // 0: chosen per pass (run_pipeline)
-    if (h->fuse_variant < 10) h->ts = h->L > 1024 ? 6 : 5;
-    if (const char* s = getenv("GEM_TILE_SHIFT")) { int v = atoi(s); if (v >= 4 && v <= (h->fuse_variant >= 10 ? 5 : 6)) h->ts = v; }
-    if (const char* s = getenv("GEM_IPT")) h->ipt_override = atoi(s);
+    if (const char* s = getenv("GEM_TILE_SHIFT")) { const int v = atoi(s); if (v == 4 || v == 5) h->ts = v; }
 
     auto bail = [&](const char* what, hipError_t err) { int rc = fail(nullptr, GEM_ERR_HIP, what, err); gem_destroy(h); return rc; };
     if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);

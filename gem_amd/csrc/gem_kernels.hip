@@ -1,18 +1,19 @@
 // gem_kernels.hip -- gfx950 kernels of the GEM point-cloud -> elevation-grid hot path.
 //
-// Pipeline for one cloud (replaces G_pointsprocess + G_fuse, gpu_process.cu:384-455 / 477-537):
+// Pipeline for one pass (replaces G_pointsprocess + G_fuse, gpu_process.cu:384-455 / 477-537):
 //
-//   k_bin   one WAVE per "unit" of 64*IPT consecutive points: coalesced float4 XYZI loads,
-//           projection + variance + 2.5-D binning in registers, then a wave-local STABLE
-//           counting sort of the unit's points by map tile (32x32 or 64x64 cells).  Emits
-//           16-byte records {cell-in-tile, h, var, src} grouped by tile inside the unit's own
-//           slice of the record arena (no global scan needed) and a (start,count) descriptor
-//           per (tile, unit).
-//   k_fuse  one workgroup per tile: stages the tile's elevation/variance in LDS, gathers the
-//           tile's records unit by unit (ascending unit == ascending input index), stable-sorts
-//           them by cell in LDS (per-wave histograms + ballot ranking), then one lane per cell
-//           walks its points in input order applying the reference's non-associative
-//           recurrence, and the tile is written back once with the variance floor applied.
+//   k_bin_wave   one WAVE per "unit" of 64 consecutive points: coalesced float4 XYZI loads,
+//                projection + variance + 2.5-D binning in registers, then a wave-local STABLE
+//                grouping of the unit's points by map tile (16x16 or 32x32 cells) from ballots.
+//                Emits 16-byte records {cell-in-tile, h, var, src} grouped by tile inside the unit's
+//                own slice of the record arena (no global scan, no atomics) and one 16-bit
+//                descriptor {start, count} per (sweep, tile, unit).
+//   k_fuse_list  one workgroup per tile: ordered compaction of the tile's live descriptors,
+//                records gathered into LDS in input order, arrival ranks per cell from an LDS atomic,
+//                the cell's owner sorts its <= 7 slot numbers in registers and applies the
+//                reference's non-associative recurrence in input order; any multiplicity beyond that
+//                goes through per-wave in-order linked lists.  The tile is read once and written
+//                back once with the variance floor applied.
 //
 // The reference's fusion is order dependent (variance floor inside the loop, Mahalanobis branch),
 // so every step above preserves ascending point index per cell; there are no float atomics.
@@ -118,9 +119,9 @@ __global__ __launch_bounds__(256) void k_project(FrameConst fc, int n, float* __
 // ------------------------------------------------------------------------------------------
 // k_bin_wave : one WAVE = one unit of 64 consecutive points.  No LDS, no loops, no barriers.
 // ------------------------------------------------------------------------------------------
-// Descriptor word of (tile, unit):  epoch << 17 | start << 9 | count.  Only the tiles a unit
-// actually touches are written; stale words are recognised by their epoch, so the table is
-// never cleared between frames.
+// Descriptor word of (sweep, tile, unit), 16 bits:  start << 7 | count  (count 1..64, 0 = empty).
+// Only the tiles a unit actually touches are written; k_fuse_list zeroes every word it consumes,
+// so the table is all-zero again after each pass and never needs a clearing kernel.
 template <int SRC, int TS, bool BATCH>
 __global__ __launch_bounds__(256) void k_bin_wave(BinArgs a)
 {
@@ -130,13 +131,14 @@ __global__ __launch_bounds__(256) void k_bin_wave(BinArgs a)
     const int unit = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (unit >= a.B) return;                               // whole wave leaves together
 
-    int sweep = 0, unit_first = 0;
+    int sweep = 0, unit_first = 0, orig0 = 0;
     long long base, sweep_begin = 0, sweep_end = a.n;
     if (BATCH) {
         int lo = 0, hi = a.n_sweeps;
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.sweep_unit0[mid] <= unit) lo = mid; else hi = mid; }
         sweep = lo; unit_first = a.sweep_unit0[sweep];
         sweep_begin = a.sweep_first[sweep]; sweep_end = a.sweep_first[sweep + 1];
+        orig0 = a.sweep_orig0 ? a.sweep_orig0[sweep] : 0;            // a big cloud cut into sweeps keeps its point numbering
         base = sweep_begin + (long long)(unit - unit_first) * U;
     } else {
         base = (long long)unit * U;
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256) void k_bin_wave(BinArgs a)
         int row, col; float h, v; bool colour_ok = false;
         if (SRC == 0) {
             const float4 p = a.xyzi[i];
-            const Projected r = project_point(fc, p.x, p.y, p.z, a.orig ? a.orig[i] : (int)(i - sweep_begin));
+            const Projected r = project_point(fc, p.x, p.y, p.z, a.orig ? a.orig[i] : (int)(i - sweep_begin) + orig0);
             row = r.row; col = r.col; h = r.h; v = r.var;
             if (a.rgb) {
                 const uint32_t c = a.rgb[i];
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256) void k_bin_wave(BinArgs a)
     if (valid) a.rec[(size_t)unit * U + start + rank] = make_uint4(cl, __float_as_uint(hh), __float_as_uint(vv), src);
     if (leader) {
         // table layout [sweep][tile][unit in sweep]: the words one sweep writes stay within T * Bpad * 4 bytes
-        a.seg[((size_t)sweep * a.T + tile) * a.Bpad + (unit - unit_first)] = (a.epoch << kSegEpochShift) | (start << kSegCountBits) | cnt;
+        a.seg[((size_t)sweep * a.T + tile) * a.Bpad + (unit - unit_first)] = (uint16_t)((start << kSegCountBits) | cnt);
         a.flag[(size_t)tile * a.n_sweeps + sweep] = a.epoch;       // "tile touched in this sweep" (same value from every writer)
     }
 
@@ -192,439 +194,6 @@ __global__ __launch_bounds__(256) void k_bin_wave(BinArgs a)
         const uint32_t nb = (uint32_t)__popcll(__ballot(valid));
         if (lane == 0 && nb) atomicAdd(&a.counters[0], (unsigned long long)nb);
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_bin_lds : one WAVE = one unit of 64*IPT points (IPT = 2, 4); per-tile counts in LDS so that a
-// tile's points from all chunks of the unit land contiguously.  Used for larger clouds, where
-// 64-point units would make the (tile x unit) descriptor table too big.
-// ------------------------------------------------------------------------------------------
-template <int IPT, int SRC, int TS, bool BATCH>
-__global__ __launch_bounds__(64) void k_bin_lds(BinArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_cnt[];      // [T]
-    constexpr int TE = 1 << TS;
-    constexpr int U = 64 * IPT;
-    const int lane = lane_id();
-    const int unit = (int)blockIdx.x;
-    const int T = a.T;
-
-    int sweep = 0, unit_first = 0;
-    long long base, sweep_begin = 0, sweep_end = a.n;
-    if (BATCH) {
-        int lo = 0, hi = a.n_sweeps;                 // sweep_unit0[lo] <= unit < sweep_unit0[hi]
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.sweep_unit0[mid] <= unit) lo = mid; else hi = mid; }
-        sweep = lo; unit_first = a.sweep_unit0[sweep];
-        sweep_begin = a.sweep_first[sweep]; sweep_end = a.sweep_first[sweep + 1];
-        base = sweep_begin + (long long)(unit - unit_first) * U;
-    } else {
-        base = (long long)unit * U;
-    }
-    const FrameConst fc = BATCH ? a.frames[sweep] : a.frame0;
-    const long long left = sweep_end - base;
-    const int npts = left < U ? (int)left : U;
-
-    for (int t = lane; t < T; t += 64) lds_cnt[t] = 0;
-    __syncthreads();
-
-    uint32_t tile[IPT], cl[IPT], src[IPT];
-    float hh[IPT], vv[IPT];
-    uint32_t n_binned = 0;
-
-#pragma unroll
-    for (int j = 0; j < IPT; ++j) {
-        const int o = j * 64 + lane;
-        tile[j] = (uint32_t)kInvalidTile; cl[j] = 0; hh[j] = 0.0f; vv[j] = 0.0f; src[j] = 0;
-        if (o < npts) {
-            const long long i = base + o;
-            int row, col; float h, v; bool colour_ok = false;
-            if (SRC == 0) {
-                const float4 p = a.xyzi[i];
-                const Projected r = project_point(fc, p.x, p.y, p.z, a.orig ? a.orig[i] : (int)(i - sweep_begin));
-                row = r.row; col = r.col; h = r.h; v = r.var;
-                if (a.rgb) {
-                    const uint32_t c = a.rgb[i];
-                    colour_ok = ((c >> 16) & 0xff) != 0 && ((c >> 8) & 0xff) != 0 && (c & 0xff) != 0 && p.w != 0.0f;
-                }
-            } else {
-                const int cell = a.f_index[i]; h = a.f_height[i]; v = a.f_var[i];
-                row = -1; col = -1;
-                if (cell >= 0 && cell < fc.L * fc.L) { row = cell / fc.L; col = cell - row * fc.L; }
-                if (a.f_R) colour_ok = a.f_R[i] != 0 && a.f_G[i] != 0 && a.f_B[i] != 0 && a.f_I[i] != 0.0f;
-            }
-            if (row >= fc.row0 && row < fc.row1 && h != -1.0f) {     // GPU:482
-                tile[j] = (uint32_t)((row >> TS) * a.tiles_per_row + (col >> TS));
-                cl[j] = (uint32_t)(((row & (TE - 1)) << TS) | (col & (TE - 1))) | (colour_ok ? 0x80000000u : 0u);
-                hh[j] = h; vv[j] = v; src[j] = (uint32_t)i;
-                atomicAdd(&lds_cnt[tile[j]], 1u);
-                ++n_binned;
-            }
-        }
-    }
-    __syncthreads();
-
-    // wave-level exclusive scan of the T tile counts (blocked: lane owns K consecutive tiles)
-    const int K = (T + 63) / 64;
-    const int t0 = lane * K;
-    uint32_t local = 0;
-    for (int k = 0; k < K; ++k) { const int t = t0 + k; if (t < T) local += lds_cnt[t]; }
-    uint32_t run = wave_inclusive_scan(local) - local;
-    uint32_t* seg = a.seg;
-    for (int k = 0; k < K; ++k) {
-        const int t = t0 + k;
-        if (t < T) {
-            const uint32_t c = lds_cnt[t];
-            lds_cnt[t] = run;                                       // becomes the running base of tile t
-            if (c) { seg[((size_t)sweep * a.T + t) * a.Bpad + (unit - unit_first)] = (a.epoch << kSegEpochShift) | (run << kSegCountBits) | c; a.flag[(size_t)t * a.n_sweeps + sweep] = a.epoch; }
-            run += c;
-        }
-    }
-    __syncthreads();
-
-    // stable placement, chunk by chunk in input order, into this unit's slice of the arena
-    uint4* rec = a.rec + (size_t)unit * U;
-    const uint64_t lt = lanemask_lt();
-#pragma unroll
-    for (int j = 0; j < IPT; ++j) {
-        const bool valid = tile[j] != (uint32_t)kInvalidTile;
-        const uint64_t peers = wave_peers(valid, tile[j], a.tile_bits);
-        const uint32_t rank = (uint32_t)__popcll(peers & lt);
-        uint32_t old = 0;
-        if (valid) {
-            old = lds_cnt[tile[j]];                                  // same address within a group: broadcast
-            if (rank == 0) lds_cnt[tile[j]] = old + (uint32_t)__popcll(peers);
-            rec[old + rank] = make_uint4(cl[j], __float_as_uint(hh[j]), __float_as_uint(vv[j]), src[j]);
-        }
-        __syncthreads();                                             // one wave: orders the LDS update before the next chunk's reads
-    }
-
-    if (a.counters) {
-        uint32_t s = n_binned;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, 64);
-        if (lane == 0 && s) atomicAdd(&a.counters[0], (unsigned long long)s);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_fuse : one workgroup of NT threads per tile of TE x TE cells.
-// ------------------------------------------------------------------------------------------
-// Thread t owns cells {t + NT*q} of the tile for the whole kernel: their (elevation, variance)
-// live in registers from the single read to the single write-back.  LDS holds the per-batch sort:
-//   wc[NW][CELLS] u16 | cstart[CELLS] u16 | ccount[CELLS] u16 | s_h[PB] f32 | s_v[PB] f32
-//   | s_src[PB] u32 (ATTR only) | scratch[16] u32 | touched[CELLS/32] u32
-// (s_h doubles as the list of record addresses of the batch until the records are in registers)
-template <int TS, int NT, int R, int ATTR>
-__global__ __launch_bounds__(NT, (NT == 256 ? 6 : 4)) void k_fuse(FuseArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    constexpr int TE = 1 << TS;
-    constexpr int CELLS = TE * TE;
-    constexpr int NW = NT / 64;
-    constexpr int PB = NT * R;
-    constexpr int CPT = CELLS / NT;                  // cells per thread (>= 1)
-    static_assert(CELLS % NT == 0 && CPT >= 1, "tile must have at least one cell per thread");
-
-    uint16_t* wc      = reinterpret_cast<uint16_t*>(lds_raw);              // [NW][CELLS]
-    uint16_t* cstart  = wc + NW * CELLS;
-    uint16_t* ccount  = cstart + CELLS;
-    float*    s_h     = reinterpret_cast<float*>(ccount + CELLS);
-    float*    s_v     = s_h + PB;
-    uint32_t* s_src   = reinterpret_cast<uint32_t*>(s_v + PB);             // [PB] only when ATTR != 0
-    uint32_t* scratch = s_src + (ATTR ? PB : 0);
-    uint32_t* touched = scratch + 16;
-    uint32_t* kaddr   = reinterpret_cast<uint32_t*>(s_h);                  // [PB] arena addresses; dead once the records are in registers
-
-    const int tid = (int)threadIdx.x;
-    const int lane = lane_id();
-    const int w = tid >> 6;
-    const int tile = (int)blockIdx.x;
-    const int tr = tile / a.tiles_per_row, tc = tile - tr * a.tiles_per_row;
-    const int row_base = tr << TS, col_base = tc << TS;
-    const int L = a.L;
-    const uint32_t epoch = a.epoch;
-    const uint64_t lt = lanemask_lt();
-    int dbg_k = 0;
-#define GEM_STAMP() do { if (a.dbg && tid == 0 && dbg_k < 16) a.dbg[(size_t)tile * 16 + dbg_k++] = (unsigned long long)__builtin_readcyclecounter(); } while (0)
-    GEM_STAMP();                                                         // 0: start
-
-    // ---- 0. batched call: does this tile receive any point at all? (single sweep: step 3 tells) ----
-    if (!a.dense && a.n_sweeps > 1) {
-        int any = 0;
-        for (int sw = 0; sw < a.n_sweeps; ++sw) {
-            const uint32_t* row = a.seg + ((size_t)sw * a.T + tile) * a.Bpad;
-            const int Bs = a.sweep_unit0[sw + 1] - a.sweep_unit0[sw];
-            for (int u = tid; u < Bs; u += NT) any |= (row[u] >> kSegEpochShift) == epoch;
-        }
-        if (!__syncthreads_or(any)) return;
-    }
-
-    // ---- 1. the single read of the tile ---------------------------------------------------------
-    float ce[CPT], cs[CPT];
-    bool  owned[CPT];
-#pragma unroll
-    for (int q = 0; q < CPT; ++q) {
-        const int c = tid + NT * q;
-        const int row = row_base + (c >> TS), col = col_base + (c & (TE - 1));
-        owned[q] = row < a.row1 && row >= a.row0 && col < L;
-        ce[q] = kEmptyElevation; cs[q] = kInitVariance;
-        if (owned[q]) {
-            const size_t g = (size_t)row * L + col;
-            ce[q] = a.elevation[g]; cs[q] = a.variance[g];
-        }
-    }
-
-    GEM_STAMP();                                                         // 1: tile loads issued
-    for (int sweep = 0; sweep < a.n_sweeps; ++sweep) {
-        const int ub = a.sweep_unit0 ? a.sweep_unit0[sweep] : 0;        // multiple of 4 (host pads sweeps)
-        const int ue = a.sweep_unit0 ? a.sweep_unit0[sweep + 1] : a.B_total;
-        const int B = ue - ub;
-        const uint32_t* seg = a.seg + ((size_t)sweep * a.T + tile) * a.Bpad;    // this sweep's descriptor row of the tile
-
-        // ---- 2. Mapvar_update increments queued before this sweep (GPU:540-547) ------------------
-#pragma unroll
-        for (int q = 0; q < CPT; ++q) {
-            if (sweep == 0)
-                for (int k = 0; k < a.n_pending; ++k) if (cs[q] != kInitVariance) cs[q] += a.pending[k];
-            if (a.var_updates) { if (cs[q] != kInitVariance) cs[q] += a.var_updates[sweep]; }
-        }
-
-        // ---- 3/4. batches of PB points, in input order.  Each batch makes ONE vectorised pass over
-        //      the tile's descriptor row (4 units per thread and step), turning every unit's
-        //      (start, count) into the arena addresses of its records for k in [bbase, bbase + PB).
-        uint32_t P = 0;
-        bool first = true;
-        uint32_t* khead = reinterpret_cast<uint32_t*>(s_v);              // [PB] head markers (s_v is dead here)
-        constexpr int V = 2;                                             // uint4 descriptor loads per thread and chunk
-        for (uint32_t bbase = 0; first || bbase < P; bbase += PB) {
-            uint4 e[V];
-            {   // first chunk's loads fly while the LDS tables are cleared
-                const int u = tid * (4 * V);
-#pragma unroll
-                for (int x = 0; x < V; ++x) {
-                    e[x] = make_uint4(0, 0, 0, 0);
-                    if (u + 4 * x < B) e[x] = *reinterpret_cast<const uint4*>(seg + u + 4 * x);   // rows are padded to 4 units
-                }
-            }
-            for (int c = tid; c < PB; c += NT) khead[c] = 0;
-            {   // zero the per-wave cell counters (u16 pairs)
-                uint32_t* z = reinterpret_cast<uint32_t*>(wc);
-                for (int c = tid; c < NW * CELLS / 2; c += NT) z[c] = 0;
-            }
-            if (bbase == 0 && tid < CELLS / 32) touched[tid] = 0;
-            __syncthreads();
-            uint32_t carry = 0;
-            for (int ubase = 0; ubase < B; ubase += NT * 4 * V) {
-                const int u = ubase + tid * (4 * V);                     // thread owns 4*V consecutive units
-                if (ubase != 0) {
-#pragma unroll
-                    for (int x = 0; x < V; ++x) {
-                        e[x] = make_uint4(0, 0, 0, 0);
-                        if (u + 4 * x < B) e[x] = *reinterpret_cast<const uint4*>(seg + u + 4 * x);
-                    }
-                }
-                uint32_t ev[4 * V], cnt[4 * V], local = 0;
-#pragma unroll
-                for (int x = 0; x < V; ++x) { ev[4 * x] = e[x].x; ev[4 * x + 1] = e[x].y; ev[4 * x + 2] = e[x].z; ev[4 * x + 3] = e[x].w; }
-#pragma unroll
-                for (int j = 0; j < 4 * V; ++j) {
-                    cnt[j] = ((ev[j] >> kSegEpochShift) == epoch && u + j < B) ? (ev[j] & kSegCountMask) : 0u;
-                    local += cnt[j];
-                }
-                uint32_t tot;
-                uint32_t run = carry + block_exclusive_scan<NT>(local, scratch, &tot);
-                carry += tot;
-                // mark where each non-empty unit's records start inside the window [bbase, bbase + PB):
-                // khead[pos] = pos + 1, kaddr[pos] = (arena address of the unit's first record) - k
-#pragma unroll
-                for (int j = 0; j < 4 * V; ++j) {
-                    if (cnt[j] != 0 && run + cnt[j] > bbase && run < bbase + PB) {
-                        const uint32_t addr0 = (uint32_t)(ub + u + j) * (uint32_t)a.U + ((ev[j] >> kSegCountBits) & kSegStartMask);
-                        const uint32_t pos = run > bbase ? run - bbase : 0u;
-                        khead[pos] = pos + 1u;
-                        kaddr[pos] = addr0 - run;                        // address(k) = kaddr[head] + k  (mod 2^32)
-                    }
-                    run += cnt[j];
-                }
-            }
-            P = carry;
-            first = false;
-            GEM_STAMP();                                                 // 2: descriptor row expanded
-            if (P == 0) break;                                           // block-uniform
-            const uint32_t Pb = min((uint32_t)PB, P - bbase);
-            const uint32_t span = ((Pb + NT - 1u) / NT) * 64u;          // contiguous k-range per wave
-            const uint32_t nchunk = span / 64u;                          // <= R
-
-            __syncthreads();                                             // heads visible
-
-            // fill forward: every k of the batch learns its unit's head (max-scan over head positions)
-            {
-                const uint32_t I = (Pb + NT - 1u) / NT;                  // consecutive k per thread, <= R
-                const uint32_t k0 = (uint32_t)tid * I;
-                uint32_t hp[R], cur = 0;
-#pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    hp[i] = 0;
-                    if ((uint32_t)i < I && k0 + i < Pb) { const uint32_t v = khead[k0 + i]; cur = v ? v : cur; hp[i] = cur; }
-                }
-                const uint32_t inc = wave_inclusive_max(cur);            // max-scan of the threads' last heads
-                if (lane == 63) scratch[w] = inc;
-                uint32_t before = wave_prev(inc);
-                __syncthreads();
-                for (int i = 0; i < w; ++i) before = max(before, scratch[i]);
-                uint32_t adr[R];
-#pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    adr[i] = 0;
-                    if ((uint32_t)i < I && k0 + i < Pb) { const uint32_t hh = hp[i] ? hp[i] : before; adr[i] = kaddr[hh - 1u] + bbase + k0 + i; }
-                }
-                __syncthreads();                                         // all head deltas read before kaddr is overwritten
-#pragma unroll
-                for (int i = 0; i < R; ++i)
-                    if ((uint32_t)i < I && k0 + i < Pb) kaddr[k0 + i] = adr[i];
-            }
-            __syncthreads();
-
-            // gather this thread's R records
-            bool act[R];
-            uint4 rr[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t kl = (uint32_t)w * span + (uint32_t)r * 64u + (uint32_t)lane;
-                act[r] = (uint32_t)r < nchunk && kl < Pb;
-                rr[r] = make_uint4(0, 0, 0, 0);
-                if (act[r]) rr[r] = a.rec[kaddr[kl]];
-            }
-            GEM_STAMP();                                                 // 3: record loads issued
-            // count per (wave, cell) and remember each record's offset inside its (wave, cell) run
-            uint32_t loff[R];
-            uint16_t* wcw = wc + w * CELLS;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                loff[r] = 0;
-                if ((uint32_t)r < nchunk) {                               // wave-uniform
-                    const uint32_t cell = rr[r].x & 0xffffu;
-                    const uint64_t peers = wave_peers(act[r], cell, 2 * TS);
-                    const uint32_t rank = (uint32_t)__popcll(peers & lt);
-                    if (act[r]) {
-                        const uint32_t old = wcw[cell];                   // same address within a group: broadcast
-                        if (rank == 0) wcw[cell] = (uint16_t)(old + (uint32_t)__popcll(peers));
-                        loff[r] = old + rank;
-                    }
-                    __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): LDS update lands before the next chunk reads
-                }
-            }
-            __syncthreads();
-            GEM_STAMP();                                                 // 5: records loaded + counted
-
-            // exclusive scan in (cell-major, wave-minor) order
-            {
-                const int c0 = tid * CPT;
-                uint32_t loc = 0;
-#pragma unroll
-                for (int q = 0; q < CPT; ++q)
-#pragma unroll
-                    for (int ww = 0; ww < NW; ++ww) loc += wc[ww * CELLS + c0 + q];
-                uint32_t tot;
-                uint32_t rn = block_exclusive_scan<NT>(loc, scratch, &tot);
-#pragma unroll
-                for (int q = 0; q < CPT; ++q) {
-                    const int c = c0 + q;
-                    const uint32_t st = rn;
-#pragma unroll
-                    for (int ww = 0; ww < NW; ++ww) { const uint32_t x = wc[ww * CELLS + c]; wc[ww * CELLS + c] = (uint16_t)rn; rn += x; }
-                    cstart[c] = (uint16_t)st;
-                    ccount[c] = (uint16_t)(rn - st);
-                    if (a.counters && rn != st) atomicOr(&touched[c >> 5], 1u << (c & 31));
-                }
-            }
-            __syncthreads();
-            GEM_STAMP();                                                 // 6: cell scan done
-
-            // stable placement
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (act[r]) {
-                    const uint32_t pos = (uint32_t)wcw[rr[r].x & 0xffffu] + loff[r];
-                    s_h[pos] = __uint_as_float(rr[r].y); s_v[pos] = __uint_as_float(rr[r].z);
-                    if (ATTR) s_src[pos] = (rr[r].w & 0x7fffffffu) | (rr[r].x & 0x80000000u);
-                }
-            }
-            __syncthreads();
-            GEM_STAMP();                                                 // 7: placed
-
-            // one lane per cell walks its points in input order (GPU:480-531); a thread's CPT cells are
-            // independent chains and advance together so their divisions overlap
-            {
-                uint32_t wcnt[CPT], wst[CPT], wlast[CPT], maxc = 0;
-#pragma unroll
-                for (int q = 0; q < CPT; ++q) {
-                    const int c = tid + NT * q;
-                    wcnt[q] = ccount[c]; wst[q] = cstart[c]; wlast[q] = 0xffffffffu;
-                    maxc = max(maxc, wcnt[q]);
-                }
-                for (uint32_t p = 0; p < maxc; ++p) {
-#pragma unroll
-                    for (int q = 0; q < CPT; ++q) {
-                        if (p < wcnt[q]) {
-                            const uint32_t idx = wst[q] + p;
-                            const bool taken = fuse_step(ce[q], cs[q], s_h[idx], s_v[idx], a.mahal, a.var_floor);
-                            if (ATTR) { const uint32_t sv = s_src[idx]; if (taken && (sv & 0x80000000u)) wlast[q] = sv & 0x7fffffffu; }
-                        }
-                    }
-                }
-                if (ATTR) {
-#pragma unroll
-                    for (int q = 0; q < CPT; ++q) {
-                        const uint32_t last = wlast[q];
-                        if (last != 0xffffffffu) {
-                            // colour / intensity of the last taken point with all four non-zero (GPU:487-494)
-                            const int c = tid + NT * q;
-                            const int row = row_base + (c >> TS), col = col_base + (c & (TE - 1));
-                            const size_t g = (size_t)row * L + col;
-                            if (ATTR == 1) {
-                                const uint32_t cc = a.rgb[last];
-                                a.intensity[g] = a.xyzi[last].w;
-                                a.colorR[g] = (int)((cc >> 16) & 0xff); a.colorG[g] = (int)((cc >> 8) & 0xff); a.colorB[g] = (int)(cc & 0xff);
-                            } else {
-                                a.intensity[g] = a.f_I[last];
-                                a.colorR[g] = a.f_R[last]; a.colorG[g] = a.f_G[last]; a.colorB[g] = a.f_B[last];
-                            }
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            GEM_STAMP();                                                 // 8: walked
-        }
-
-        if (P == 0 && !a.dense && a.n_sweeps == 1) return;               // block-uniform: untouched tile, nothing to write
-
-        // ---- 5. variance floor at the end of every Fuse (GPU:533-534), on every cell -------------
-#pragma unroll
-        for (int q = 0; q < CPT; ++q) if (cs[q] < a.var_floor) cs[q] = a.var_floor;
-
-        if (a.counters && P != 0) {
-            if (tid < CELLS / 32) {
-                const uint32_t n = (uint32_t)__popc(touched[tid]);
-                if (n) atomicAdd(&a.counters[1], (unsigned long long)n);
-            }
-            __syncthreads();
-        }
-    }
-
-    // ---- 6. the single write-back of the tile ----------------------------------------------------
-#pragma unroll
-    for (int q = 0; q < CPT; ++q) {
-        if (owned[q]) {
-            const int c = tid + NT * q;
-            const size_t g = (size_t)(row_base + (c >> TS)) * L + col_base + (c & (TE - 1));
-            a.elevation[g] = ce[q];
-            a.variance[g] = cs[q];
-        }
-    }
-    GEM_STAMP();                                                         // 9: stores issued
-#undef GEM_STAMP
 }
 
 // ------------------------------------------------------------------------------------------
@@ -649,7 +218,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 6 : 4)) void k_fuse(FuseArgs a)
 // phases hide behind other tiles), 32x32 tiles with PB = 4096 ~ 88 KB.
 constexpr int kChunkUnits = 2048;        // descriptor words scanned per block pass
 constexpr int kRankMax    = 7;           // fast path: records per cell and batch
-constexpr int fuse_list_max_batches(int pb) { return kChunkUnits * 256 / (pb - 256) + 2; }
+constexpr int fuse_list_max_batches(int pb) { return kChunkUnits * 64 / (pb - 64) + 2; }
 
 #define GEM_CSWAP(a, b) do { const uint32_t lo_ = min(a, b), hi_ = max(a, b); a = lo_; b = hi_; } while (0)
 
@@ -664,10 +233,10 @@ __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_
     constexpr int UPT = kChunkUnits / NT;            // descriptor words per thread and chunk (4 or 8)
     constexpr int DCAP = PB < kChunkUnits ? PB : kChunkUnits;      // a batch has at most one descriptor per record
     constexpr int MAXB = fuse_list_max_batches(PB);
-    constexpr uint32_t Q = PB - 256;                 // batch b = descriptors whose record prefix lies in [b*Q, (b+1)*Q)
+    constexpr uint32_t Q = PB - 64;                  // batch b = descriptors whose record prefix lies in [b*Q, (b+1)*Q); a descriptor holds <= 64 records
     constexpr uint32_t NIL = 0xffffu;
     constexpr int XBYTES = CELLS * NW * 4 > CELLS * 16 ? CELLS * NW * 4 : CELLS * 16;
-    static_assert(CELLS % NT == 0 && UPT % 4 == 0 && (NW == 4 || NW == 8) && PB >= 512 && PB <= 4096, "geometry");
+    static_assert(CELLS % NT == 0 && (UPT == 4 || UPT == 8) && (NW == 4 || NW == 8) && PB >= 512 && PB <= 4096, "geometry");
 
     // region X: fast path rows[CELLS] of 8 u16 {slot 0..6, count}; generic path head / tail[CELLS][NW]
     uint16_t* rowp    = reinterpret_cast<uint16_t*>(lds_raw);
@@ -690,7 +259,7 @@ __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_
     const int tr = tile / a.tiles_per_row, tc = tile - tr * a.tiles_per_row;
     const int row_base = tr << TS, col_base = tc << TS;
     const int L = a.L;
-    const uint32_t epoch = a.epoch;
+    const uint32_t epoch = a.epoch;                                      // stamps the touched flags of this pass
     const uint64_t lt = lanemask_lt();
     int dbg_k = 0;
 #define GEM_STAMP() do { if (a.dbg && tid == 0 && dbg_k < 16) a.dbg[(size_t)tile * 16 + dbg_k++] = (unsigned long long)__builtin_readcyclecounter(); } while (0)
@@ -703,16 +272,21 @@ __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_
         const int sidx = sbase + lane;
         return __ballot(sidx < a.n_sweeps && flagrow[sidx] == epoch);
     };
-    auto load_row = [&](int sweep, int cbase, uint32_t (&e4)[UPT]) {
+    auto row_ptr = [&](int sweep) -> uint16_t* { return a.seg + ((size_t)sweep * a.T + tile) * a.Bpad; };   // table layout [sweep][tile][unit in sweep]
+    auto load_row = [&](int sweep, int cbase, uint32_t (&e)[UPT]) {
         const int ubx = a.sweep_unit0 ? a.sweep_unit0[sweep] : 0;
         const int Bx = (a.sweep_unit0 ? a.sweep_unit0[sweep + 1] : a.B_total) - ubx;
-        const uint32_t* segx = a.seg + ((size_t)sweep * a.T + tile) * a.Bpad;   // table layout [sweep][tile][unit in sweep]
-        const int u0 = cbase + tid * UPT;
-#pragma unroll
-        for (int x = 0; x < UPT / 4; ++x) {
-            uint4 e = make_uint4(0, 0, 0, 0);
-            if (u0 + 4 * x < Bx) e = *reinterpret_cast<const uint4*>(segx + u0 + 4 * x);         // rows are padded to 4 units
-            e4[4 * x] = e.x; e4[4 * x + 1] = e.y; e4[4 * x + 2] = e.z; e4[4 * x + 3] = e.w;
+        const uint16_t* segx = row_ptr(sweep);
+        const int u0 = cbase + tid * UPT;                                // rows are padded to 8 units (16 B)
+        if constexpr (UPT == 8) {
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (u0 < Bx) q = *reinterpret_cast<const uint4*>(segx + u0);
+            e[0] = q.x & 0xffffu; e[1] = q.x >> 16; e[2] = q.y & 0xffffu; e[3] = q.y >> 16;
+            e[4] = q.z & 0xffffu; e[5] = q.z >> 16; e[6] = q.w & 0xffffu; e[7] = q.w >> 16;
+        } else {
+            uint2 q = make_uint2(0, 0);
+            if (u0 < Bx) q = *reinterpret_cast<const uint2*>(segx + u0);
+            e[0] = q.x & 0xffffu; e[1] = q.x >> 16; e[2] = q.y & 0xffffu; e[3] = q.y >> 16;
         }
     };
     // descriptor words of the first chunk of sweep 0: issued before anything else so that their
@@ -751,6 +325,7 @@ __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_
     }
     GEM_STAMP();                                                         // 1: tile loads issued
 
+    uint32_t tmask = 0;                                                  // cells of this thread touched in this sweep (or pass)
     for (int sweep = 0; sweep < a.n_sweeps; ++sweep) {
         if (sweep != 0 && (sweep & 63) == 0) smask = sweep_mask(sweep);
         const bool touched_sweep = (smask >> (sweep & 63)) & 1ull;       // block-uniform
@@ -768,8 +343,8 @@ __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_
                 for (int k = 0; k < a.n_pending; ++k) if (cs[q] != kInitVariance) cs[q] += a.pending[k];
             if (a.var_updates) { if (cs[q] != kInitVariance) cs[q] += a.var_updates[sweep]; }
         }
-        if (a.counters && tid == 0) misc[0] = 0;
-        uint32_t tmask = 0;                                              // cells of this thread touched in this sweep
+        if (a.counters && tid == 0 && (sweep == 0 || !a.count_per_pass)) misc[0] = 0;
+        if (!a.count_per_pass) tmask = 0;
 
         for (int cbase = 0; touched_sweep && cbase < B; cbase += kChunkUnits) {
             // ---- 1. ordered compaction of the chunk's live descriptors ----------------------------
@@ -788,11 +363,15 @@ __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_
                 }
             }
             uint32_t packed = 0;                                         // live descriptors << 20 | records
+            {
+                uint16_t* rowx = row_ptr(sweep);
 #pragma unroll
-            for (int j = 0; j < UPT; ++j) {
-                const bool live = (ev[j] >> kSegEpochShift) == epoch && u0 + j < B && (ev[j] & kSegCountMask) != 0;
-                if (!live) ev[j] = 0;
-                packed += live ? ((1u << 20) | (ev[j] & kSegCountMask)) : 0u;
+                for (int j = 0; j < UPT; ++j) {
+                    const bool live = ev[j] != 0 && u0 + j < B;
+                    if (live) rowx[u0 + j] = 0;                          // consumed: the table is all-zero again after the pass
+                    else ev[j] = 0;
+                    packed += live ? ((1u << 20) | (ev[j] & kSegCountMask)) : 0u;
+                }
             }
             if (a.dbg) { asm volatile("" :: "v"(packed)); GEM_STAMP(); }                      // 2: descriptor words arrived
             uint32_t tot;
@@ -864,25 +443,17 @@ __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_
                     if (rk < (uint32_t)kRankMax) rowp[cell * 8 + rk] = (uint16_t)sl;
                     else misc[1] = 1u;
                 };
-                auto file = [&](uint32_t dd, const uint4 (&rr)[PF], const uint32_t (&sl)[PF]) {
+                auto file = [&](const uint4 (&rr)[PF], const uint32_t (&sl)[PF]) {
 #pragma unroll
-                    for (int x = 0; x < PF; ++x) {
-                        if (sl[x] != 0xffffffffu) file_one(rr[x], sl[x]);
-                        if (dd + x < dw1) {                              // wave-uniform; units of more than 64 points only
-                            const uint32_t rc = dl_rc[dd + x], cnt = rc & 0x1ffu;
-                            for (uint32_t o = 64; o < cnt; o += 64) {
-                                if (o + (uint32_t)lane < cnt) file_one(a.rec[dl_addr[dd + x] + o + (uint32_t)lane], (rc >> 9) - slot0 + o + (uint32_t)lane);
-                            }
-                        }
-                    }
+                    for (int x = 0; x < PF; ++x) if (sl[x] != 0xffffffffu) file_one(rr[x], sl[x]);
                 };
                 if (dw0 < dw1) {
                     fetch(dw0, rA, sA);
                     for (uint32_t dd = dw0; dd < dw1; dd += 2 * PF) {   // wave-uniform
                         fetch(dd + PF, rB, sB);
-                        file(dd, rA, sA);
+                        file(rA, sA);
                         fetch(dd + 2 * PF, rA, sA);
-                        file(dd + PF, rB, sB);
+                        file(rB, sB);
                     }
                 }
                 __syncthreads();
@@ -1071,7 +642,7 @@ __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_
 #pragma unroll
         for (int q = 0; q < CPT; ++q) if (cs[q] < a.var_floor) cs[q] = a.var_floor;
 
-        if (a.counters) {
+        if (a.counters && (!a.count_per_pass || sweep == a.n_sweeps - 1)) {
             __syncthreads();
             if (tmask) atomicAdd(&misc[0], (uint32_t)__popc(tmask));
             __syncthreads();
@@ -1183,80 +754,17 @@ static hipError_t launch_bin_wave(hipStream_t st, const BinArgs& a, int ts, Laun
     if (ts == 4) {
         if (batch) GEM_LAUNCH((k_bin_wave<SRC, 4, true>), grid, block, 0, st, ev, a);
         else       GEM_LAUNCH((k_bin_wave<SRC, 4, false>), grid, block, 0, st, ev, a);
-    } else if (ts == 5) {
+    } else {
         if (batch) GEM_LAUNCH((k_bin_wave<SRC, 5, true>), grid, block, 0, st, ev, a);
         else       GEM_LAUNCH((k_bin_wave<SRC, 5, false>), grid, block, 0, st, ev, a);
-    } else {
-        if (batch) GEM_LAUNCH((k_bin_wave<SRC, 6, true>), grid, block, 0, st, ev, a);
-        else       GEM_LAUNCH((k_bin_wave<SRC, 6, false>), grid, block, 0, st, ev, a);
     }
     return hipGetLastError();
 }
 
-template <int IPT, int SRC>
-static hipError_t launch_bin_lds(hipStream_t st, const BinArgs& a, int ts, LaunchEvents ev)
-{
-    const size_t lds = (size_t)a.T * sizeof(uint32_t);
-    const bool batch = a.n_sweeps > 1;
-    if (ts == 4) {
-        if (batch) GEM_LAUNCH((k_bin_lds<IPT, SRC, 4, true>), dim3(a.B), dim3(64), lds, st, ev, a);
-        else       GEM_LAUNCH((k_bin_lds<IPT, SRC, 4, false>), dim3(a.B), dim3(64), lds, st, ev, a);
-    } else if (ts == 5) {
-        if (batch) GEM_LAUNCH((k_bin_lds<IPT, SRC, 5, true>), dim3(a.B), dim3(64), lds, st, ev, a);
-        else       GEM_LAUNCH((k_bin_lds<IPT, SRC, 5, false>), dim3(a.B), dim3(64), lds, st, ev, a);
-    } else {
-        if (batch) GEM_LAUNCH((k_bin_lds<IPT, SRC, 6, true>), dim3(a.B), dim3(64), lds, st, ev, a);
-        else       GEM_LAUNCH((k_bin_lds<IPT, SRC, 6, false>), dim3(a.B), dim3(64), lds, st, ev, a);
-    }
-    return hipGetLastError();
-}
-
-hipError_t launch_bin(hipStream_t st, const BinArgs& a, int ipt, int src, int ts, LaunchEvents ev)
+hipError_t launch_bin(hipStream_t st, const BinArgs& a, int src, int ts, LaunchEvents ev)
 {
     if (a.B <= 0) return hipSuccess;
-    if (src == 0) {
-        switch (ipt) {
-        case 1:  return launch_bin_wave<0>(st, a, ts, ev);
-        case 2:  return launch_bin_lds<2, 0>(st, a, ts, ev);
-        default: return launch_bin_lds<4, 0>(st, a, ts, ev);
-        }
-    }
-    switch (ipt) {
-    case 1:  return launch_bin_wave<1>(st, a, ts, ev);
-    case 2:  return launch_bin_lds<2, 1>(st, a, ts, ev);
-    default: return launch_bin_lds<4, 1>(st, a, ts, ev);
-    }
-}
-
-size_t fuse_lds_bytes(int ts, int nt, int r, int bpad, int attr)
-{
-    const size_t cells = (size_t)1 << (2 * ts);
-    const size_t nw = nt / 64, pb = (size_t)nt * r;
-    size_t b = nw * cells * 2           // wc
-             + cells * 2 * 2            // cstart, ccount
-             + pb * 4 * (attr ? 3 : 2)  // s_h, s_v (, s_src)
-             + 16 * 4                   // scratch
-             + cells / 32 * 4;          // touched
-    (void)bpad;
-    return (b + 15) & ~(size_t)15;
-}
-
-template <int TS, int NT, int R>
-static hipError_t launch_fuse_attr(hipStream_t st, const FuseArgs& a, int attr, LaunchEvents ev)
-{
-    const size_t lds = fuse_lds_bytes(TS, NT, R, a.Bpad, attr);
-    // more than 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel
-    static size_t configured[3] = {0, 0, 0};
-    if (lds > 64 * 1024 && lds > configured[attr]) {
-        const void* fn = attr == 0 ? (const void*)k_fuse<TS, NT, R, 0> : attr == 1 ? (const void*)k_fuse<TS, NT, R, 1> : (const void*)k_fuse<TS, NT, R, 2>;
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured[attr] = lds;
-    }
-    if (attr == 0)      GEM_LAUNCH((k_fuse<TS, NT, R, 0>), dim3(a.T), dim3(NT), lds, st, ev, a);
-    else if (attr == 1) GEM_LAUNCH((k_fuse<TS, NT, R, 1>), dim3(a.T), dim3(NT), lds, st, ev, a);
-    else                GEM_LAUNCH((k_fuse<TS, NT, R, 2>), dim3(a.T), dim3(NT), lds, st, ev, a);
-    return hipGetLastError();
+    return src == 0 ? launch_bin_wave<0>(st, a, ts, ev) : launch_bin_wave<1>(st, a, ts, ev);
 }
 
 // ---- k_fuse_list -------------------------------------------------------------------------------------
@@ -1274,13 +782,15 @@ static size_t fuse_list_lds(int cells, int nw, int pb, int attr)
 }
 
 // (tile shift, variant) -> threads per tile and records per LDS batch
+//   16x16 tiles: 256 threads, 1024-record batches (~26 KB of LDS, 4 workgroups per CU)
+//   32x32 tiles: variant 10 = 256 threads / 4096, 11 = 512 / 4096, 12 = 512 / 2048 (2 per CU, the default)
 static void fuse_list_geometry(int ts, int variant, int* nt, int* pb)
 {
     if (ts == 4) { *nt = 256; *pb = 1024; }
-    else         { *nt = variant == 10 ? 256 : 512; *pb = variant == 12 ? 2048 : 4096; }
+    else         { *nt = variant == 10 ? 256 : 512; *pb = (variant == 10 || variant == 11) ? 4096 : 2048; }
 }
 
-size_t fuse_list_lds_bytes(int ts, int variant, int attr)
+size_t fuse_lds_bytes(int ts, int variant, int attr)
 {
     int nt, pb; fuse_list_geometry(ts, variant, &nt, &pb);
     return fuse_list_lds((1 << (2 * ts)), nt / 64, pb, attr);
@@ -1291,7 +801,7 @@ static hipError_t launch_fuse_list(hipStream_t st, const FuseArgs& a, int attr, 
 {
     const size_t lds = fuse_list_lds(1 << (2 * TS), NT / 64, PB, attr);
     static size_t configured[3] = {0, 0, 0};
-    if (lds > 64 * 1024 && lds > configured[attr]) {
+    if (lds > 64 * 1024 && lds > configured[attr]) {   // more than 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel
         const void* fn = attr == 0 ? (const void*)k_fuse_list<TS, NT, PB, 0> : attr == 1 ? (const void*)k_fuse_list<TS, NT, PB, 1> : (const void*)k_fuse_list<TS, NT, PB, 2>;
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1303,32 +813,13 @@ static hipError_t launch_fuse_list(hipStream_t st, const FuseArgs& a, int attr, 
     return hipGetLastError();
 }
 
-// geometry of the fuse kernel for a tile shift: threads per tile and records per thread and batch
-// (variants 0..2: k_fuse, the LDS counting-sort kernel; variants >= 10: k_fuse_list)
-void fuse_geometry(int ts, int variant, int* nt, int* r)
-{
-    if (variant >= 10)  { int pb; fuse_list_geometry(ts, variant, nt, &pb); *r = 0; }
-    else if (ts == 4)   { *nt = 256; *r = 4; }
-    else if (ts == 5)   { if (variant == 1) { *nt = 1024; *r = 4; } else if (variant == 2) { *nt = 256; *r = 8; } else { *nt = 512; *r = 8; } }
-    else                { *nt = 1024; *r = 4; }
-}
-
 hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr, int variant, LaunchEvents ev)
 {
     if (a.T <= 0) return hipSuccess;
-    if (variant >= 10) {
-        if (ts == 4) return launch_fuse_list<4, 256, 1024>(st, a, attr, ev);
-        if (variant == 10) return launch_fuse_list<5, 256, 4096>(st, a, attr, ev);
-        if (variant == 12) return launch_fuse_list<5, 512, 2048>(st, a, attr, ev);
-        return launch_fuse_list<5, 512, 4096>(st, a, attr, ev);
-    }
-    if (ts == 4) return launch_fuse_attr<4, 256, 4>(st, a, attr, ev);
-    if (ts == 5) {
-        if (variant == 1) return launch_fuse_attr<5, 1024, 4>(st, a, attr, ev);
-        if (variant == 2) return launch_fuse_attr<5, 256, 8>(st, a, attr, ev);
-        return launch_fuse_attr<5, 512, 8>(st, a, attr, ev);
-    }
-    return launch_fuse_attr<6, 1024, 4>(st, a, attr, ev);
+    if (ts == 4) return launch_fuse_list<4, 256, 1024>(st, a, attr, ev);
+    if (variant == 10) return launch_fuse_list<5, 256, 4096>(st, a, attr, ev);
+    if (variant == 11) return launch_fuse_list<5, 512, 4096>(st, a, attr, ev);
+    return launch_fuse_list<5, 512, 2048>(st, a, attr, ev);
 }
 
 hipError_t launch_init(hipStream_t st, const LayerPtrs& m, int cells, int clear_lowest)

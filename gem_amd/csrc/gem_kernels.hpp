@@ -7,27 +7,26 @@ namespace gem {
 
 constexpr int kMaxPending = 4;  // queued Mapvar_update increments folded into the next fuse
 
-// (tile, unit) descriptor word:  epoch << 17 | start << 9 | count   (units hold <= 256 records)
-constexpr int      kSegCountBits  = 9;
-constexpr int      kSegStartBits  = 8;
-constexpr int      kSegEpochShift = kSegCountBits + kSegStartBits;
+// (sweep, tile, unit) descriptor word, 16 bits:  start << 7 | count  (a unit holds 64 records; 0 = empty)
+constexpr int      kSegCountBits  = 7;
 constexpr uint32_t kSegCountMask  = (1u << kSegCountBits) - 1u;
-constexpr uint32_t kSegStartMask  = (1u << kSegStartBits) - 1u;
-constexpr uint32_t kSegEpochMax   = (1u << (32 - kSegEpochShift)) - 1u;
+constexpr uint32_t kSegStartMask  = 63u;
+constexpr uint32_t kFlagEpochMax  = 0xfffffff0u;      // touched-flag stamps of a pass; the flag table is cleared when this is reached
 
 struct LayerPtrs {
     float *elevation, *variance, *intensity, *traver, *lowest;
     int   *colorR, *colorG, *colorB;
 };
 
-// A "unit" is 64*IPT consecutive points of one sweep, binned by one wave.  Unit u owns record
-// slots [u*U, (u+1)*U) of the arena and column u of the (tile x unit) descriptor table.
+// A "unit" is 64 consecutive points of one sweep, binned by one wave.  Unit u owns record slots
+// [64 u, 64 (u + 1)) of the arena and one word per tile in its sweep's block of the descriptor table.
 struct BinArgs {
     FrameConst frame0;                 // single-sweep call: the frame, by value (SGPRs)
     // batched call (n_sweeps > 1): per-sweep tables in device memory
     const FrameConst* frames;          // [n_sweeps]
     const int*        sweep_unit0;     // [n_sweeps+1] first unit of each sweep
     const long long*  sweep_first;     // [n_sweeps+1] first point of each sweep in the concatenated cloud
+    const int*        sweep_orig0;     // [n_sweeps] original index of the sweep's first point (a big cloud cut into sweeps), or NULL
     int               n_sweeps;
     long long         n;               // total points
     // input, SRC 0: interleaved XYZI (+ optional packed rgb, original pixel index)
@@ -40,24 +39,24 @@ struct BinArgs {
     // tiling
     int T;                             // number of tiles
     int tile_bits;                     // ceil(log2(T))
-    uint32_t epoch;                    // stamps the descriptor words of this pass
+    uint32_t epoch;                    // stamps the touched flags of this pass
     int tiles_per_row;
     int B;                             // number of units (grid size)
-    int Bpad;                          // units of the longest sweep, multiple of 4: row length of the descriptor table
+    int Bpad;                          // units of the longest sweep, multiple of 8: row length of the descriptor table
     // outputs
     uint4*    rec;                     // [B * U]
-    uint32_t* seg;                     // [n_sweeps][T][Bpad]  descriptor words
+    uint16_t* seg;                     // [n_sweeps][T][Bpad]  descriptor words (all-zero between passes)
     uint32_t* flag;                    // [n_sweeps][T]  == epoch when the sweep put a record into the tile
     unsigned long long* counters;      // optional: [0] += binned points
 };
 
 struct FuseArgs {
     const uint4*    rec;
-    const uint32_t* seg;               // [n_sweeps][T][Bpad]
+    uint16_t* seg;                     // [n_sweeps][T][Bpad]  consumed words are zeroed
     const uint32_t* flag;              // [n_sweeps][T]
     uint32_t epoch;
     int   B_total;                     // all units of the pass
-    int   U;                           // records per unit slot
+    int   U;                           // records per unit slot (64)
     int   n_sweeps;
     const int* sweep_unit0;            // [n_sweeps+1] (NULL when n_sweeps == 1: units [0, B_total))
     int   Bpad;                        // units of the longest sweep: row length of seg
@@ -72,7 +71,8 @@ struct FuseArgs {
     float* intensity; int *colorR, *colorG, *colorB;
     const float4* xyzi; const uint32_t* rgb;
     const int* f_R; const int* f_G; const int* f_B; const float* f_I;
-    unsigned long long* counters;      // optional: [1] += distinct touched cells (per sweep)
+    unsigned long long* counters;      // optional: [1] += distinct touched cells per sweep (per pass when count_per_pass)
+    int   count_per_pass;              // the sweeps are one cloud cut into pieces: count a cell once
     unsigned long long* dbg;           // optional: [T][16] cycle-counter stamps of thread 0 (profiling aid)
 };
 
@@ -80,11 +80,9 @@ hipError_t launch_project(hipStream_t st, const FrameConst& fc, int n, float* x,
                           int write_back, int* map_idx, float* var, float* xt, float* yt, float* zt);
 struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };   // optional dispatch time-stamps
 
-hipError_t launch_bin(hipStream_t st, const BinArgs& a, int ipt, int src, int ts, LaunchEvents ev);
+hipError_t launch_bin(hipStream_t st, const BinArgs& a, int src, int ts, LaunchEvents ev);
 hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr, int variant, LaunchEvents ev);
-void       fuse_geometry(int ts, int variant, int* nt, int* r);
-size_t     fuse_lds_bytes(int ts, int nt, int r, int bpad, int attr);
-size_t     fuse_list_lds_bytes(int ts, int variant, int attr);
+size_t     fuse_lds_bytes(int ts, int variant, int attr);
 hipError_t launch_init(hipStream_t st, const LayerPtrs& m, int cells, int clear_lowest);
 hipError_t launch_clear_strip(hipStream_t st, const LayerPtrs& m, int L, int start, int count, int is_row);
 hipError_t launch_dense_variance(hipStream_t st, float* variance, int cells, int n_pending, const float* pending,
