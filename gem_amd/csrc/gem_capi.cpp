@@ -54,7 +54,7 @@ struct gem_handle {
     // Pipeline intermediates, double-buffered: k_bin of pass p+1 runs on `bin_stream` while k_fuse of
     // pass p runs on `stream` (binning does not depend on the map, only on the cloud and the pose).
     struct PassBuffers {
-        Arena rec, seg, flag;          // records, descriptor table, per-(sweep, tile) touched stamps
+        Arena rec, seg, flag, gflag;   // records, descriptor table, touched stamps per (tile, sweep) and per (sweep, tile, 32 units)
         Arena tables;                  // batched-call tables (frames, sweep_unit0, sweep_first, var_updates)
         hipEvent_t bin_done = nullptr, fuse_done = nullptr;
         bool fuse_recorded = false;
@@ -231,7 +231,7 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     for (int s = 0; s < in.n_sweeps; ++s) {
         const long long cnt = batched ? in.offsets[s + 1] - in.offsets[s] : in.n;
         long long units = (cnt + U - 1) / U;
-        units = (units + 7) & ~7ll;                 // descriptor rows are read 8 units (16 B) at a time
+        units = (units + 31) & ~31ll;               // descriptor rows are flagged in groups of 32 units (64 B)
         if (units > 0x3fffffff) return fail(h, GEM_ERR_INVALID, "cloud too large");
         unit0[s + 1] = unit0[s] + (int)units;
         bpad = std::max(bpad, (int)units);
@@ -286,10 +286,13 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
         }
         // touched flags [tile][sweep]: stamped with the pass's epoch instead of being cleared
         const size_t need_flag = (size_t)T * in.n_sweeps * sizeof(uint32_t);
-        const bool grow_flag = need_flag > pb.flag.cap;
+        const size_t need_gflag = (size_t)in.n_sweeps * T * (bpad / 32) * sizeof(uint32_t);
+        const bool grow_flag = need_flag > pb.flag.cap || need_gflag > pb.gflag.cap;
         if ((rc = ensure(h, pb.flag, need_flag))) return rc;
+        if ((rc = ensure(h, pb.gflag, need_gflag))) return rc;
         if (grow_flag || pb.epoch >= kFlagEpochMax) {
             GEM_HIP(h, hipMemsetAsync(pb.flag.p, 0, pb.flag.cap, sbin));
+            GEM_HIP(h, hipMemsetAsync(pb.gflag.p, 0, pb.gflag.cap, sbin));
             pb.epoch = 0;
         }
         ++pb.epoch;
@@ -331,11 +334,11 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     ba.T = T; ba.tiles_per_row = tiles_per_row; ba.B = B; ba.Bpad = bpad;
     ba.tile_bits = 0; while ((1 << ba.tile_bits) < T) ++ba.tile_bits;
     ba.epoch = pb.epoch;
-    ba.rec = static_cast<uint4*>(pb.rec.p); ba.seg = static_cast<uint16_t*>(pb.seg.p); ba.flag = static_cast<uint32_t*>(pb.flag.p);
+    ba.rec = static_cast<uint4*>(pb.rec.p); ba.seg = static_cast<uint16_t*>(pb.seg.p); ba.flag = static_cast<uint32_t*>(pb.flag.p); ba.gflag = static_cast<uint32_t*>(pb.gflag.p);
     ba.counters = h->counting ? h->d_counters : nullptr;
 
     fa.epoch = pb.epoch;
-    fa.rec = ba.rec; fa.seg = ba.seg; fa.flag = ba.flag; fa.B_total = B; fa.U = U; fa.n_sweeps = in.n_sweeps; fa.Bpad = bpad;
+    fa.rec = ba.rec; fa.seg = ba.seg; fa.flag = ba.flag; fa.gflag = ba.gflag; fa.B_total = B; fa.U = U; fa.n_sweeps = in.n_sweeps; fa.Bpad = bpad;
     fa.T = T; fa.tiles_per_row = tiles_per_row; fa.L = h->L; fa.row0 = h->row0; fa.row1 = h->row1;
     fa.mahal = h->cfg.mahalanobis_threshold; fa.var_floor = h->cfg.variance_floor;
     fa.dense = dense ? 1 : 0;
@@ -451,7 +454,7 @@ void gem_destroy(gem_handle* h)
     if (h->d_counters) hipFree(h->d_counters);
     for (Arena* a : {&h->stage, &h->scratch, &h->dbg}) if (a->p) hipFree(a->p);
     for (auto& b : h->pb) {
-        for (Arena* a : {&b.rec, &b.seg, &b.flag, &b.tables}) if (a->p) hipFree(a->p);
+        for (Arena* a : {&b.rec, &b.seg, &b.flag, &b.gflag, &b.tables}) if (a->p) hipFree(a->p);
         if (b.bin_done) hipEventDestroy(b.bin_done);
         if (b.fuse_done) hipEventDestroy(b.fuse_done);
     }

@@ -188,6 +188,7 @@ __global__ __launch_bounds__(256) void k_bin_wave(BinArgs a)
         // table layout [sweep][tile][unit in sweep]: the words one sweep writes stay within T * Bpad * 4 bytes
         a.seg[((size_t)sweep * a.T + tile) * a.Bpad + (unit - unit_first)] = (uint16_t)((start << kSegCountBits) | cnt);
         a.flag[(size_t)tile * a.n_sweeps + sweep] = a.epoch;       // "tile touched in this sweep" (same value from every writer)
+        a.gflag[((size_t)sweep * a.T + tile) * (a.Bpad >> 5) + ((unit - unit_first) >> 5)] = a.epoch;   // "... by this group of 32 units"
     }
 
     if (a.counters) {
@@ -273,27 +274,35 @@ __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_
         return __ballot(sidx < a.n_sweeps && flagrow[sidx] == epoch);
     };
     auto row_ptr = [&](int sweep) -> uint16_t* { return a.seg + ((size_t)sweep * a.T + tile) * a.Bpad; };   // table layout [sweep][tile][unit in sweep]
-    auto load_row = [&](int sweep, int cbase, uint32_t (&e)[UPT]) {
+    // A row is only read where k_bin stamped the group of 32 units (64 bytes of descriptor words) as live for
+    // this tile: gflag[sweep][tile][group] == epoch.  A LiDAR ring crosses a tile in a few groups, so this cuts
+    // the row traffic by an order of magnitude at the price of one small dependent load.
+    auto load_gflag = [&](int sweep, int cbase) -> uint32_t {
+        const int g = (cbase + tid * UPT) >> 5;
+        return g < (a.Bpad >> 5) ? a.gflag[((size_t)sweep * a.T + tile) * (a.Bpad >> 5) + g] : 0u;
+    };
+    auto load_row = [&](int sweep, int cbase, uint32_t gf, uint32_t (&e)[UPT]) {
         const int ubx = a.sweep_unit0 ? a.sweep_unit0[sweep] : 0;
         const int Bx = (a.sweep_unit0 ? a.sweep_unit0[sweep + 1] : a.B_total) - ubx;
         const uint16_t* segx = row_ptr(sweep);
-        const int u0 = cbase + tid * UPT;                                // rows are padded to 8 units (16 B)
+        const int u0 = cbase + tid * UPT;                                // rows are padded to 32 units
+        const bool on = gf == epoch && u0 < Bx;
         if constexpr (UPT == 8) {
             uint4 q = make_uint4(0, 0, 0, 0);
-            if (u0 < Bx) q = *reinterpret_cast<const uint4*>(segx + u0);
+            if (on) q = *reinterpret_cast<const uint4*>(segx + u0);
             e[0] = q.x & 0xffffu; e[1] = q.x >> 16; e[2] = q.y & 0xffffu; e[3] = q.y >> 16;
             e[4] = q.z & 0xffffu; e[5] = q.z >> 16; e[6] = q.w & 0xffffu; e[7] = q.w >> 16;
         } else {
             uint2 q = make_uint2(0, 0);
-            if (u0 < Bx) q = *reinterpret_cast<const uint2*>(segx + u0);
+            if (on) q = *reinterpret_cast<const uint2*>(segx + u0);
             e[0] = q.x & 0xffffu; e[1] = q.x >> 16; e[2] = q.y & 0xffffu; e[3] = q.y >> 16;
         }
     };
-    // descriptor words of the first chunk of sweep 0: issued before anything else so that their
-    // latency overlaps the flag test and the tile read
+    // group flags of the first chunk of sweep 0: issued before anything else so that their latency
+    // overlaps the sweep-mask test and the tile read
     uint32_t ev[UPT], evn[UPT];
-    load_row(0, 0, ev);
-    int prefetched = 0;                                                  // sweep whose first chunk sits in ev (sweep 0) / evn
+    uint32_t gf0 = load_gflag(0, 0), gfn = 0;
+    int prefetched = -1;                                                 // sweep whose first chunk sits in evn
 
     // ---- the single read of the tile (issued before the flag test: one memory latency, not two) ----
     float ce[CPT], cs[CPT];
@@ -349,18 +358,16 @@ __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_
         for (int cbase = 0; touched_sweep && cbase < B; cbase += kChunkUnits) {
             // ---- 1. ordered compaction of the chunk's live descriptors ----------------------------
             const int u0 = cbase + tid * UPT;
-            if (cbase == 0 && sweep != 0 && prefetched == sweep) {
+            int next_sweep = -1;
+            if (cbase == 0 && prefetched == sweep) {
 #pragma unroll
                 for (int j = 0; j < UPT; ++j) ev[j] = evn[j];
-            } else if (sweep != 0 || cbase != 0) {
-                load_row(sweep, cbase, ev);
+            } else {
+                load_row(sweep, cbase, (sweep == 0 && cbase == 0) ? gf0 : load_gflag(sweep, cbase), ev);
             }
-            if (cbase == 0) {                                            // next touched sweep of this 64-block: its row starts flying now
-                const uint64_t later = (sweep & 63) == 63 ? 0ull : (smask >> ((sweep & 63) + 1));
-                if (later != 0) {
-                    prefetched = sweep + 1 + (__ffsll((unsigned long long)later) - 1);
-                    load_row(prefetched, 0, evn);
-                }
+            if (cbase == 0) {                                            // next touched sweep of this 64-block: its group flags start flying now,
+                const uint64_t later = (sweep & 63) == 63 ? 0ull : (smask >> ((sweep & 63) + 1));   // its row after the scan below
+                if (later != 0) { next_sweep = sweep + 1 + (__ffsll((unsigned long long)later) - 1); gfn = load_gflag(next_sweep, 0); }
             }
             uint32_t packed = 0;                                         // live descriptors << 20 | records
             {
@@ -377,6 +384,7 @@ __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_
             uint32_t tot;
             const uint32_t run = block_exclusive_scan<NT>(packed, scratch, &tot);
             const uint32_t nd = tot >> 20, P = tot & 0xfffffu;
+            if (next_sweep >= 0) { load_row(next_sweep, 0, gfn, evn); prefetched = next_sweep; }
             if (P == 0) continue;                                        // block-uniform
             const uint32_t nb = (P - 1u) / Q + 1u;                       // batches 0 .. nb-2 are non-empty (a descriptor holds < Q records)
             if (nb > 1) {

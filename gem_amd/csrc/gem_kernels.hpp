@@ -42,18 +42,20 @@ struct BinArgs {
     uint32_t epoch;                    // stamps the touched flags of this pass
     int tiles_per_row;
     int B;                             // number of units (grid size)
-    int Bpad;                          // units of the longest sweep, multiple of 8: row length of the descriptor table
+    int Bpad;                          // units of the longest sweep, multiple of 32: row length of the descriptor table
     // outputs
     uint4*    rec;                     // [B * U]
     uint16_t* seg;                     // [n_sweeps][T][Bpad]  descriptor words (all-zero between passes)
-    uint32_t* flag;                    // [n_sweeps][T]  == epoch when the sweep put a record into the tile
+    uint32_t* flag;                    // [T][n_sweeps]  == epoch when the sweep put a record into the tile
+    uint32_t* gflag;                   // [n_sweeps][T][Bpad/32]  == epoch when that group of 32 units did
     unsigned long long* counters;      // optional: [0] += binned points
 };
 
 struct FuseArgs {
     const uint4*    rec;
     uint16_t* seg;                     // [n_sweeps][T][Bpad]  consumed words are zeroed
-    const uint32_t* flag;              // [n_sweeps][T]
+    const uint32_t* flag;              // [T][n_sweeps]
+    const uint32_t* gflag;             // [n_sweeps][T][Bpad/32]
     uint32_t epoch;
     int   B_total;                     // all units of the pass
     int   U;                           // records per unit slot (64)
