@@ -10,9 +10,9 @@ Steps cycle through 8 distinct seeded sweeps (moving sensor), so after the first
 populated and the Kalman / Mahalanobis branches are the ones exercised.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling by spatial tiling --
-each step fuses N sweeps (N x 131 072 points); rank r owns storage-row strip r of the map, bins all
-N sweeps, fuses only its strip, and the strips are exchanged with an RCCL all-gather (xGMI) through
-the C ABI (gem_allgather_layers) every step.
+each step fuses N sweeps (N x 131 072 points) in one batched call; rank r owns storage-row strip r of
+the map, bins all N sweeps, fuses only its strip, and the strips are exchanged with an RCCL all-gather
+(xGMI) through the C ABI (gem_allgather_layers) every step.
 
 Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel (HIP-event timed on the
 stream it runs on, in a second timed loop), `cpu_baseline` the CPU oracle on this box's host cores.
@@ -121,7 +121,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or bool(os.environ.get("GEM_BENCH_FORCE_DIST"))      # the env var exercises the N > 1 code path with one rank
     if args.gpus != world and distributed:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
@@ -141,13 +141,27 @@ def main():
         emap.comm_init(uid[0], world, rank)
 
     sweeps_per_step = world
+    if distributed:
+        # the N sweeps of a step go through ONE batched call (gem_add_batch_device, no variance increments):
+        # two launches per step instead of 2 N.  The 8 distinct sweeps are cycled, so there are at most 8
+        # distinct concatenations.
+        cat, offs, frs = {}, {}, {}
+        for i0 in range(N_DISTINCT):
+            ks = [(i0 * sweeps_per_step + j) % N_DISTINCT for j in range(sweeps_per_step)]
+            key = tuple(ks)
+            if key not in cat:
+                cat[key] = torch.cat([d_clouds[k] for k in ks], 0).contiguous()
+                offs[key] = np.concatenate([[0], np.cumsum([d_clouds[k].shape[0] for k in ks])])
+                frs[key] = [wl.frames[k] for k in ks]
 
     def step(i: int):
-        for j in range(sweeps_per_step):
-            k = (i * sweeps_per_step + j) % N_DISTINCT
-            emap.add(wl.frames[k], d_clouds[k])
         if distributed:
+            key = tuple((i * sweeps_per_step + j) % N_DISTINCT for j in range(sweeps_per_step))
+            emap.add_batch(frs[key], cat[key], offs[key], None)
             emap.allgather_layers(False)
+            return
+        k = i % N_DISTINCT
+        emap.add(wl.frames[k], d_clouds[k])
 
     def barrier():
         if distributed:
