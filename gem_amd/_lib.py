@@ -14,7 +14,7 @@ GEM_OK = 0
 
 # layers / layouts / models (include/gem_hip.h)
 LAYER_ELEVATION, LAYER_VARIANCE, LAYER_INTENSITY, LAYER_TRAVER, LAYER_LOWEST, \
-    LAYER_COLOR_R, LAYER_COLOR_G, LAYER_COLOR_B = range(8)
+    LAYER_COLOR_R, LAYER_COLOR_G, LAYER_COLOR_B, LAYER_ROUGH, LAYER_SLOPE = range(10)
 LAYOUT_STORAGE_ROWMAJOR, LAYOUT_GRIDMAP_COLMAJOR_NAN = 0, 1
 MODEL_LASER, MODEL_STRUCTURED_LIGHT, MODEL_STEREO, MODEL_PERFECT = range(4)
 
@@ -61,6 +61,7 @@ SIGNATURES = {
     "gem_get_layer": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "gem_set_layer": (c_int, [c_void_p, c_int, c_void_p]),
     "gem_layer_device_ptr": (c_int, [c_void_p, c_int, POINTER(c_void_p)]),
+    "gem_map_feature": (c_int, [c_void_p] + [c_void_p] * 9),
     "gem_set_timing": (c_int, [c_void_p, c_int]),
     "gem_set_counting": (c_int, [c_void_p, c_int]),
     "gem_get_stats": (c_int, [c_void_p, POINTER(Stats), c_int]),

@@ -27,6 +27,7 @@ LAYER_BY_NAME = {
     "elevation": _lib.LAYER_ELEVATION, "variance": _lib.LAYER_VARIANCE, "intensity": _lib.LAYER_INTENSITY,
     "traver": _lib.LAYER_TRAVER, "lowest_scan_point": _lib.LAYER_LOWEST,
     "color_r": _lib.LAYER_COLOR_R, "color_g": _lib.LAYER_COLOR_G, "color_b": _lib.LAYER_COLOR_B,
+    "rough": _lib.LAYER_ROUGH, "slope": _lib.LAYER_SLOPE,
 }
 _INT_LAYERS = {_lib.LAYER_COLOR_R, _lib.LAYER_COLOR_G, _lib.LAYER_COLOR_B}
 
@@ -316,6 +317,20 @@ class ElevationMap:
     # -- Mapvar_update (RMU.cpp:81) ------------------------------------------------------------------
     def mapvar_update(self, var_update: float) -> None:
         self._check(self._lib.gem_mapvar_update(self._h, float(var_update)), "gem_mapvar_update")
+
+    # -- Map_feature (EMg.cpp:410): traversability stage on the fused map --------------------------------------
+    def map_feature(self, fetch: bool = True):
+        """Computes the rough / slope / traver layers on the device (gem_map_feature).  With fetch=True returns
+        dict(rough, slope, traver) as host arrays; with fetch=False it only enqueues the kernel."""
+        L = self.length
+        if not fetch:
+            self._check(self._lib.gem_map_feature(self._h, *([None] * 9)), "gem_map_feature")
+            return None
+        out = {k: np.empty((L, L), np.float32) for k in ("rough", "slope", "traver")}
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._check(self._lib.gem_map_feature(self._h, None, None, None, None, None, p(out["rough"]), p(out["slope"]),
+                                              p(out["traver"]), None), "gem_map_feature")
+        return out
 
     # -- layers ----------------------------------------------------------------------------------------
     def layer(self, name_or_id, layout: int = _lib.LAYOUT_STORAGE_ROWMAJOR) -> np.ndarray:

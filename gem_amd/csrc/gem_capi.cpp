@@ -433,6 +433,8 @@ int gem_create(const gem_map_config* cfg, gem_handle** out)
     h->layers.colorR    = reinterpret_cast<int*>(b + layer_bytes * GEM_LAYER_COLOR_R);
     h->layers.colorG    = reinterpret_cast<int*>(b + layer_bytes * GEM_LAYER_COLOR_G);
     h->layers.colorB    = reinterpret_cast<int*>(b + layer_bytes * GEM_LAYER_COLOR_B);
+    h->layers.rough     = reinterpret_cast<float*>(b + layer_bytes * GEM_LAYER_ROUGH);
+    h->layers.slope     = reinterpret_cast<float*>(b + layer_bytes * GEM_LAYER_SLOPE);
     if ((e = hipMalloc(reinterpret_cast<void**>(&h->d_counters), 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc(counters)", e);
     if ((e = launch_init(h->stream, h->layers, h->cells, 1)) != hipSuccess) return bail("k_init", e);   // G_Init_map
     if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return bail("hipStreamSynchronize", e);
@@ -689,6 +691,8 @@ static void* layer_ptr(gem_handle* h, int layer)
     case GEM_LAYER_COLOR_R:   return h->layers.colorR;
     case GEM_LAYER_COLOR_G:   return h->layers.colorG;
     case GEM_LAYER_COLOR_B:   return h->layers.colorB;
+    case GEM_LAYER_ROUGH:     return h->layers.rough;
+    case GEM_LAYER_SLOPE:     return h->layers.slope;
     default: return nullptr;
     }
 }
@@ -707,7 +711,7 @@ int gem_get_layer(gem_handle* h, int layer, int layout, void* dst_host)
         GEM_HIP(h, hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, h->stream));
     } else if (layout == GEM_LAYOUT_GRIDMAP_COLMAJOR_NAN) {
         if ((rc = ensure(h, h->scratch, bytes))) return rc;
-        const int is_int = layer >= GEM_LAYER_COLOR_R;
+        const int is_int = layer >= GEM_LAYER_COLOR_R && layer <= GEM_LAYER_COLOR_B;
         GEM_HIP(h, launch_export_gridmap(h->stream, src, h->layers.elevation, static_cast<float*>(h->scratch.p), h->L, is_int));
         GEM_HIP(h, hipMemcpyAsync(dst_host, h->scratch.p, bytes, hipMemcpyDeviceToHost, h->stream));
     } else {
@@ -738,6 +742,30 @@ int gem_layer_device_ptr(gem_handle* h, int layer, void** out_device_ptr)
     std::lock_guard<std::mutex> lk(h->mu);
     *out_device_ptr = layer_ptr(h, layer);
     return *out_device_ptr ? GEM_OK : fail(h, GEM_ERR_INVALID, "gem_layer_device_ptr: bad layer");
+}
+
+// Map_feature (gpu_process.cu:1256-1302): the reference mallocs nine device arrays, runs G_Mapfeature and
+// copies all nine back every frame; here the kernel writes three resident layers and only the arrays
+// the caller asks for are copied.
+int gem_map_feature(gem_handle* h, float* elevation, float* variance, int* colorR, int* colorG, int* colorB,
+                    float* rough, float* slope, float* traver, float* intensity)
+{
+    if (!h) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    int rc = flush_pending(h, false);
+    if (rc) return rc;
+    GEM_HIP(h, launch_map_feature(h->stream, h->layers.elevation, h->layers.traver, h->layers.rough, h->layers.slope,
+                                  h->L, h->res, h->start[0], h->start[1], h->row0, h->row1));
+    const size_t bytes = (size_t)h->cells * 4;
+    struct { void* dst; const void* src; } out[9] = {
+        {elevation, h->layers.elevation}, {variance, h->layers.variance}, {colorR, h->layers.colorR}, {colorG, h->layers.colorG},
+        {colorB, h->layers.colorB}, {rough, h->layers.rough}, {slope, h->layers.slope}, {traver, h->layers.traver},
+        {intensity, h->layers.intensity}};
+    bool any = false;
+    for (auto& o : out) if (o.dst) { GEM_HIP(h, hipMemcpyAsync(o.dst, o.src, bytes, hipMemcpyDeviceToHost, h->stream)); any = true; }
+    if (any) GEM_HIP(h, hipStreamSynchronize(h->stream));
+    return GEM_OK;
 }
 
 int gem_set_timing(gem_handle* h, int enabled)

@@ -681,7 +681,7 @@ __global__ __launch_bounds__(256) void k_init(LayerPtrs m, int cells, int clear_
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += gridDim.x * blockDim.x) {
         m.intensity[i] = 0.0f; m.elevation[i] = kEmptyElevation; m.variance[i] = kInitVariance;
-        m.traver[i] = -10.0f;
+        m.traver[i] = -10.0f; m.rough[i] = 0.0f; m.slope[i] = 0.0f;
         if (clear_lowest) m.lowest[i] = 100.0f;
         m.colorR[i] = 0; m.colorG[i] = 0; m.colorB[i] = 0;
     }
@@ -725,6 +725,122 @@ __global__ __launch_bounds__(256) void k_export_gridmap(const void* __restrict__
         if (elevation[g] == kEmptyElevation) v = __builtin_nanf("");
         dst[i] = v;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_map_feature : traversability stage that follows the fusion every frame (G_Mapfeature,
+// GPU:549-670, with the Jacobi eigen-solver computerEigenvalue, GPU:66-187).  One thread per cell:
+// plane fit over the valid cells of the 5x5 neighbourhood (bounds in unrolled coordinates, wrapped
+// storage reads -- and, like the reference, STORAGE coordinates times the resolution as x / y), smallest
+// eigenvector -> slope, |h - mean z| -> roughness, traver = 0.5 (1 - slope/0.6) + 0.5 (1 - rough/0.2).
+// The neighbourhood is walked twice (means, then covariance) instead of staging 25 points per thread;
+// both walks add in the reference's order.  The symmetric 3x3 matrix lives in six scalars: of the
+// reference's six off-diagonal candidates only (0,1), (0,2), (1,2) can win its strict-greater scan.
+// Trigonometry: the reference's float calls are evaluated in double and rounded (see oracle/ and DESIGN.md).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float f_sin(float x)            { return (float)sin((double)x); }
+__device__ __forceinline__ float f_cos(float x)            { return (float)cos((double)x); }
+__device__ __forceinline__ float f_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
+__device__ __forceinline__ float f_acos(float x)           { return (float)acos((double)x); }
+
+__global__ __launch_bounds__(256) void k_map_feature(const float* __restrict__ elevation, float* __restrict__ traver,
+                                                     float* __restrict__ rough, float* __restrict__ slope,
+                                                     int L, float res, int sx, int sy, int row0, int row1)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= L * L) return;
+    const int cell_x = idx / L, cell_y = idx - cell_x * L;
+    if (cell_x < row0 || cell_x >= row1) return;                       // multi-GPU: only the owned strip
+    const float height = elevation[idx];
+    float r_out = 0.0f, s_out = 0.0f;
+    if (height != kEmptyElevation) {                                    // GPU:581
+        int gx = cell_x + L - sx; if (gx >= L) gx -= L;                 // unrolled index of the cell, GPU:587-588
+        int gy = cell_y + L - sy; if (gy >= L) gy -= L;
+        float mx = 0.0f, my = 0.0f, mz = 0.0f;
+        int n = 0;
+#pragma unroll
+        for (int i = -2; i < 3; ++i)
+#pragma unroll
+            for (int j = -2; j < 3; ++j) {
+                const int ex = gx + i, ey = gy + j;
+                if (ex >= 0 && ex < L && ey >= 0 && ey < L) {
+                    int px = cell_x + i; px = px < 0 ? px + L : (px >= L ? px - L : px);     // GPU:596-600
+                    int py = cell_y + j; py = py < 0 ? py + L : (py >= L ? py - L : py);
+                    const float z = elevation[px * L + py];
+                    if (z != kEmptyElevation) { mx = mx + (float)px * res; my = my + (float)py * res; mz = mz + z; ++n; }
+                }
+            }
+        float tr = -10.0f;                                              // GPU:660-666
+        if (n > 7) {
+            mx = mx / (float)n; my = my / (float)n; mz = mz / (float)n;
+            float a00 = 0.f, a11 = 0.f, a22 = 0.f, a01 = 0.f, a02 = 0.f, a12 = 0.f;
+#pragma unroll
+            for (int i = -2; i < 3; ++i)
+#pragma unroll
+                for (int j = -2; j < 3; ++j) {
+                    const int ex = gx + i, ey = gy + j;
+                    if (ex >= 0 && ex < L && ey >= 0 && ey < L) {
+                        int px = cell_x + i; px = px < 0 ? px + L : (px >= L ? px - L : px);
+                        int py = cell_y + j; py = py < 0 ? py + L : (py >= L ? py - L : py);
+                        const float z = elevation[px * L + py];
+                        if (z != kEmptyElevation) {                     // GPU:624-635
+                            const float dx = (float)px * res - mx, dy = (float)py * res - my, dz = z - mz;
+                            a00 = a00 + dx * dx; a11 = a11 + dy * dy; a22 = a22 + dz * dz;
+                            a01 = a01 + dx * dy; a02 = a02 + dx * dz; a12 = a12 + dy * dz;
+                        }
+                    }
+                }
+            // ---- computerEigenvalue (GPU:66-187), dbEps = 0.01, nJt = 30 ----
+            float v00 = 1.f, v01 = 0.f, v02 = 0.f, v10 = 0.f, v11 = 1.f, v12 = 0.f, v20 = 0.f, v21 = 0.f, v22 = 1.f;
+            int count = 0;
+            while (true) {
+                float mxv = a01; int pair = 0;                          // GPU:85-100 (signed start value, strict >)
+                { const float d = fabsf(a01); if (d > mxv) { mxv = d; pair = 0; } }
+                { const float d = fabsf(a02); if (d > mxv) { mxv = d; pair = 1; } }
+                { const float d = fabsf(a12); if (d > mxv) { mxv = d; pair = 2; } }
+                if (mxv < 0.01f) break;
+                if (count > 30) break;
+                ++count;
+                // (p, q, r): pair 0 -> (0,1,2), 1 -> (0,2,1), 2 -> (1,2,0)
+                float app, aqq, apq, arp, arq;
+                if (pair == 0)      { app = a00; aqq = a11; apq = a01; arp = a02; arq = a12; }
+                else if (pair == 1) { app = a00; aqq = a22; apq = a02; arp = a01; arq = a12; }
+                else                { app = a11; aqq = a22; apq = a12; arp = a01; arq = a02; }
+                const float ang = (float)(0.5 * (double)f_atan2(-2 * apq, aqq - app));             // GPU:116
+                const float sn = f_sin(ang), cs = f_cos(ang), sn2 = f_sin(2 * ang), cs2 = f_cos(2 * ang);
+                const float npp = app * cs * cs + aqq * sn * sn + 2 * apq * cs * sn;                // GPU:122-123
+                const float nqq = app * sn * sn + aqq * cs * cs - 2 * apq * cs * sn;                // GPU:124-125
+                const float npq = (float)(0.5 * (double)(aqq - app) * (double)sn2 + (double)(apq * cs2));   // GPU:126
+                const float nrp = arq * sn + arp * cs;                                               // GPU:129-151
+                const float nrq = arq * cs - arp * sn;
+                if (pair == 0)      { a00 = npp; a11 = nqq; a01 = npq; a02 = nrp; a12 = nrq; }
+                else if (pair == 1) { a00 = npp; a22 = nqq; a02 = npq; a01 = nrp; a12 = nrq; }
+                else                { a11 = npp; a22 = nqq; a12 = npq; a01 = nrp; a02 = nrq; }
+                // eigenvector columns p, q (GPU:154-161)
+                float u0, u1, u2, w0, w1, w2;
+                if (pair == 0)      { u0 = v00; u1 = v10; u2 = v20; w0 = v01; w1 = v11; w2 = v21; }
+                else if (pair == 1) { u0 = v00; u1 = v10; u2 = v20; w0 = v02; w1 = v12; w2 = v22; }
+                else                { u0 = v01; u1 = v11; u2 = v21; w0 = v02; w1 = v12; w2 = v22; }
+                const float nu0 = w0 * sn + u0 * cs, nw0 = w0 * cs - u0 * sn;
+                const float nu1 = w1 * sn + u1 * cs, nw1 = w1 * cs - u1 * sn;
+                const float nu2 = w2 * sn + u2 * cs, nw2 = w2 * cs - u2 * sn;
+                if (pair == 0)      { v00 = nu0; v10 = nu1; v20 = nu2; v01 = nw0; v11 = nw1; v21 = nw2; }
+                else if (pair == 1) { v00 = nu0; v10 = nu1; v20 = nu2; v02 = nw0; v12 = nw1; v22 = nw2; }
+                else                { v01 = nu0; v11 = nu1; v21 = nu2; v02 = nw0; v12 = nw1; v22 = nw2; }
+            }
+            // z component of the eigenvector of the smallest eigenvalue (first minimum wins, GPU:168-186)
+            float mn = a00, nz = v20;
+            if (mn > a11) { mn = a11; nz = v21; }
+            if (mn > a22) { mn = a22; nz = v22; }
+            const float Slope = nz > 0 ? f_acos(nz) : f_acos(-nz);     // GPU:647-650
+            const float Rough = fabsf(height - mz);
+            tr = (float)(0.5 * (1.0 - (double)Slope / 0.6) + 0.5 * (1.0 - ((double)Rough / 0.2)));   // GPU:653
+            s_out = Slope; r_out = Rough;
+        }
+        traver[idx] = tr;                                               // map_traver, GPU:658 / 665
+    }
+    rough[idx] = r_out;
+    slope[idx] = s_out;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -850,6 +966,13 @@ hipError_t launch_dense_variance(hipStream_t st, float* variance, int cells, int
     for (int i = 0; i < n_pending && i < 4; ++i) p[i] = pending[i];
     hipLaunchKernelGGL(k_dense_variance, dim3(grid_for(cells, 256)), dim3(256), 0, st, variance, cells, n_pending,
                        p[0], p[1], p[2], p[3], apply_floor, var_floor);
+    return hipGetLastError();
+}
+
+hipError_t launch_map_feature(hipStream_t st, const float* elevation, float* traver, float* rough, float* slope,
+                              int L, float res, int sx, int sy, int row0, int row1)
+{
+    hipLaunchKernelGGL(k_map_feature, dim3((L * L + 255) / 256), dim3(256), 0, st, elevation, traver, rough, slope, L, res, sx, sy, row0, row1);
     return hipGetLastError();
 }
 

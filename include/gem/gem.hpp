@@ -220,18 +220,23 @@ public:
     // Mapvar_update(length, var_update)  (RobotMotionMapUpdater.cpp:81)
     void update(float varianceUpdate) { check(gem_mapvar_update(h_, varianceUpdate), "gem_mapvar_update"); }
 
+    // Map_feature(...) (ElevationMapping.cpp:410): traversability stage on the fused map; computes the ROUGH, SLOPE and
+    // TRAVER layers on the device and copies out the arrays that are not null (flat storage order, length^2 floats)
+    void mapFeature(float* rough = nullptr, float* slope = nullptr, float* traver = nullptr)
+    { check(gem_map_feature(h_, nullptr, nullptr, nullptr, nullptr, nullptr, rough, slope, traver, nullptr), "gem_map_feature"); }
+
     // flat [storage_x * length + storage_y] array, the layout ElevationMap::show indexes (ElevationMap.cpp:98-111)
     std::vector<float> layer(int which) const
     {
         std::vector<float> v(static_cast<size_t>(length_) * length_);
-        if (which >= GEM_LAYER_COLOR_R) throw Error(GEM_ERR_INVALID, "colour layers are int32: use colorLayer()");
+        if (which >= GEM_LAYER_COLOR_R && which <= GEM_LAYER_COLOR_B) throw Error(GEM_ERR_INVALID, "colour layers are int32: use colorLayer()");
         check(gem_get_layer(h_, which, GEM_LAYOUT_STORAGE_ROWMAJOR, v.data()), "gem_get_layer");
         return v;
     }
     std::vector<int> colorLayer(int which) const
     {
         std::vector<int> v(static_cast<size_t>(length_) * length_);
-        if (which < GEM_LAYER_COLOR_R) throw Error(GEM_ERR_INVALID, "not a colour layer");
+        if (which < GEM_LAYER_COLOR_R || which > GEM_LAYER_COLOR_B) throw Error(GEM_ERR_INVALID, "not a colour layer");
         check(gem_get_layer(h_, which, GEM_LAYOUT_STORAGE_ROWMAJOR, v.data()), "gem_get_layer");
         return v;
     }

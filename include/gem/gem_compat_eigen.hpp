@@ -12,9 +12,9 @@
 // (by-value Matrix4f / Matrix3f / RowVector3f arguments), which exists in the ROS workspace but not in
 // this repository's build container -- tests/cpp compiles it against a minimal stand-in.
 //
-// Hot-path symbols are complete.  Map_feature / Raytracing / Map_optmove / Map_closeloop belong to the
-// post-processing stages that are outside the hot path (SURVEY.md 8f "next" rows); they are provided so the
-// node links, with the behaviour documented on each.
+// Hot-path symbols and Map_feature (the traversability stage) are complete.  Raytracing /
+// Map_optmove / Map_closeloop belong to later post-processing stages; they are provided so
+// the node links, with the behaviour documented on each.
 #pragma once
 
 #include <Eigen/Core>
@@ -104,21 +104,14 @@ void Mapvar_update(int length, float var_update)
     gem_compat::report(gem_mapvar_update(gem_compat::handle(), var_update), "Mapvar_update");
 }
 
-// gpu_process.cu:1256-1302 -- traversability stage, OUTSIDE the hot path.  Copies the fused
-// layers out exactly as the reference does (9 D2H copies, gpu_process.cu:1283-1291); rough / slope / traver
-// are not computed here and are returned as -10 ("no information", the value G_Init_map gives map_traver).
+// gpu_process.cu:1256-1302 -- traversability stage (G_Mapfeature + the Jacobi eigen-solver run on the device,
+// k_map_feature), then the nine layers are copied out as the reference does (gpu_process.cu:1283-1291).
 void Map_feature(int length, float* elevation, float* var, int* colorR, int* colorG, int* colorB,
                  float* rough, float* slope, float* traver, float* intensity)
 {
-    gem_handle* h = gem_compat::handle();
-    gem_compat::report(gem_get_layer(h, GEM_LAYER_ELEVATION, GEM_LAYOUT_STORAGE_ROWMAJOR, elevation), "Map_feature");
-    gem_compat::report(gem_get_layer(h, GEM_LAYER_VARIANCE, GEM_LAYOUT_STORAGE_ROWMAJOR, var), "Map_feature");
-    gem_compat::report(gem_get_layer(h, GEM_LAYER_COLOR_R, GEM_LAYOUT_STORAGE_ROWMAJOR, colorR), "Map_feature");
-    gem_compat::report(gem_get_layer(h, GEM_LAYER_COLOR_G, GEM_LAYOUT_STORAGE_ROWMAJOR, colorG), "Map_feature");
-    gem_compat::report(gem_get_layer(h, GEM_LAYER_COLOR_B, GEM_LAYOUT_STORAGE_ROWMAJOR, colorB), "Map_feature");
-    gem_compat::report(gem_get_layer(h, GEM_LAYER_INTENSITY, GEM_LAYOUT_STORAGE_ROWMAJOR, intensity), "Map_feature");
-    const size_t n = static_cast<size_t>(length) * length;
-    for (size_t i = 0; i < n; ++i) { rough[i] = -10.0f; slope[i] = -10.0f; traver[i] = -10.0f; }
+    (void)length;
+    gem_compat::report(gem_map_feature(gem_compat::handle(), elevation, var, colorR, colorG, colorB, rough, slope, traver, intensity),
+                       "Map_feature");
 }
 
 // gpu_process.cu:1304-1318 -- visibility clean-up, outside the hot path: no-op.

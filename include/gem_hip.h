@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GEM_ABI_VERSION 1
+#define GEM_ABI_VERSION 2
 
 typedef enum gem_status {
     GEM_OK = 0,
@@ -46,7 +46,8 @@ enum { GEM_MODEL_LASER = 0, GEM_MODEL_STRUCTURED_LIGHT = 1, GEM_MODEL_STEREO = 2
 enum {
     GEM_LAYER_ELEVATION = 0, GEM_LAYER_VARIANCE = 1, GEM_LAYER_INTENSITY = 2, GEM_LAYER_TRAVER = 3,
     GEM_LAYER_LOWEST = 4, GEM_LAYER_COLOR_R = 5, GEM_LAYER_COLOR_G = 6, GEM_LAYER_COLOR_B = 7,
-    GEM_LAYER_COUNT = 8
+    GEM_LAYER_ROUGH = 8, GEM_LAYER_SLOPE = 9,      /* outputs of gem_map_feature (visualMap_ layers "rough", "slope", EM.cpp:44) */
+    GEM_LAYER_COUNT = 10
 };
 /* layouts for gem_get_layer / gem_set_layer */
 enum {
@@ -151,6 +152,15 @@ int  gem_mapvar_update(gem_handle* h, float var_update);
 int  gem_get_layer(gem_handle* h, int layer, int layout, void* dst_host);
 int  gem_set_layer(gem_handle* h, int layer, const void* src_host);     /* STORAGE_ROWMAJOR only */
 int  gem_layer_device_ptr(gem_handle* h, int layer, void** out_device_ptr);
+
+/* ---- traversability stage that follows the fusion every frame: Map_feature (GPU:1256-1302, kernel
+ *      G_Mapfeature GPU:549-670 with the Jacobi eigen-solver GPU:66-187; called EMg.cpp:410).  Computes the
+ *      ROUGH, SLOPE and TRAVER layers on the device from ELEVATION.  Each host pointer may be NULL (nothing is
+ *      copied for it); with all NULL the call only enqueues the kernel.  Like the reference, the nine arrays
+ *      hold L*L elements in STORAGE_ROWMAJOR order.  Cells without elevation report rough = slope = 0 and
+ *      keep their stored traversability (the reference leaves its output arrays uninitialised there).       */
+int  gem_map_feature(gem_handle* h, float* elevation, float* variance, int* colorR, int* colorG, int* colorB,
+                     float* rough, float* slope, float* traver, float* intensity);
 
 /* ---- statistics / timing (bench harness) --------------------------------------------------------- */
 int  gem_set_timing(gem_handle* h, int enabled);      /* record hipEvents around each pipeline kernel */

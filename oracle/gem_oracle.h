@@ -94,6 +94,10 @@ void gemo_mapvar_update(gemo_map* m, float var_update);
 int  gemo_add(gemo_map* m, const gemo_frame* f, int n, const float* xyzi, const unsigned* rgb,
               const int* orig_index, long long counts[2]);
 
+/* GPU:549-670 (G_Mapfeature) + GPU:66-187 (computerEigenvalue): 5x5-neighbourhood plane fit per cell ->
+ * roughness, slope and traversability; updates m->traver like map_traver.  Outputs may be NULL. */
+void gemo_map_feature(gemo_map* m, float* rough, float* slope, float* traver_out);
+
 /* RMU.cpp:42-145 restated with plain arrays: returns the scalar var_update handed to Mapvar_update.
  * pose: position[3] + rotation matrix R_IB row-major[9]; cov: 6x6 row-major; state carries the
  * previous pose / previous reduced covariance exactly like the class members. */

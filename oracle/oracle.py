@@ -64,6 +64,7 @@ def lib() -> C.CDLL:
         l.gemo_fuse.argtypes = [POINTER(OMap), c_int] + [c_void_p] * 7
         l.gemo_fuse_literal.argtypes = [POINTER(OMap), c_int] + [c_void_p] * 7
         l.gemo_mapvar_update.argtypes = [POINTER(OMap), c_float]
+        l.gemo_map_feature.argtypes = [POINTER(OMap), c_void_p, c_void_p, c_void_p]
         l.gemo_add.restype = c_int
         l.gemo_add.argtypes = [POINTER(OMap), POINTER(OFrame), c_int, c_void_p, c_void_p, c_void_p, POINTER(c_longlong)]
         l.gemo_motion_init.argtypes = [POINTER(OMotion), c_double]
@@ -155,6 +156,13 @@ class OracleMap:
 
     def mapvar_update(self, u: float):
         self._l.gemo_mapvar_update(self._m, c_float(u))
+
+    def map_feature(self):
+        """G_Mapfeature (gpu_process.cu:549-670): returns dict(rough, slope, traver) and updates the traver layer."""
+        n = self.length * self.length
+        out = {k: np.zeros(n, np.float32) for k in ("rough", "slope", "traver")}
+        self._l.gemo_map_feature(self._m, _vp(out["rough"]), _vp(out["slope"]), _vp(out["traver"]))
+        return {k: v.reshape(self.length, self.length) for k, v in out.items()}
 
     def layer(self, name: str) -> np.ndarray:
         m = self._m.contents

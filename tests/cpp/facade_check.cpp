@@ -62,6 +62,9 @@ int main(int argc, char** argv)
     CHECK(v[idx[0]] == ss + 1e-5f);
     CHECK(e[idx[3]] == 0.1f);
     CHECK(e[0] == -10.f && v[0] == 1e-4f + 1e-5f);
+    // traversability stage: a cell without elevation reports nothing, an isolated cell has < 8 neighbours -> traver -10
+    CHECK(rough[0] == 0.f && slope[0] == 0.f && trav[0] == -10.f);
+    CHECK(trav[idx[0]] == -10.f && rough[idx[0]] == 0.f);
     Raytracing(L);
 
     // ---- the C++ facade --------------------------------------------------------------------------
