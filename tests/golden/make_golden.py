@@ -9,6 +9,8 @@ PARITY UNPINNED by the reference; the oracle itself is pinned by tests/test_orac
 
   c1.npz       BASELINE config 1 (10 k planar points -> 200 x 200 @ 0.1 m): inputs AND outputs
   chain.npz    a 600-point single-cell chain + collisions case: inputs and outputs
+  feature.npz  a 48 x 48 terrain (slopes, a step, holes) after a Move: elevation in, rough / slope / traver out
+               (the traversability stage, gemo_map_feature)
   digests.json SHA-256 of the oracle's layers for configs C2 / C3 / C4(4 sweeps) and of the input
                clouds (detects drift of the seeded generators)
 """
@@ -65,6 +67,21 @@ def main():
     m2 = oracle.OracleMap(32, 0.1)
     m2.add(f, pts)
     np.savez_compressed(HERE / "chain.npz", cloud=pts, elevation=m2.layer("elevation"), variance=m2.layer("variance"))
+
+    # ---- traversability stage on a rough terrain ----------------------------------------------------
+    L, res = 48, 0.1
+    rng = np.random.default_rng(7)
+    x, y = np.meshgrid(np.arange(L) * res, np.arange(L) * res, indexing="ij")
+    z = 0.7 * x - 0.2 * y + 0.3 * np.sin(2 * np.pi * x / 0.9) * np.cos(2 * np.pi * y / 0.7) + rng.normal(0, 0.01, (L, L))
+    z[rng.random((L, L)) < 0.12] = -10.0
+    z[20:21, :] += 0.4
+    z = z.astype(np.float32)
+    m3 = oracle.OracleMap(L, res)
+    m3.move(np.array([0.73, -0.41, 0.0], np.float32))
+    m3.set_layer("elevation", z)
+    ft = m3.map_feature()
+    np.savez_compressed(HERE / "feature.npz", elevation=z, position=np.array([0.73, -0.41, 0.0], np.float32),
+                        rough=ft["rough"], slope=ft["slope"], traver=ft["traver"])
 
     # ---- digests of the big configurations --------------------------------------------------------
     for name, mk in (("c2", synth.config_c2), ("c2_filter", lambda: synth.config_c2(reference_filter=True)), ("c3", synth.config_c3)):
