@@ -299,12 +299,27 @@ __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_
         }
     };
     // group flags of the first chunk of sweep 0: issued before anything else so that their latency
-    // overlaps the sweep-mask test and the tile read
+    // overlaps the sweep-mask test
     uint32_t ev[UPT], evn[UPT];
-    uint32_t gf0 = load_gflag(0, 0), gfn = 0;
+    const uint32_t gf0 = load_gflag(0, 0);
+    uint32_t gfn = 0;
     int prefetched = -1;                                                 // sweep whose first chunk sits in evn
 
-    // ---- the single read of the tile (issued before the flag test: one memory latency, not two) ----
+    // does this tile receive any point of this pass?
+    uint64_t smask = sweep_mask(0);
+    {
+        bool any_touched = smask != 0;
+        for (int sb = 64; sb < a.n_sweeps && !any_touched; sb += 64) any_touched = sweep_mask(sb) != 0;
+        if (!any_touched && !a.dense) return;
+    }
+    // descriptor words of the first touched sweep: in flight before the tile itself is read, so that the
+    // (larger, strided) tile loads do not sit in front of them in the memory pipeline
+    if (smask != 0) {
+        prefetched = __ffsll((unsigned long long)smask) - 1;
+        load_row(prefetched, 0, prefetched == 0 ? gf0 : load_gflag(prefetched, 0), evn);
+    }
+
+    // ---- the single read of the tile ---------------------------------------------------------------
     float ce[CPT], cs[CPT];
     bool  owned[CPT];
 #pragma unroll
@@ -317,14 +332,6 @@ __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_
             const size_t g = (size_t)row * L + col;
             ce[q] = a.elevation[g]; cs[q] = a.variance[g];
         }
-    }
-
-    // does this tile receive any point of this pass?
-    uint64_t smask = sweep_mask(0);
-    {
-        bool any_touched = smask != 0;
-        for (int sb = 64; sb < a.n_sweeps && !any_touched; sb += 64) any_touched = sweep_mask(sb) != 0;
-        if (!any_touched && !a.dense) return;
     }
 
     {   // fast-path rows start with count 0; the owner leaves every row it consumed at count 0 again
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_
 #pragma unroll
                 for (int j = 0; j < UPT; ++j) ev[j] = evn[j];
             } else {
-                load_row(sweep, cbase, (sweep == 0 && cbase == 0) ? gf0 : load_gflag(sweep, cbase), ev);
+                load_row(sweep, cbase, load_gflag(sweep, cbase), ev);
             }
             if (cbase == 0) {                                            // next touched sweep of this 64-block: its group flags start flying now,
                 const uint64_t later = (sweep & 63) == 63 ? 0ull : (smask >> ((sweep & 63) + 1));   // its row after the scan below
