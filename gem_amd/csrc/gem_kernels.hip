@@ -101,6 +101,22 @@ __device__ __forceinline__ uint64_t wave_peers(bool valid, uint32_t key, int nbi
     return valid ? peers : 0ull;
 }
 
+// The same when a wave holds only a few distinct keys (the 64 consecutive points of a LiDAR ring or of an
+// image row fall into 2-8 tiles): one ballot per distinct key, taken from the first lane still unmatched.
+// More than 8 distinct keys (a random cloud) fall back to the per-bit form.
+__device__ __forceinline__ uint64_t wave_peers_few(bool valid, uint32_t key, int nbits)
+{
+    uint64_t remaining = __ballot(valid), peers = 0;
+    for (int it = 0; it < 8 && remaining != 0; ++it) {   // wave-uniform
+        const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, __ffsll((unsigned long long)remaining) - 1);
+        const bool mine = valid && key == k;
+        const uint64_t m = __ballot(mine);
+        peers = mine ? m : peers;
+        remaining &= ~m;
+    }
+    return remaining != 0 ? wave_peers(valid, key, nbits) : peers;
+}
+
 // ------------------------------------------------------------------------------------------
 // k_project : Process_points' kernel (GPU:384-455) for the GEM-compatible host-array entry.
 // ------------------------------------------------------------------------------------------
@@ -174,7 +190,7 @@ __global__ __launch_bounds__(256) void k_bin_wave(BinArgs a)
     }
 
     // group the wave's points by tile, stable in lane (= input) order
-    const uint64_t peers = wave_peers(valid, tile, a.tile_bits);
+    const uint64_t peers = wave_peers_few(valid, tile, a.tile_bits);
     const uint64_t lt = lanemask_lt();
     const uint32_t rank = (uint32_t)__popcll(peers & lt);
     const uint32_t cnt = (uint32_t)__popcll(peers);
