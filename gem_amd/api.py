@@ -318,6 +318,16 @@ class ElevationMap:
     def mapvar_update(self, var_update: float) -> None:
         self._check(self._lib.gem_mapvar_update(self._h, float(var_update)), "gem_mapvar_update")
 
+    # -- loop-closure re-anchoring (Map_optmove, EMg.cpp:1020; Map_closeloop) -------------------------------------
+    def map_optmove(self, opt_xy, height_update: float) -> np.ndarray:
+        p = (C.c_float * 2)(float(opt_xy[0]), float(opt_xy[1])); out = (C.c_float * 2)()
+        self._check(self._lib.gem_map_optmove(self._h, p, float(height_update), out), "gem_map_optmove")
+        return np.array([out[0], out[1]], np.float32)
+
+    def map_closeloop(self, xy, height_update: float) -> None:
+        p = (C.c_float * 2)(float(xy[0]), float(xy[1]))
+        self._check(self._lib.gem_map_closeloop(self._h, p, float(height_update)), "gem_map_closeloop")
+
     # -- Map_feature (EMg.cpp:410): traversability stage on the fused map --------------------------------------
     def map_feature(self, fetch: bool = True):
         """Computes the rough / slope / traver layers on the device (gem_map_feature).  With fetch=True returns

@@ -744,6 +744,43 @@ int gem_layer_device_ptr(gem_handle* h, int layer, void** out_device_ptr)
     return *out_device_ptr ? GEM_OK : fail(h, GEM_ERR_INVALID, "gem_layer_device_ptr: bad layer");
 }
 
+// Map_optmove (gpu_process.cu:1215-1233, alignedPosition :1203-1213): after a loop closure the map centre is
+// relabelled to the optimised position snapped to the old centre's cell lattice -- the circular buffer is not
+// shifted, nothing is cleared -- and every valid elevation moves by height_update (G_update_mapheight :1195-1202).
+int gem_map_optmove(gem_handle* h, const float opt_position[2], float height_update, float out_aligned_position[2])
+{
+    if (!h || !opt_position) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    for (int i = 0; i < 2; ++i) {
+        const float d = opt_position[i] - h->center[i];
+        const int shift = static_cast<int>(static_cast<double>(d / h->res) + 0.5 * (d > 0 ? 1 : -1));     // :1210
+        h->center[i] = h->center[i] + h->res * static_cast<float>(shift);                                  // :1211
+    }
+    if (out_aligned_position) { out_aligned_position[0] = h->center[0]; out_aligned_position[1] = h->center[1]; }
+    GEM_HIP(h, launch_update_height(h->stream, h->layers.elevation, h->cells, height_update));
+    return GEM_OK;
+}
+
+// Map_closeloop (gpu_process.cu:1235-1254; declared by the node, never called): the centre moves by the aligned
+// shift through PositionToRange like Move's, the buffer stays, plus the height shift.
+int gem_map_closeloop(gem_handle* h, const float update_position[2], float height_update)
+{
+    if (!h || !update_position) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    for (int i = 0; i < 2; ++i) {
+        const float d = update_position[i] - h->center[i];
+        const int shift = static_cast<int>(static_cast<double>(d / h->res) + 0.5 * (d > 0 ? 1 : -1));     // :897
+        const float aligned = static_cast<float>(shift) * h->res;                                          // :909
+        const int p_index = static_cast<int>(roundf(h->center[i] / h->res));                               // :996-1002
+        const int s_index = static_cast<int>(roundf(aligned / h->res));
+        h->center[i] = static_cast<float>(p_index + s_index) * h->res;
+    }
+    GEM_HIP(h, launch_update_height(h->stream, h->layers.elevation, h->cells, height_update));
+    return GEM_OK;
+}
+
 // Map_feature (gpu_process.cu:1256-1302): the reference mallocs nine device arrays, runs G_Mapfeature and
 // copies all nine back every frame; here the kernel writes three resident layers and only the arrays
 // the caller asks for are copied.

@@ -735,6 +735,15 @@ __global__ __launch_bounds__(256) void k_dense_variance(float* __restrict__ vari
     }
 }
 
+// G_update_mapheight (GPU:1195-1202): loop-closure height shift of every cell that holds an elevation
+__global__ __launch_bounds__(256) void k_update_height(float* __restrict__ elevation, int cells, float dz)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += gridDim.x * blockDim.x) {
+        const float e = elevation[i];
+        if (e != kEmptyElevation) elevation[i] = e + dz;
+    }
+}
+
 // grid_map export (EM.cpp:98-111 reads the flat arrays with the GridMap *buffer* index; a
 // grid_map::Matrix is an Eigen column-major float matrix; empty cells become NaN)
 __global__ __launch_bounds__(256) void k_export_gridmap(const void* __restrict__ src, const float* __restrict__ elevation,
@@ -989,6 +998,12 @@ hipError_t launch_dense_variance(hipStream_t st, float* variance, int cells, int
     for (int i = 0; i < n_pending && i < 4; ++i) p[i] = pending[i];
     hipLaunchKernelGGL(k_dense_variance, dim3(grid_for(cells, 256)), dim3(256), 0, st, variance, cells, n_pending,
                        p[0], p[1], p[2], p[3], apply_floor, var_floor);
+    return hipGetLastError();
+}
+
+hipError_t launch_update_height(hipStream_t st, float* elevation, int cells, float dz)
+{
+    hipLaunchKernelGGL(k_update_height, dim3(grid_for(cells, 256)), dim3(256), 0, st, elevation, cells, dz);
     return hipGetLastError();
 }
 

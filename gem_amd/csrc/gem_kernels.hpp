@@ -90,6 +90,7 @@ hipError_t launch_init(hipStream_t st, const LayerPtrs& m, int cells, int clear_
 hipError_t launch_clear_strip(hipStream_t st, const LayerPtrs& m, int L, int start, int count, int is_row);
 hipError_t launch_dense_variance(hipStream_t st, float* variance, int cells, int n_pending, const float* pending,
                                  int apply_floor, float var_floor);
+hipError_t launch_update_height(hipStream_t st, float* elevation, int cells, float dz);
 hipError_t launch_map_feature(hipStream_t st, const float* elevation, float* traver, float* rough, float* slope,
                               int L, float res, int sx, int sy, int row0, int row1);
 hipError_t launch_export_gridmap(hipStream_t st, const void* src, const float* elevation, float* dst, int L, int is_int);

@@ -117,19 +117,17 @@ void Map_feature(int length, float* elevation, float* var, int* colorR, int* col
 // gpu_process.cu:1304-1318 -- visibility clean-up, outside the hot path: no-op.
 void Raytracing(int length) { (void)length; }
 
-// gpu_process.cu:1215-1233 -- loop-closure shift, outside the hot path: recentres the map;
-// the height offset of G_update_mapheight is not applied.
+// gpu_process.cu:1215-1233 -- loop-closure re-anchoring: the centre is relabelled to the optimised
+// position snapped to the cell lattice and every valid elevation moves by height_update (gem_map_optmove).
 void Map_optmove(float* opt_p, float height_update, float resolution, int length, float* opt_alignedPosition)
 {
-    (void)height_update; (void)resolution; (void)length;
-    float pos[3] = {opt_p[0], opt_p[1], 0.0f};
-    float center[2]; int start[2]; float shift[2];
-    gem_compat::report(gem_move(gem_compat::handle(), pos, center, start, shift), "Map_optmove");
-    opt_alignedPosition[0] = center[0]; opt_alignedPosition[1] = center[1];
+    (void)resolution; (void)length;
+    gem_compat::report(gem_map_optmove(gem_compat::handle(), opt_p, height_update, opt_alignedPosition), "Map_optmove");
 }
 
 // gpu_process.cu:1235-1254 -- declared by the node (ElevationMapping.cpp:46) but never called.
 void Map_closeloop(float* update_position, float height_update, int length, float resolution)
 {
-    (void)update_position; (void)height_update; (void)length; (void)resolution;
+    (void)length; (void)resolution;
+    gem_compat::report(gem_map_closeloop(gem_compat::handle(), update_position, height_update), "Map_closeloop");
 }

@@ -162,6 +162,13 @@ int  gem_layer_device_ptr(gem_handle* h, int layer, void** out_device_ptr);
 int  gem_map_feature(gem_handle* h, float* elevation, float* variance, int* colorR, int* colorG, int* colorB,
                      float* rough, float* slope, float* traver, float* intensity);
 
+/* ---- loop-closure re-anchoring: Map_optmove (GPU:1215-1233, called EMg.cpp:1020) relabels the
+ *      map centre to opt_position snapped to the old centre's cell lattice (the circular buffer is not shifted,
+ *      nothing is cleared) and adds height_update to every valid elevation (G_update_mapheight, GPU:1195-1202);
+ *      Map_closeloop (GPU:1235-1254) moves the centre by the aligned shift instead.                         */
+int  gem_map_optmove(gem_handle* h, const float opt_position[2], float height_update, float out_aligned_position[2]);
+int  gem_map_closeloop(gem_handle* h, const float update_position[2], float height_update);
+
 /* ---- statistics / timing (bench harness) --------------------------------------------------------- */
 int  gem_set_timing(gem_handle* h, int enabled);      /* record hipEvents around each pipeline kernel */
 int  gem_set_counting(gem_handle* h, int enabled);    /* count binned points / touched cells on device */

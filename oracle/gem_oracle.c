@@ -421,3 +421,37 @@ int gemo_add(gemo_map* m, const gemo_frame* f, int n, const float* xyzi, const u
     free(touched);
     return accepted;
 }
+
+
+/* GPU:1195-1202 (G_update_mapheight): elevation += dz on the cells that hold one */
+static void update_map_height(gemo_map* m, float dz)
+{
+    for (int i = 0; i < m->L * m->L; ++i) if (m->elevation[i] != -10.0f) m->elevation[i] += dz;
+}
+
+/* GPU:1215-1233 (Map_optmove, called EMg.cpp:1020 after a loop closure) with alignedPosition GPU:1203-1213:
+ * the map CENTRE is relabelled to the optimised position snapped to the cell lattice of the old centre (the
+ * circular buffer is not shifted and nothing is cleared) and every valid elevation is shifted by dz. */
+void gemo_map_optmove(gemo_map* m, const float opt_p[2], float height_update, float out_aligned[2])
+{
+    for (int i = 0; i < 2; ++i) {
+        const float position_shift = opt_p[i] - m->center[i];
+        const int index_shift = (int)((double)(position_shift / m->res) + 0.5 * (position_shift > 0 ? 1 : -1));   /* GPU:1210 */
+        out_aligned[i] = m->center[i] + m->res * (float)index_shift;                                              /* GPU:1211 */
+    }
+    m->center[0] = out_aligned[0]; m->center[1] = out_aligned[1];
+    update_map_height(m, height_update);
+}
+
+/* GPU:1235-1254 (Map_closeloop; declared EMg.cpp:46, never called): the centre moves by the aligned shift
+ * through PositionToRange like Move's, again without touching the buffer, plus the height shift. */
+void gemo_map_closeloop(gemo_map* m, const float update_position[2], float height_update)
+{
+    for (int i = 0; i < 2; ++i) {
+        const float position_shift = update_position[i] - m->center[i];
+        const int index_shift = (int)((double)(position_shift / m->res) + 0.5 * (position_shift > 0 ? 1 : -1));   /* GPU:897 */
+        const float aligned = (float)index_shift * m->res;                                                        /* GPU:909 */
+        m->center[i] = position_to_range(m->center[i], aligned, m->res);                                          /* GPU:996-1002 */
+    }
+    update_map_height(m, height_update);
+}

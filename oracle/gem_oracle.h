@@ -94,6 +94,10 @@ void gemo_mapvar_update(gemo_map* m, float var_update);
 int  gemo_add(gemo_map* m, const gemo_frame* f, int n, const float* xyzi, const unsigned* rgb,
               const int* orig_index, long long counts[2]);
 
+/* GPU:1215-1233 / 1235-1254 with G_update_mapheight GPU:1195-1202: loop-closure re-anchoring of the map. */
+void gemo_map_optmove(gemo_map* m, const float opt_p[2], float height_update, float out_aligned[2]);
+void gemo_map_closeloop(gemo_map* m, const float update_position[2], float height_update);
+
 /* GPU:549-670 (G_Mapfeature) + GPU:66-187 (computerEigenvalue): 5x5-neighbourhood plane fit per cell ->
  * roughness, slope and traversability; updates m->traver like map_traver.  Outputs may be NULL. */
 void gemo_map_feature(gemo_map* m, float* rough, float* slope, float* traver_out);

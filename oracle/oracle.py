@@ -65,6 +65,8 @@ def lib() -> C.CDLL:
         l.gemo_fuse_literal.argtypes = [POINTER(OMap), c_int] + [c_void_p] * 7
         l.gemo_mapvar_update.argtypes = [POINTER(OMap), c_float]
         l.gemo_map_feature.argtypes = [POINTER(OMap), c_void_p, c_void_p, c_void_p]
+        l.gemo_map_optmove.argtypes = [POINTER(OMap), POINTER(c_float), c_float, POINTER(c_float)]
+        l.gemo_map_closeloop.argtypes = [POINTER(OMap), POINTER(c_float), c_float]
         l.gemo_add.restype = c_int
         l.gemo_add.argtypes = [POINTER(OMap), POINTER(OFrame), c_int, c_void_p, c_void_p, c_void_p, POINTER(c_longlong)]
         l.gemo_motion_init.argtypes = [POINTER(OMotion), c_double]
@@ -156,6 +158,16 @@ class OracleMap:
 
     def mapvar_update(self, u: float):
         self._l.gemo_mapvar_update(self._m, c_float(u))
+
+    def map_optmove(self, opt_xy, height_update: float):
+        """Map_optmove (gpu_process.cu:1215-1233): returns the aligned centre."""
+        p = (c_float * 2)(float(opt_xy[0]), float(opt_xy[1])); out = (c_float * 2)()
+        self._l.gemo_map_optmove(self._m, p, c_float(height_update), out)
+        return np.array([out[0], out[1]], np.float32)
+
+    def map_closeloop(self, xy, height_update: float):
+        p = (c_float * 2)(float(xy[0]), float(xy[1]))
+        self._l.gemo_map_closeloop(self._m, p, c_float(height_update))
 
     def map_feature(self):
         """G_Mapfeature (gpu_process.cu:549-670): returns dict(rough, slope, traver) and updates the traver layer."""

@@ -105,3 +105,34 @@ def test_map_feature_after_fusion(oracle_mod):
     for k in ("rough", "slope", "traver"):
         assert np.array_equal(g[k], o[k]), k
     assert (o["traver"] != -10).sum() > 10000
+
+
+# ---- loop-closure re-anchoring: Map_optmove / Map_closeloop (gpu_process.cu:1215-1254) ---------------------------------------
+def test_optmove_relabels_the_centre_and_shifts_heights(oracle_mod):
+    m = oracle_mod.OracleMap(16, 0.1)
+    e = np.full((16, 16), -10, F32); e[3, 4] = 0.5; e[9, 9] = -0.25
+    m.set_layer("elevation", e)
+    m.move(np.array([0.3, -0.2, 0.0], F32))
+    c0, s0 = m.pose()
+    aligned = m.map_optmove([c0[0] + 0.234, c0[1] - 0.561], 0.125)
+    c1, s1 = m.pose()
+    assert tuple(s1) == tuple(s0)                                           # the circular buffer is not shifted
+    assert np.allclose(aligned, [c0[0] + 0.2, c0[1] - 0.6], atol=1e-6) and np.allclose(c1, aligned)
+    out = m.layer("elevation")
+    assert out[3, 4] == F32(0.5) + F32(0.125) and out[9, 9] == F32(-0.25) + F32(0.125) and out[0, 0] == -10
+
+
+@pytest.mark.gpu
+def test_optmove_and_closeloop_parity(oracle_mod):
+    from gem_amd import ElevationMap
+    L, res = 64, 0.1
+    gpu, ref = ElevationMap(L, res), oracle_mod.OracleMap(L, res)
+    z = terrain(L, res, 5)
+    for m in (gpu, ref):
+        m.move(np.array([1.03, -0.46, 0], F32)); m.set_layer("elevation", z)
+    a_g, a_o = gpu.map_optmove([1.31, -0.77], 0.071), ref.map_optmove([1.31, -0.77], 0.071)
+    assert np.array_equal(a_g, a_o)
+    gpu.map_closeloop([0.52, 0.18], -0.033); ref.map_closeloop([0.52, 0.18], -0.033)
+    cg, sg = gpu.pose(); co, so = ref.pose()
+    assert np.array_equal(np.asarray(cg, F32), np.asarray(co, F32)) and tuple(sg) == tuple(so)
+    assert np.array_equal(gpu.layer("elevation"), ref.layer("elevation"))
