@@ -81,7 +81,7 @@ def pmc_traffic(kernel_prefix: str):
         except Exception:
             continue
         for k, v in c.items():
-            if k.split("<")[0].endswith(kernel_prefix) and "hbm_bytes_high" in v:
+            if k.split("<")[0].split("(")[0].endswith(kernel_prefix) and "hbm_bytes_high" in v:
                 best = (f.name, v)
     return best
 
@@ -207,7 +207,12 @@ def main():
     # XYZI record per point; k_fuse reads + writes elevation and variance once per touched cell.
     alg_bin = 16.0 * n_per * sweeps_per_step
     alg_fuse = 16.0 * cells * sweeps_per_step
-    if us_fuse >= us_bin:
+    us_frame = 1e3 * st["ms_frame"] / max(st["launches_frame"], 1)
+    if st["launches_frame"] > st["launches_fuse"]:
+        # steady state of a stream of single sweeps: ONE launch per step, k_frame = fuse of the previous sweep's
+        # records + binning of the new cloud, so its algorithmic bytes are the whole frame's
+        dom, dom_us, dom_bytes = "k_frame", us_frame, alg_bin + alg_fuse
+    elif us_fuse >= us_bin:
         dom, dom_us, dom_bytes = "k_fuse_list", us_fuse, alg_fuse
     else:
         dom, dom_us, dom_bytes = "k_bin_wave", us_bin, alg_bin
@@ -220,9 +225,10 @@ def main():
                         f"per launch; uncorrected {pm[1]['hbm_bytes_low']:.0f} B")
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                "us_per_launch": {"k_bin_wave": us_bin, "k_fuse_list": us_fuse},
-                "algorithmic_bytes_per_launch": {"k_bin_wave": alg_bin, "k_fuse_list": alg_fuse},
-                "pipeline_GBps": (alg_bin + alg_fuse) / ((us_bin + us_fuse) * 1e-6) / 1e9 if us_bin + us_fuse > 0 else 0.0,
+                "us_per_launch": {"k_frame": us_frame, "k_bin_wave": us_bin, "k_fuse_list": us_fuse},
+                "launches": {"k_frame": st["launches_frame"], "k_bin_wave": st["launches_bin"], "k_fuse_list": st["launches_fuse"]},
+                "algorithmic_bytes_per_launch": {"k_frame": alg_bin + alg_fuse, "k_bin_wave": alg_bin, "k_fuse_list": alg_fuse},
+                "pipeline_GBps": (alg_bin + alg_fuse) * args.steps / ((st["ms_frame"] + st["ms_bin"] + st["ms_fuse"]) * 1e-3) / 1e9,
                 "note": "one sweep is ~3 MB of algorithmic traffic (0.5 us at the HBM rate): both kernels are launch/latency "
                         "bound on this workload, see DESIGN.md section 6; `batched_c4` is the bandwidth-regime figure"}
 

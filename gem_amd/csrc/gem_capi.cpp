@@ -61,6 +61,11 @@ struct gem_handle {
         uint32_t epoch = 0;            // touched-flag stamp of the last pass (0 = the flag table holds no live stamps)
     } pb[2];
     unsigned pass = 0;
+    // A stream of single device-resident sweeps runs as ONE launch per frame: k_frame fuses the previous
+    // frame's records next to the binning of the new cloud.  The fuse of the newest frame is therefore
+    // deferred until the next gem_add_device -- or until anything observes or modifies the map.
+    struct Deferred { bool valid = false; FuseArgs fa{}; int ts = 0, attr = 0; } deferred;
+    bool defer = true;
     hipStream_t bin_stream = nullptr;
     bool overlap = true;
     long long overlap_min_points = 1000000;
@@ -163,17 +168,29 @@ void fold_events(gem_handle* h)
     for (auto& ep : h->events) {
         float ms = 0.f;
         if (hipEventSynchronize(ep.b) == hipSuccess && hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
-            if (ep.kind == 0) { h->stats.ms_bin += ms; h->stats.launches_bin++; }
-            else              { h->stats.ms_fuse += ms; h->stats.launches_fuse++; }
+            if (ep.kind == 0)      { h->stats.ms_bin += ms; h->stats.launches_bin++; }
+            else if (ep.kind == 1) { h->stats.ms_fuse += ms; h->stats.launches_fuse++; }
+            else                   { h->stats.ms_frame += ms; h->stats.launches_frame++; }
         }
         h->pool.push_back(ep);
     }
     h->events.clear();
 }
 
+// the fuse of the newest frame, if it is still pending (see gem_handle::deferred)
+int flush_deferred(gem_handle* h)
+{
+    if (!h->deferred.valid) return GEM_OK;
+    h->deferred.valid = false;
+    Timed t(h, 1);
+    GEM_HIP(h, launch_fuse(h->stream, h->deferred.fa, h->deferred.ts, h->deferred.attr, h->fuse_variant, t.events()));
+    return GEM_OK;
+}
+
 // standalone dense pass: queued Mapvar_update increments (+ optionally the variance floor)
 int flush_pending(gem_handle* h, bool with_floor)
 {
+    { const int rc = flush_deferred(h); if (rc) return rc; }
     if (h->n_pending == 0 && !with_floor) return GEM_OK;
     GEM_HIP(h, launch_dense_variance(h->stream, h->layers.variance, h->cells, h->n_pending, h->pending, with_floor ? 1 : 0,
                                      h->cfg.variance_floor));
@@ -191,6 +208,7 @@ int index_to_range(int index, int L)          // gpu_process.cu:914-919
 // One pipeline pass over up to `n` points that are already on the device.
 struct PassInput {
     int src = 0;                       // 0 = XYZI cloud, 1 = Fuse() arrays
+    bool device_input = false;         // the caller's device buffers are read directly (no staging copy)
     int n_sweeps = 1;
     long long n = 0;
     const gem_frame_params* params = nullptr;      // [n_sweeps] (src 0)
@@ -272,7 +290,11 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     // (batches / aggregated clouds: C4 379 -> 313 us); single sweeps stay on one stream.
     const bool overlap = h->overlap && in.n >= h->overlap_min_points && h->stream == h->own_stream && h->bin_stream &&
                          !h->counting && !h->dbg_on;
-    gem_handle::PassBuffers& pb = h->pb[overlap ? (h->pass++ & 1u) : 0u];
+    // one launch per frame for a stream of single sweeps (k_frame): needs the other half of the double buffer
+    const bool defer = h->defer && in.device_input && in.src == 0 && !batched && attr == 0 && ts == 4 && !overlap &&
+                       !h->counting && !h->dbg_on;
+    if (!defer) { const int rcd = flush_deferred(h); if (rcd) return rcd; }
+    gem_handle::PassBuffers& pb = h->pb[(overlap || defer) ? (h->pass++ & 1u) : 0u];
     hipStream_t sbin = overlap ? h->bin_stream : h->stream;
     int rc;
     if ((rc = ensure(h, pb.rec, (size_t)B * U * sizeof(uint4)))) return rc;
@@ -356,6 +378,15 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
         fa.dbg = static_cast<unsigned long long*>(h->dbg.p);
     }
 
+    if (defer) {
+        if (h->deferred.valid) { Timed t(h, 2); GEM_HIP(h, launch_frame(h->stream, h->deferred.fa, ba, t.events())); }
+        else                   { Timed t(h, 0); GEM_HIP(h, launch_bin(h->stream, ba, in.src, ts, t.events())); }
+        h->deferred.fa = fa; h->deferred.ts = ts; h->deferred.attr = attr; h->deferred.valid = true;
+        h->n_pending = 0;
+        h->floor_dirty = false;
+        h->stats.points_in = in.n;
+        return GEM_OK;
+    }
     if (h->counting) GEM_HIP(h, hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
     { Timed t(h, 0); GEM_HIP(h, launch_bin(sbin, ba, in.src, ts, t.events())); }
     if (overlap) {
@@ -419,6 +450,7 @@ int gem_create(const gem_map_config* cfg, gem_handle** out)
         if ((e = hipEventCreateWithFlags(&b.bin_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&b.fuse_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     }
+    if (const char* s = getenv("GEM_DEFER")) h->defer = atoi(s) != 0;
     if (const char* s = getenv("GEM_OVERLAP")) { h->overlap = atoi(s) != 0; if (atoi(s) > 1) h->overlap_min_points = 0; }
     // one allocation for the 8 layers (gpu_process.cu:954-961 uses 8 cudaMalloc)
     void* base = nullptr;
@@ -447,7 +479,7 @@ void gem_destroy(gem_handle* h)
 {
     if (!h) return;
     hipSetDevice(h->device);
-    if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->stream) { flush_deferred(h); hipStreamSynchronize(h->stream); }
     if (h->bin_stream) hipStreamSynchronize(h->bin_stream);
     if (h->comm) ncclCommDestroy(h->comm);
     fold_events(h);
@@ -471,6 +503,7 @@ int gem_set_stream(gem_handle* h, void* hip_stream)
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
+    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
     GEM_HIP(h, hipStreamSynchronize(h->stream));
     if (h->bin_stream) GEM_HIP(h, hipStreamSynchronize(h->bin_stream));
     h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
@@ -482,6 +515,7 @@ int gem_synchronize(gem_handle* h)
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
+    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
     GEM_HIP(h, hipStreamSynchronize(h->stream));
     return GEM_OK;
 }
@@ -502,6 +536,7 @@ int gem_move(gem_handle* h, const float position[3], float out_center[2], int ou
     if (!h || !position) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
+    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
     const int L = h->L; const float res = h->res;
     h->sensor_z = position[2];
     int shift[2]; float aligned[2];
@@ -618,7 +653,7 @@ int gem_add_device(gem_handle* h, const gem_frame_params* p, int n, const void* 
     if (!h || !p || n < 0 || (n > 0 && !d_xyzi)) return h ? fail(h, GEM_ERR_INVALID, "gem_add_device: bad argument") : GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
-    PassInput in; in.src = 0; in.n = n; in.params = p;
+    PassInput in; in.src = 0; in.n = n; in.params = p; in.device_input = true;
     in.xyzi = static_cast<const float4*>(d_xyzi); in.rgb = static_cast<const uint32_t*>(d_rgb); in.orig = static_cast<const int*>(d_orig_index);
     return run_pipeline(h, in);
 }
@@ -657,7 +692,7 @@ int gem_add_batch_device(gem_handle* h, int n_sweeps, const gem_frame_params* pa
             if (h->n_pending == kMaxPending) { int rc = flush_pending(h, false); if (rc) return rc; }
             h->pending[h->n_pending++] = var_updates[0];
         }
-        PassInput in; in.src = 0; in.n = offsets[1] - offsets[0]; in.params = params;
+        PassInput in; in.src = 0; in.n = offsets[1] - offsets[0]; in.params = params; in.device_input = true;
         in.xyzi = static_cast<const float4*>(d_xyzi) + offsets[0];
         return run_pipeline(h, in);
     }
@@ -740,6 +775,8 @@ int gem_layer_device_ptr(gem_handle* h, int layer, void** out_device_ptr)
 {
     if (!h || !out_device_ptr) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    { const int rcd = flush_deferred(h); if (rcd) return rcd; }   // the caller is about to read or write the layer
     *out_device_ptr = layer_ptr(h, layer);
     return *out_device_ptr ? GEM_OK : fail(h, GEM_ERR_INVALID, "gem_layer_device_ptr: bad layer");
 }
@@ -752,6 +789,7 @@ int gem_map_optmove(gem_handle* h, const float opt_position[2], float height_upd
     if (!h || !opt_position) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
+    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
     for (int i = 0; i < 2; ++i) {
         const float d = opt_position[i] - h->center[i];
         const int shift = static_cast<int>(static_cast<double>(d / h->res) + 0.5 * (d > 0 ? 1 : -1));     // :1210
@@ -769,6 +807,7 @@ int gem_map_closeloop(gem_handle* h, const float update_position[2], float heigh
     if (!h || !update_position) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
+    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
     for (int i = 0; i < 2; ++i) {
         const float d = update_position[i] - h->center[i];
         const int shift = static_cast<int>(static_cast<double>(d / h->res) + 0.5 * (d > 0 ? 1 : -1));     // :897
@@ -809,6 +848,8 @@ int gem_set_timing(gem_handle* h, int enabled)
 {
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
     h->timing = enabled != 0;
     return GEM_OK;
 }
@@ -817,6 +858,8 @@ int gem_set_counting(gem_handle* h, int enabled)
 {
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
     h->counting = enabled != 0;
     return GEM_OK;
 }
@@ -826,6 +869,7 @@ int gem_get_stats(gem_handle* h, gem_stats* out, int reset)
     if (!h || !out) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
+    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
     GEM_HIP(h, hipStreamSynchronize(h->stream));
     fold_events(h);
     if (h->counting) {
@@ -845,6 +889,7 @@ int gem_debug_fuse_stamps(gem_handle* h, int enable, unsigned long long* out, in
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
+    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
     h->dbg_on = enable != 0;
     if (out && h->dbg.p) {
         GEM_HIP(h, hipStreamSynchronize(h->stream));
@@ -871,6 +916,7 @@ int gem_comm_init(gem_handle* h, const void* unique_id_128_bytes, int nranks, in
     if (!h || !unique_id_128_bytes || nranks <= 0 || rank < 0 || rank >= nranks) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
+    { const int rcd = flush_deferred(h); if (rcd) return rcd; }   // the strip changes below
     ncclUniqueId id;
     memcpy(&id, unique_id_128_bytes, sizeof(id));
     ncclResult_t r = ncclCommInitRank(&h->comm, nranks, id, rank);

@@ -139,12 +139,12 @@ __global__ __launch_bounds__(256) void k_project(FrameConst fc, int n, float* __
 // Only the tiles a unit actually touches are written; k_fuse_list zeroes every word it consumes,
 // so the table is all-zero again after each pass and never needs a clearing kernel.
 template <int SRC, int TS, bool BATCH>
-__global__ __launch_bounds__(256) void k_bin_wave(BinArgs a)
+__device__ __forceinline__ void bin_wave_body(const BinArgs& a, int block)
 {
     constexpr int TE = 1 << TS;
     constexpr int U = 64;
     const int lane = lane_id();
-    const int unit = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int unit = (int)(block * 4 + (threadIdx.x >> 6));
     if (unit >= a.B) return;                               // whole wave leaves together
 
     int sweep = 0, unit_first = 0, orig0 = 0;
@@ -213,6 +213,9 @@ __global__ __launch_bounds__(256) void k_bin_wave(BinArgs a)
     }
 }
 
+template <int SRC, int TS, bool BATCH>
+__global__ __launch_bounds__(256) void k_bin_wave(BinArgs a) { bin_wave_body<SRC, TS, BATCH>(a, (int)blockIdx.x); }
+
 // ------------------------------------------------------------------------------------------
 // k_fuse_list : one workgroup of NT threads per tile -- the lean fuse.
 // ------------------------------------------------------------------------------------------
@@ -240,9 +243,8 @@ constexpr int fuse_list_max_batches(int pb) { return kChunkUnits * 64 / (pb - 64
 #define GEM_CSWAP(a, b) do { const uint32_t lo_ = min(a, b), hi_ = max(a, b); a = lo_; b = hi_; } while (0)
 
 template <int TS, int NT, int PB, int ATTR>
-__global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_list(FuseArgs a)
+__device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsigned char* lds_raw)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr int TE = 1 << TS;
     constexpr int CELLS = TE * TE;
     constexpr int NW = NT / 64;
@@ -272,7 +274,6 @@ __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_
     const int tid = (int)threadIdx.x;
     const int lane = lane_id();
     const int w = tid >> 6;
-    const int tile = (int)blockIdx.x;
     const int tr = tile / a.tiles_per_row, tc = tile - tr * a.tiles_per_row;
     const int row_base = tr << TS, col_base = tc << TS;
     const int L = a.L;
@@ -696,6 +697,27 @@ __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_
 #undef GEM_STAMP
 }
 
+template <int TS, int NT, int PB, int ATTR>
+__global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_list(FuseArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
+    fuse_list_body<TS, NT, PB, ATTR>(a, (int)blockIdx.x, lds_dyn);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_frame : the steady state of a stream of single sweeps in ONE launch per frame -- the fusion of the
+// previous frame's records (blocks [0, T)) next to the binning of this frame's cloud (blocks [T, T + B/4)).
+// Binning depends on the cloud and the pose only, so the two halves are independent; they use the two halves
+// of the double-buffered arenas.  Saves one kernel boundary (~3 us here) per frame and lets the binning run on
+// the CUs the fuse leaves idle.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4) void k_frame(FuseArgs fa, BinArgs ba)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
+    if ((int)blockIdx.x < fa.T) fuse_list_body<4, 256, 1024, 0>(fa, (int)blockIdx.x, lds_dyn);
+    else bin_wave_body<0, 4, false>(ba, (int)blockIdx.x - fa.T);
+}
+
 // ------------------------------------------------------------------------------------------
 // dense / state kernels
 // ------------------------------------------------------------------------------------------
@@ -976,6 +998,14 @@ hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr, int 
     if (variant == 10) return launch_fuse_list<5, 256, 4096>(st, a, attr, ev);
     if (variant == 11) return launch_fuse_list<5, 512, 4096>(st, a, attr, ev);
     return launch_fuse_list<5, 512, 2048>(st, a, attr, ev);
+}
+
+// fuse of the previous frame + bin of this one (single sweeps on 16x16 tiles, no attributes)
+hipError_t launch_frame(hipStream_t st, const FuseArgs& fa, const BinArgs& ba, LaunchEvents ev)
+{
+    const dim3 grid(fa.T + (ba.B + 3) / 4), block(256);
+    GEM_LAUNCH((k_frame), grid, block, fuse_list_lds(256, 4, 1024, 0), st, ev, fa, ba);
+    return hipGetLastError();
 }
 
 hipError_t launch_init(hipStream_t st, const LayerPtrs& m, int cells, int clear_lowest)

@@ -85,6 +85,7 @@ struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };   // option
 
 hipError_t launch_bin(hipStream_t st, const BinArgs& a, int src, int ts, LaunchEvents ev);
 hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr, int variant, LaunchEvents ev);
+hipError_t launch_frame(hipStream_t st, const FuseArgs& fuse_prev, const BinArgs& bin_this, LaunchEvents ev);
 size_t     fuse_lds_bytes(int ts, int variant, int attr);
 hipError_t launch_init(hipStream_t st, const LayerPtrs& m, int cells, int clear_lowest);
 hipError_t launch_clear_strip(hipStream_t st, const LayerPtrs& m, int L, int start, int count, int is_row);

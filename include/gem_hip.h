@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GEM_ABI_VERSION 2
+#define GEM_ABI_VERSION 3
 
 typedef enum gem_status {
     GEM_OK = 0,
@@ -100,6 +100,8 @@ typedef struct gem_stats {
     long long cells_touched;       /* distinct cells that received >= 1 point                                  */
     float     ms_bin, ms_fuse;     /* accumulated kernel time of the two pipeline kernels since reset          */
     int       launches_bin, launches_fuse;
+    float     ms_frame;            /* ... and of k_frame (fuse of the previous sweep + bin of the new one)     */
+    int       launches_frame;
 } gem_stats;
 
 /* ---- lifecycle: replaces Init_GPU_elevationmap (GPU:940-994, called EMg.cpp:199) --------------- */

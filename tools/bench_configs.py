@@ -35,7 +35,7 @@ def timed(emap, fn, reps, warm=3):
     for _ in range(reps):
         fn()
     st = emap.stats(); emap.set_timing(False)
-    return wall, 1e3 * st["ms_bin"] / reps, 1e3 * st["ms_fuse"] / reps
+    return wall, 1e3 * st["ms_bin"] / reps, 1e3 * (st["ms_fuse"] + st["ms_frame"]) / reps
 
 
 def touched(emap, fn):
