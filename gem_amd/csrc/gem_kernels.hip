@@ -23,6 +23,8 @@
 
 #include <hip/hip_ext.h>
 
+#include <type_traits>
+
 namespace gem {
 
 // ------------------------------------------------------------------------------------------
@@ -242,9 +244,13 @@ constexpr int fuse_list_max_batches(int pb) { return kChunkUnits * 64 / (pb - 64
 
 #define GEM_CSWAP(a, b) do { const uint32_t lo_ = min(a, b), hi_ = max(a, b); a = lo_; b = hi_; } while (0)
 
-template <int TS, int NT, int PB, int ATTR>
+template <int TS, int NT, int PB, int ATTR, bool BATCH>
 __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsigned char* lds_raw)
 {
+    // BATCH = false: one sweep, no per-sweep tables in device memory, no variance increments between sweeps --
+    // the sweep loop below collapses and none of its scalar bookkeeping is compiled in
+    const int NS = BATCH ? a.n_sweeps : 1;
+    const float* const var_updates = BATCH ? a.var_updates : nullptr;
     constexpr int TE = 1 << TS;
     constexpr int CELLS = TE * TE;
     constexpr int NW = NT / 64;
@@ -285,10 +291,10 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
 
     // which sweeps put a record into this tile?  flag[tile][sweep] == epoch (stamped by k_bin): one
     // coalesced load per 64 sweeps, turned into a wave-uniform bit mask
-    const uint32_t* flagrow = a.flag + (size_t)tile * a.n_sweeps;
+    const uint32_t* flagrow = a.flag + (size_t)tile * NS;
     auto sweep_mask = [&](int sbase) -> uint64_t {
         const int sidx = sbase + lane;
-        return __ballot(sidx < a.n_sweeps && flagrow[sidx] == epoch);
+        return __ballot(sidx < NS && flagrow[sidx] == epoch);
     };
     auto row_ptr = [&](int sweep) -> uint16_t* { return a.seg + ((size_t)sweep * a.T + tile) * a.Bpad; };   // table layout [sweep][tile][unit in sweep]
     // A row is only read where k_bin stamped the group of 32 units (64 bytes of descriptor words) as live for
@@ -298,26 +304,30 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
         const int g = (cbase + tid * UPT) >> 5;
         return g < (a.Bpad >> 5) ? a.gflag[((size_t)sweep * a.T + tile) * (a.Bpad >> 5) + g] : 0u;
     };
-    auto load_row = [&](int sweep, int cbase, uint32_t gf, uint32_t (&e)[UPT]) {
-        const int ubx = a.sweep_unit0 ? a.sweep_unit0[sweep] : 0;
-        const int Bx = (a.sweep_unit0 ? a.sweep_unit0[sweep + 1] : a.B_total) - ubx;
+    // the row words of a thread stay packed (one 16- or 8-byte register group) until they are needed: unpacking
+    // at the load would make the compiler wait for the load right there
+    using RowWords = typename std::conditional<UPT == 8, uint4, uint2>::type;
+    auto load_row = [&](int sweep, int cbase, uint32_t gf, bool& on) -> RowWords {
+        const int Bx = BATCH ? a.sweep_unit0[sweep + 1] - a.sweep_unit0[sweep] : a.B_total;
         const uint16_t* segx = row_ptr(sweep);
         const int u0 = cbase + tid * UPT;                                // rows are padded to 32 units
-        const bool on = gf == epoch && u0 < Bx;
-        if constexpr (UPT == 8) {
-            uint4 q = make_uint4(0, 0, 0, 0);
-            if (on) q = *reinterpret_cast<const uint4*>(segx + u0);
-            e[0] = q.x & 0xffffu; e[1] = q.x >> 16; e[2] = q.y & 0xffffu; e[3] = q.y >> 16;
-            e[4] = q.z & 0xffffu; e[5] = q.z >> 16; e[6] = q.w & 0xffffu; e[7] = q.w >> 16;
-        } else {
-            uint2 q = make_uint2(0, 0);
-            if (on) q = *reinterpret_cast<const uint2*>(segx + u0);
-            e[0] = q.x & 0xffffu; e[1] = q.x >> 16; e[2] = q.y & 0xffffu; e[3] = q.y >> 16;
+        // clamped address instead of a branch around the load: the number of loads in flight stays known
+        on = gf == epoch && u0 < Bx;
+        return *reinterpret_cast<const RowWords*>(segx + (on ? u0 : 0));  // `on` is applied when the words are unpacked
+    };
+    auto unpack_row = [&](const RowWords& q, bool on, uint32_t (&e)[UPT]) {
+        e[0] = q.x & 0xffffu; e[1] = q.x >> 16; e[2] = q.y & 0xffffu; e[3] = q.y >> 16;
+        if constexpr (UPT == 8) { e[4] = q.z & 0xffffu; e[5] = q.z >> 16; e[6] = q.w & 0xffffu; e[7] = q.w >> 16; }
+        if (!on) {
+#pragma unroll
+            for (int j = 0; j < UPT; ++j) e[j] = 0;
         }
     };
     // group flags of the first chunk of sweep 0: issued before anything else so that their latency
     // overlaps the sweep-mask test
-    uint32_t ev[UPT], evn[UPT];
+    uint32_t ev[UPT];
+    RowWords evn;
+    bool evn_on = false;
     const uint32_t gf0 = load_gflag(0, 0);
     uint32_t gfn = 0;
     int prefetched = -1;                                                 // sweep whose first chunk sits in evn
@@ -326,14 +336,14 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
     uint64_t smask = sweep_mask(0);
     {
         bool any_touched = smask != 0;
-        for (int sb = 64; sb < a.n_sweeps && !any_touched; sb += 64) any_touched = sweep_mask(sb) != 0;
+        for (int sb = 64; sb < NS && !any_touched; sb += 64) any_touched = sweep_mask(sb) != 0;
         if (!any_touched && !a.dense) return;
     }
     // descriptor words of the first touched sweep: in flight before the tile itself is read, so that the
     // (larger, strided) tile loads do not sit in front of them in the memory pipeline
     if (smask != 0) {
         prefetched = __ffsll((unsigned long long)smask) - 1;
-        load_row(prefetched, 0, prefetched == 0 ? gf0 : load_gflag(prefetched, 0), evn);
+        evn = load_row(prefetched, 0, prefetched == 0 ? gf0 : load_gflag(prefetched, 0), evn_on);
     }
 
     // ---- the single read of the tile ---------------------------------------------------------------
@@ -344,11 +354,11 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
         const int c = tid + NT * q;
         const int row = row_base + (c >> TS), col = col_base + (c & (TE - 1));
         owned[q] = row < a.row1 && row >= a.row0 && col < L;
-        ce[q] = kEmptyElevation; cs[q] = kInitVariance;
-        if (owned[q]) {
-            const size_t g = (size_t)row * L + col;
-            ce[q] = a.elevation[g]; cs[q] = a.variance[g];
-        }
+        // unconditional loads (clamped address): a load inside a branch would make the number of loads in flight
+        // unknown to the compiler, which then waits for ALL of them wherever it needs the descriptor words
+        // (cells outside the map or the strip read cell 0; they receive no records and are never written back)
+        const size_t g = owned[q] ? (size_t)row * L + col : 0;
+        ce[q] = a.elevation[g]; cs[q] = a.variance[g];
     }
 
     {   // fast-path rows start with count 0; the owner leaves every row it consumed at count 0 again
@@ -359,23 +369,30 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
     GEM_STAMP();                                                         // 1: tile loads issued
 
     uint32_t tmask = 0;                                                  // cells of this thread touched in this sweep (or pass)
-    for (int sweep = 0; sweep < a.n_sweeps; ++sweep) {
+    for (int sweep = 0; sweep < NS; ++sweep) {
         if (sweep != 0 && (sweep & 63) == 0) smask = sweep_mask(sweep);
         const bool touched_sweep = (smask >> (sweep & 63)) & 1ull;       // block-uniform
         // a sweep that neither reaches this tile nor carries a variance increment changes nothing
         // (the floor below is idempotent and has been applied by an earlier sweep or is applied by a later one)
-        if (!touched_sweep && !a.var_updates && sweep != 0 && sweep != a.n_sweeps - 1) continue;
-        const int ub = a.sweep_unit0 ? a.sweep_unit0[sweep] : 0;        // multiple of 4 (host pads sweeps)
-        const int ue = a.sweep_unit0 ? a.sweep_unit0[sweep + 1] : a.B_total;
+        if (!touched_sweep && !var_updates && sweep != 0 && sweep != NS - 1) continue;
+        const int ub = BATCH ? a.sweep_unit0[sweep] : 0;                 // multiple of 32 (host pads sweeps)
+        const int ue = BATCH ? a.sweep_unit0[sweep + 1] : a.B_total;
         const int B = ue - ub;
 
-        // ---- Mapvar_update increments queued before this sweep (GPU:540-547) ----------------------
+        // ---- Mapvar_update increments queued before this sweep (GPU:540-547): applied lazily, right before
+        //      the first use of the variances in this sweep, so that the tile read (strided 64-byte segments,
+        //      the slowest loads of the kernel) stays in flight behind the descriptor scan and the record gather
+        bool incs_applied = false;
+        auto apply_increments = [&]() {
+            if (incs_applied) return;
+            incs_applied = true;
 #pragma unroll
-        for (int q = 0; q < CPT; ++q) {
-            if (sweep == 0)
-                for (int k = 0; k < a.n_pending; ++k) if (cs[q] != kInitVariance) cs[q] += a.pending[k];
-            if (a.var_updates) { if (cs[q] != kInitVariance) cs[q] += a.var_updates[sweep]; }
-        }
+            for (int q = 0; q < CPT; ++q) {
+                if (sweep == 0)
+                    for (int k = 0; k < a.n_pending; ++k) if (cs[q] != kInitVariance) cs[q] += a.pending[k];
+                if (var_updates) { if (cs[q] != kInitVariance) cs[q] += var_updates[sweep]; }
+            }
+        };
         if (a.counters && tid == 0 && (sweep == 0 || !a.count_per_pass)) misc[0] = 0;
         if (!a.count_per_pass) tmask = 0;
 
@@ -383,32 +400,35 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
             // ---- 1. ordered compaction of the chunk's live descriptors ----------------------------
             const int u0 = cbase + tid * UPT;
             int next_sweep = -1;
-            if (cbase == 0 && prefetched == sweep) {
-#pragma unroll
-                for (int j = 0; j < UPT; ++j) ev[j] = evn[j];
-            } else {
-                load_row(sweep, cbase, load_gflag(sweep, cbase), ev);
-            }
+            if (cbase == 0 && prefetched == sweep) unpack_row(evn, evn_on, ev);
+            else { bool on; const RowWords q = load_row(sweep, cbase, load_gflag(sweep, cbase), on); unpack_row(q, on, ev); }
             if (cbase == 0) {                                            // next touched sweep of this 64-block: its group flags start flying now,
                 const uint64_t later = (sweep & 63) == 63 ? 0ull : (smask >> ((sweep & 63) + 1));   // its row after the scan below
                 if (later != 0) { next_sweep = sweep + 1 + (__ffsll((unsigned long long)later) - 1); gfn = load_gflag(next_sweep, 0); }
             }
             uint32_t packed = 0;                                         // live descriptors << 20 | records
             {
-                uint16_t* rowx = row_ptr(sweep);
+                uint32_t any = 0;
 #pragma unroll
                 for (int j = 0; j < UPT; ++j) {
                     const bool live = ev[j] != 0 && u0 + j < B;
-                    if (live) rowx[u0 + j] = 0;                          // consumed: the table is all-zero again after the pass
-                    else ev[j] = 0;
+                    if (!live) ev[j] = 0;
+                    any |= ev[j];
                     packed += live ? ((1u << 20) | (ev[j] & kSegCountMask)) : 0u;
+                }
+                // consumed: one wide store of zeros over the words this thread read, so that the table is all-zero
+                // again after the pass (its other words already are)
+                if (any) {
+                    uint16_t* rowx = row_ptr(sweep) + u0;
+                    if constexpr (UPT == 8) *reinterpret_cast<uint4*>(rowx) = make_uint4(0, 0, 0, 0);
+                    else                    *reinterpret_cast<uint2*>(rowx) = make_uint2(0, 0);
                 }
             }
             if (a.dbg) { asm volatile("" :: "v"(packed)); GEM_STAMP(); }                      // 2: descriptor words arrived
             uint32_t tot;
             const uint32_t run = block_exclusive_scan<NT>(packed, scratch, &tot);
             const uint32_t nd = tot >> 20, P = tot & 0xfffffu;
-            if (next_sweep >= 0) { load_row(next_sweep, 0, gfn, evn); prefetched = next_sweep; }
+            if (next_sweep >= 0) { evn = load_row(next_sweep, 0, gfn, evn_on); prefetched = next_sweep; }
             if (P == 0) continue;                                        // block-uniform
             const uint32_t nb = (P - 1u) / Q + 1u;                       // batches 0 .. nb-2 are non-empty (a descriptor holds < Q records)
             if (nb > 1) {
@@ -491,6 +511,7 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
                 __syncthreads();
                 GEM_STAMP();                                             // 4: records in LDS, ranked
 
+                apply_increments();
                 if (misc[1] == 0) {
                     // ---- 3a. owner: sort <= 7 slot numbers, run the chains from registers.  The CPT cells
                     //      of a thread are independent chains: everything is straight-line with selects so
@@ -671,10 +692,11 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
         }
 
         // ---- variance floor at the end of every Fuse (GPU:533-534), on every cell -----------------
+        apply_increments();
 #pragma unroll
         for (int q = 0; q < CPT; ++q) if (cs[q] < a.var_floor) cs[q] = a.var_floor;
 
-        if (a.counters && (!a.count_per_pass || sweep == a.n_sweeps - 1)) {
+        if (a.counters && (!a.count_per_pass || sweep == NS - 1)) {
             __syncthreads();
             if (tmask) atomicAdd(&misc[0], (uint32_t)__popc(tmask));
             __syncthreads();
@@ -697,11 +719,11 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
 #undef GEM_STAMP
 }
 
-template <int TS, int NT, int PB, int ATTR>
+template <int TS, int NT, int PB, int ATTR, bool BATCH>
 __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_list(FuseArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
-    fuse_list_body<TS, NT, PB, ATTR>(a, (int)blockIdx.x, lds_dyn);
+    fuse_list_body<TS, NT, PB, ATTR, BATCH>(a, (int)blockIdx.x, lds_dyn);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -714,7 +736,7 @@ __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_
 __global__ __launch_bounds__(256, 4) void k_frame(FuseArgs fa, BinArgs ba)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
-    if ((int)blockIdx.x < fa.T) fuse_list_body<4, 256, 1024, 0>(fa, (int)blockIdx.x, lds_dyn);
+    if ((int)blockIdx.x < fa.T) fuse_list_body<4, 256, 1024, 0, false>(fa, (int)blockIdx.x, lds_dyn);
     else bin_wave_body<0, 4, false>(ba, (int)blockIdx.x - fa.T);
 }
 
@@ -974,21 +996,28 @@ size_t fuse_lds_bytes(int ts, int variant, int attr)
     return fuse_list_lds((1 << (2 * ts)), nt / 64, pb, attr);
 }
 
-template <int TS, int NT, int PB>
-static hipError_t launch_fuse_list(hipStream_t st, const FuseArgs& a, int attr, LaunchEvents ev)
+template <int TS, int NT, int PB, bool BATCH>
+static hipError_t launch_fuse_list_b(hipStream_t st, const FuseArgs& a, int attr, LaunchEvents ev)
 {
     const size_t lds = fuse_list_lds(1 << (2 * TS), NT / 64, PB, attr);
     static size_t configured[3] = {0, 0, 0};
     if (lds > 64 * 1024 && lds > configured[attr]) {   // more than 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel
-        const void* fn = attr == 0 ? (const void*)k_fuse_list<TS, NT, PB, 0> : attr == 1 ? (const void*)k_fuse_list<TS, NT, PB, 1> : (const void*)k_fuse_list<TS, NT, PB, 2>;
+        const void* fn = attr == 0 ? (const void*)k_fuse_list<TS, NT, PB, 0, BATCH> : attr == 1 ? (const void*)k_fuse_list<TS, NT, PB, 1, BATCH>
+                                                                                                   : (const void*)k_fuse_list<TS, NT, PB, 2, BATCH>;
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured[attr] = lds;
     }
-    if (attr == 0)      GEM_LAUNCH((k_fuse_list<TS, NT, PB, 0>), dim3(a.T), dim3(NT), lds, st, ev, a);
-    else if (attr == 1) GEM_LAUNCH((k_fuse_list<TS, NT, PB, 1>), dim3(a.T), dim3(NT), lds, st, ev, a);
-    else                GEM_LAUNCH((k_fuse_list<TS, NT, PB, 2>), dim3(a.T), dim3(NT), lds, st, ev, a);
+    if (attr == 0)      GEM_LAUNCH((k_fuse_list<TS, NT, PB, 0, BATCH>), dim3(a.T), dim3(NT), lds, st, ev, a);
+    else if (attr == 1) GEM_LAUNCH((k_fuse_list<TS, NT, PB, 1, BATCH>), dim3(a.T), dim3(NT), lds, st, ev, a);
+    else                GEM_LAUNCH((k_fuse_list<TS, NT, PB, 2, BATCH>), dim3(a.T), dim3(NT), lds, st, ev, a);
     return hipGetLastError();
+}
+
+template <int TS, int NT, int PB>
+static hipError_t launch_fuse_list(hipStream_t st, const FuseArgs& a, int attr, LaunchEvents ev)
+{
+    return a.n_sweeps > 1 ? launch_fuse_list_b<TS, NT, PB, true>(st, a, attr, ev) : launch_fuse_list_b<TS, NT, PB, false>(st, a, attr, ev);
 }
 
 hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr, int variant, LaunchEvents ev)
