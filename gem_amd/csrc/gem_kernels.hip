@@ -341,7 +341,10 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
     }
     // descriptor words of the first touched sweep: in flight before the tile itself is read, so that the
     // (larger, strided) tile loads do not sit in front of them in the memory pipeline
-    if (smask != 0) {
+    if constexpr (!BATCH) {                                              // one sweep: no branch around the load (see load_row)
+        prefetched = 0;
+        evn = load_row(0, 0, gf0, evn_on);
+    } else if (smask != 0) {
         prefetched = __ffsll((unsigned long long)smask) - 1;
         evn = load_row(prefetched, 0, prefetched == 0 ? gf0 : load_gflag(prefetched, 0), evn_on);
     }
@@ -396,7 +399,11 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
         if (a.counters && tid == 0 && (sweep == 0 || !a.count_per_pass)) misc[0] = 0;
         if (!a.count_per_pass) tmask = 0;
 
-        for (int cbase = 0; touched_sweep && cbase < B; cbase += kChunkUnits) {
+        // a single sweep holds at most kChunkUnits units (longer clouds are cut into sweeps): exactly one chunk, and no
+        // loop header at which the compiler would have to wait for every load in flight
+        const int n_chunks = !touched_sweep ? 0 : (BATCH ? (B + kChunkUnits - 1) / kChunkUnits : 1);
+        for (int ci = 0; ci < n_chunks; ++ci) {
+            const int cbase = ci * kChunkUnits;
             // ---- 1. ordered compaction of the chunk's live descriptors ----------------------------
             const int u0 = cbase + tid * UPT;
             int next_sweep = -1;
