@@ -362,6 +362,7 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     fa.epoch = pb.epoch;
     fa.rec = ba.rec; fa.seg = ba.seg; fa.flag = ba.flag; fa.gflag = ba.gflag; fa.B_total = B; fa.U = U; fa.n_sweeps = in.n_sweeps; fa.Bpad = bpad;
     fa.T = T; fa.tiles_per_row = tiles_per_row; fa.L = h->L; fa.row0 = h->row0; fa.row1 = h->row1;
+    fa.center_tr = ((h->L / 2 + h->start[0]) % h->L) >> ts; fa.center_tc = ((h->L / 2 + h->start[1]) % h->L) >> ts;
     fa.mahal = h->cfg.mahalanobis_threshold; fa.var_floor = h->cfg.variance_floor;
     fa.dense = dense ? 1 : 0;
     fa.n_pending = h->n_pending;

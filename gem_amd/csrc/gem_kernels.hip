@@ -5,7 +5,7 @@
 //   k_bin_wave   one WAVE per "unit" of 64 consecutive points: coalesced float4 XYZI loads,
 //                projection + variance + 2.5-D binning in registers, then a wave-local STABLE
 //                grouping of the unit's points by map tile (16x16 or 32x32 cells) from ballots.
-//                Emits 16-byte records {cell-in-tile, h, var, src} grouped by tile inside the unit's
+//                Emits 16-byte records {h, var, cell-in-tile, src} grouped by tile inside the unit's
 //                own slice of the record arena (no global scan, no atomics) and one 16-bit
 //                descriptor {start, count} per (sweep, tile, unit).
 //   k_fuse_list  one workgroup per tile: ordered compaction of the tile's live descriptors,
@@ -201,7 +201,7 @@ __device__ __forceinline__ void bin_wave_body(const BinArgs& a, int block)
     const uint32_t start_leader = wave_inclusive_scan(x) - x;       // groups laid out in order of first appearance
     const int my_leader = valid ? (__ffsll((unsigned long long)peers) - 1) : lane;
     const uint32_t start = (uint32_t)__shfl((int)start_leader, my_leader, 64);
-    if (valid) a.rec[(size_t)unit * U + start + rank] = make_uint4(cl, __float_as_uint(hh), __float_as_uint(vv), src);
+    if (valid) a.rec[(size_t)unit * U + start + rank] = make_uint4(__float_as_uint(hh), __float_as_uint(vv), cl, src);
     if (leader) {
         // table layout [sweep][tile][unit in sweep]: the words one sweep writes stay within T * Bpad * 4 bytes
         a.seg[((size_t)sweep * a.T + tile) * a.Bpad + (unit - unit_first)] = (uint16_t)((start << kSegCountBits) | cnt);
@@ -267,11 +267,18 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
     uint16_t* rowp    = reinterpret_cast<uint16_t*>(lds_raw);
     uint16_t* head    = rowp;
     uint16_t* tail    = head + CELLS * NW;
+    // DMA (small batches): the records are copied HBM -> LDS as they are (global_load_lds_dwordx4, no registers in
+    // between, all of a wave's loads in flight at once) into `stage`; otherwise their fields are split into s_h / s_v / s_src
+    constexpr bool DMA = PB <= 1024;
     uint16_t* nxt     = reinterpret_cast<uint16_t*>(lds_raw + XBYTES);     // [PB]
-    float*    s_h     = reinterpret_cast<float*>(nxt + PB);                // [PB]
+    uint4*    stage   = reinterpret_cast<uint4*>(nxt + PB);                // [PB] (DMA)
+    float*    s_h     = reinterpret_cast<float*>(nxt + PB);                // [PB] (!DMA)
     float*    s_v     = s_h + PB;                                          // [PB]
     uint32_t* s_src   = reinterpret_cast<uint32_t*>(s_v + PB);             // [PB] only when ATTR != 0
-    uint32_t* dl_addr = s_src + (ATTR ? PB : 0);                           // [DCAP] arena index of the first record
+    uint32_t* dl_addr = DMA ? reinterpret_cast<uint32_t*>(stage + PB) : s_src + (ATTR ? PB : 0);   // [DCAP] arena index of the first record
+    auto rec_h   = [&](uint32_t sl) -> float    { if constexpr (DMA) return __uint_as_float(stage[sl].x); else return s_h[sl]; };
+    auto rec_v   = [&](uint32_t sl) -> float    { if constexpr (DMA) return __uint_as_float(stage[sl].y); else return s_v[sl]; };
+    auto rec_src = [&](uint32_t sl) -> uint32_t { if constexpr (DMA) return (stage[sl].w & 0x7fffffffu) | (stage[sl].z & 0x80000000u); else return s_src[sl]; };
     uint32_t* dl_rc   = dl_addr + DCAP;                                    // [DCAP] record prefix << 9 | count
     uint32_t* bstart  = dl_rc + DCAP;                                      // [MAXB + 1] first descriptor of each batch
     uint32_t* scratch = bstart + MAXB + 1;                                 // [16]
@@ -280,7 +287,28 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
     const int tid = (int)threadIdx.x;
     const int lane = lane_id();
     const int w = tid >> 6;
-    const int tr = tile / a.tiles_per_row, tc = tile - tr * a.tiles_per_row;
+    // Block -> tile.  A single sweep (one launch per frame, latency matters): the map is robot-centric, so the tiles around
+    // the sensor carry most of the records.  Tiles are ranked centre-first (rows and columns c, c-1, c+1, c-2, ... mod
+    // tiles_per_row from the tile holding the map centre in storage coordinates) and rank r takes block
+    // (r mod T/4) * 4 + r div (T/4): the heaviest quarter is dispatched first AND lands one per group of four consecutive
+    // blocks, so the (up to four) workgroups resident on a CU are one heavy, one medium and two light tiles
+    // (measured: 11.7 -> 10.6 us per C2 frame; plain centre-first order, which stacks heavy tiles on a CU: 12.1 us).
+    // A batch keeps the identity mapping (every tile loops over all sweeps; the permutation cost 15 % there).
+    const int tpr = a.tiles_per_row;
+    int tr, tc;
+    if constexpr (!BATCH) {
+        const int q4 = (a.T + 3) >> 2;
+        const int rnk = (tile & 3) * q4 + (tile >> 2);
+        if (rnk >= a.T) return;
+        const int bi = rnk / tpr, bj = rnk - bi * tpr;
+        const int oi = (bi & 1) ? -((bi + 1) >> 1) : (bi >> 1), oj = (bj & 1) ? -((bj + 1) >> 1) : (bj >> 1);
+        tr = a.center_tr + oi; tr = tr < 0 ? tr + tpr : (tr >= tpr ? tr - tpr : tr);
+        tc = a.center_tc + oj; tc = tc < 0 ? tc + tpr : (tc >= tpr ? tc - tpr : tc);
+        tile = tr * tpr + tc;
+    } else {
+        if (tile >= a.T) return;
+        tr = tile / tpr; tc = tile - tr * tpr;
+    }
     const int row_base = tr << TS, col_base = tc << TS;
     const int L = a.L;
     const uint32_t epoch = a.epoch;                                      // stamps the touched flags of this pass
@@ -474,45 +502,82 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
 
                 // ---- 2 + 3a. gather into LDS in input order (record k -> slot k - slot0) and take an
                 //      arrival rank per cell for the fast path.  Wave w takes the w-th contiguous share of
-                //      the batch's descriptors, one descriptor per step (lanes < count), with the loads of
-                //      the next PF descriptors in flight while the current PF are being filed.
+                //      the batch's descriptors, one descriptor per step (lanes < count).
                 const uint32_t dw0 = (m * (uint32_t)w) / NW, dw1 = (m * (uint32_t)(w + 1)) / NW;
-                constexpr int PF = TS == 4 ? 2 : 4;
-                uint4 rA[PF], rB[PF]; uint32_t sA[PF], sB[PF];           // slot == ~0: lane inactive
-                auto fetch = [&](uint32_t dd, uint4 (&rr)[PF], uint32_t (&sl)[PF]) {
-#pragma unroll
-                    for (int x = 0; x < PF; ++x) {
-                        sl[x] = 0xffffffffu; rr[x] = make_uint4(0, 0, 0, 0);
-                        if (dd + x < dw1) {                              // wave-uniform
-                            const uint32_t rc = dl_rc[dd + x];
-                            if ((uint32_t)lane < (rc & 0x1ffu)) {
-                                sl[x] = (rc >> 9) - slot0 + (uint32_t)lane;
-                                rr[x] = a.rec[dl_addr[dd + x] + (uint32_t)lane];
-                            }
-                        }
-                    }
-                };
-                auto file_one = [&](const uint4& r, uint32_t sl) {
-                    const uint32_t cell = r.x & 0xffffu;
-                    s_h[sl] = __uint_as_float(r.y); s_v[sl] = __uint_as_float(r.z);
-                    if (ATTR) s_src[sl] = (r.w & 0x7fffffffu) | (r.x & 0x80000000u);
-                    nxt[sl] = (uint16_t)cell;                            // the generic path reads the cell from here
+                auto rank_one = [&](uint32_t cell, uint32_t sl) {
                     const uint32_t old = atomicAdd(reinterpret_cast<uint32_t*>(rowp) + cell * 4 + 3, 0x10000u);
                     const uint32_t rk = old >> 16;
                     if (rk < (uint32_t)kRankMax) rowp[cell * 8 + rk] = (uint16_t)sl;
                     else misc[1] = 1u;
                 };
-                auto file = [&](const uint4 (&rr)[PF], const uint32_t (&sl)[PF]) {
+                if constexpr (DMA) {
+                    // lane i fetches the wave's i-th descriptor; each is then broadcast (v_readlane) and turned into ONE
+                    // global_load_lds_dwordx4 whose LDS base is the descriptor's first slot: nothing waits until all are issued
+                    for (uint32_t dbase = dw0; dbase < dw1; dbase += 64) {             // wave-uniform
+                        const uint32_t nhere = min(64u, dw1 - dbase);
+                        uint32_t my_rc = 0, my_addr = 0;
+                        if ((uint32_t)lane < nhere) { my_rc = dl_rc[dbase + lane]; my_addr = dl_addr[dbase + lane]; }
+                        for (uint32_t i = 0; i < nhere; ++i) {
+                            const uint32_t rc = (uint32_t)__builtin_amdgcn_readlane((int)my_rc, (int)i);
+                            const uint32_t adr = (uint32_t)__builtin_amdgcn_readlane((int)my_addr, (int)i);
+                            if ((uint32_t)lane < (rc & 0x1ffu))
+                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.rec + adr + (uint32_t)lane),
+                                                                 (__attribute__((address_space(3))) void*)(stage + ((rc >> 9) - slot0)), 16, 0, 0);
+                        }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    const uint32_t first = (dl_rc[0] >> 9) - slot0;                     // slots of the batch: [first, first + Pb)
+                    const uint32_t Pb = (dl_rc[m - 1] >> 9) + (dl_rc[m - 1] & 0x1ffu) - (dl_rc[0] >> 9);
+                    // PB / NT slots per thread: all cell reads, then all rank atomics, then all row writes in flight together
+                    constexpr int RK = PB / NT;
+                    uint32_t rcell[RK], rold[RK];
 #pragma unroll
-                    for (int x = 0; x < PF; ++x) if (sl[x] != 0xffffffffu) file_one(rr[x], sl[x]);
-                };
-                if (dw0 < dw1) {
-                    fetch(dw0, rA, sA);
-                    for (uint32_t dd = dw0; dd < dw1; dd += 2 * PF) {   // wave-uniform
-                        fetch(dd + PF, rB, sB);
-                        file(rA, sA);
-                        fetch(dd + 2 * PF, rA, sA);
-                        file(rB, sB);
+                    for (int r = 0; r < RK; ++r) { const uint32_t k = (uint32_t)(tid + r * NT); rcell[r] = k < Pb ? (stage[first + k].z & 0xffffu) : 0u; }
+#pragma unroll
+                    for (int r = 0; r < RK; ++r) { const uint32_t k = (uint32_t)(tid + r * NT); rold[r] = 0; if (k < Pb) rold[r] = atomicAdd(reinterpret_cast<uint32_t*>(rowp) + rcell[r] * 4 + 3, 0x10000u); }
+#pragma unroll
+                    for (int r = 0; r < RK; ++r) {
+                        const uint32_t k = (uint32_t)(tid + r * NT);
+                        if (k < Pb) { const uint32_t rk = rold[r] >> 16; if (rk < (uint32_t)kRankMax) rowp[rcell[r] * 8 + rk] = (uint16_t)(first + k); else misc[1] = 1u; }
+                    }
+                } else {
+                    // through registers, the loads of the next PF descriptors in flight while the current PF are being filed
+                    constexpr int PF = 4;
+                    uint4 rA[PF], rB[PF]; uint32_t sA[PF], sB[PF];       // slot == ~0: lane inactive
+                    auto fetch = [&](uint32_t dd, uint4 (&rr)[PF], uint32_t (&sl)[PF]) {
+#pragma unroll
+                        for (int x = 0; x < PF; ++x) {
+                            sl[x] = 0xffffffffu; rr[x] = make_uint4(0, 0, 0, 0);
+                            if (dd + x < dw1) {                          // wave-uniform
+                                const uint32_t rc = dl_rc[dd + x];
+                                if ((uint32_t)lane < (rc & 0x1ffu)) {
+                                    sl[x] = (rc >> 9) - slot0 + (uint32_t)lane;
+                                    rr[x] = a.rec[dl_addr[dd + x] + (uint32_t)lane];
+                                }
+                            }
+                        }
+                    };
+                    auto file = [&](const uint4 (&rr)[PF], const uint32_t (&sl)[PF]) {
+#pragma unroll
+                        for (int x = 0; x < PF; ++x) {
+                            if (sl[x] != 0xffffffffu) {
+                                const uint32_t cell = rr[x].z & 0xffffu;
+                                s_h[sl[x]] = __uint_as_float(rr[x].x); s_v[sl[x]] = __uint_as_float(rr[x].y);
+                                if (ATTR) s_src[sl[x]] = (rr[x].w & 0x7fffffffu) | (rr[x].z & 0x80000000u);
+                                nxt[sl[x]] = (uint16_t)cell;             // the generic path reads the cell from here
+                                rank_one(cell, sl[x]);
+                            }
+                        }
+                    };
+                    if (dw0 < dw1) {
+                        fetch(dw0, rA, sA);
+                        for (uint32_t dd = dw0; dd < dw1; dd += 2 * PF) {   // wave-uniform
+                            fetch(dd + PF, rB, sB);
+                            file(rA, sA);
+                            fetch(dd + 2 * PF, rA, sA);
+                            file(rB, sB);
+                        }
                     }
                 }
                 __syncthreads();
@@ -552,8 +617,8 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
 #pragma unroll
                         for (int q = 0; q < CPT; ++q) {
                             const uint32_t sl = (uint32_t)i < n[q] ? ps[q][i] : 0u;       // slot 0 is always a valid address
-                            hh[q][i] = s_h[sl]; vv[q][i] = s_v[sl];
-                            if (ATTR) sv[q][i] = s_src[sl];
+                            hh[q][i] = rec_h(sl); vv[q][i] = rec_v(sl);
+                            if (ATTR) sv[q][i] = rec_src(sl);
                         }
                     }
                     uint32_t wlast[CPT];
@@ -607,7 +672,8 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
                         for (uint32_t kc = kbeg; kc < kend; kc += 64) {   // wave-uniform
                             const bool on = kc + (uint32_t)lane < kend;
                             const uint32_t sl = k_lo - slot0 + kc + (uint32_t)lane;
-                            const uint32_t cell = on ? (uint32_t)nxt[sl] : 0u;
+                            uint32_t cell = 0u;
+                            if (on) { if constexpr (DMA) cell = stage[sl].z & 0xffffu; else cell = nxt[sl]; }
                             const uint64_t peers = wave_peers(on, cell, 2 * TS);
                             const uint64_t above = lane == 63 ? 0ull : (peers & (~0ull << (lane + 1)));
                             if (on) {
@@ -651,12 +717,12 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
                             for (int q = 0; q < CPT; ++q) {
                                 const bool live = cur[q] != NIL;
                                 const uint32_t sl = live ? cur[q] : 0u;
-                                const float h = s_h[sl], v = s_v[sl];
+                                const float h = rec_h(sl), v = rec_v(sl);
                                 uint32_t nx = nxt[sl];
                                 float e2 = ce[q], s2 = cs[q];
                                 const bool taken = fuse_step(e2, s2, h, v, a.mahal, a.var_floor);
                                 ce[q] = live ? e2 : ce[q]; cs[q] = live ? s2 : cs[q];
-                                if (ATTR) { const uint32_t sv = s_src[sl]; if (live && taken && (sv & 0x80000000u)) wl[q] = sv & 0x7fffffffu; }
+                                if (ATTR) { const uint32_t sv = rec_src(sl); if (live && taken && (sv & 0x80000000u)) wl[q] = sv & 0x7fffffffu; }
                                 if (live && nx == NIL) {                 // end of this wave's list: continue with the next non-empty one
                                     uint32_t nw_ = NW;
 #pragma unroll
@@ -743,8 +809,9 @@ __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_
 __global__ __launch_bounds__(256, 4) void k_frame(FuseArgs fa, BinArgs ba)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
-    if ((int)blockIdx.x < fa.T) fuse_list_body<4, 256, 1024, 0, false>(fa, (int)blockIdx.x, lds_dyn);
-    else bin_wave_body<0, 4, false>(ba, (int)blockIdx.x - fa.T);
+    const int nf = (fa.T + 3) & ~3;                                      // fuse blocks (see the block -> tile mapping)
+    if ((int)blockIdx.x < nf) fuse_list_body<4, 256, 1024, 0, false>(fa, (int)blockIdx.x, lds_dyn);
+    else bin_wave_body<0, 4, false>(ba, (int)blockIdx.x - nf);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -981,7 +1048,7 @@ static size_t fuse_list_lds(int cells, int nw, int pb, int attr)
     const size_t dcap = pb < kChunkUnits ? pb : kChunkUnits;
     size_t b = x
              + (size_t)pb * 2                          // nxt
-             + (size_t)pb * 4 * (attr ? 3 : 2)         // s_h, s_v (, s_src)
+             + (pb <= 1024 ? (size_t)pb * 16 : (size_t)pb * 4 * (attr ? 3 : 2))   // stage | s_h, s_v (, s_src)
              + dcap * 4 * 2                            // dl_addr, dl_rc
              + (size_t)(fuse_list_max_batches(pb) + 1) * 4
              + 16 * 4 + 16;                            // scratch, misc
@@ -1015,9 +1082,9 @@ static hipError_t launch_fuse_list_b(hipStream_t st, const FuseArgs& a, int attr
         if (e != hipSuccess) return e;
         configured[attr] = lds;
     }
-    if (attr == 0)      GEM_LAUNCH((k_fuse_list<TS, NT, PB, 0, BATCH>), dim3(a.T), dim3(NT), lds, st, ev, a);
-    else if (attr == 1) GEM_LAUNCH((k_fuse_list<TS, NT, PB, 1, BATCH>), dim3(a.T), dim3(NT), lds, st, ev, a);
-    else                GEM_LAUNCH((k_fuse_list<TS, NT, PB, 2, BATCH>), dim3(a.T), dim3(NT), lds, st, ev, a);
+    if (attr == 0)      GEM_LAUNCH((k_fuse_list<TS, NT, PB, 0, BATCH>), dim3((a.T + 3) & ~3), dim3(NT), lds, st, ev, a);
+    else if (attr == 1) GEM_LAUNCH((k_fuse_list<TS, NT, PB, 1, BATCH>), dim3((a.T + 3) & ~3), dim3(NT), lds, st, ev, a);
+    else                GEM_LAUNCH((k_fuse_list<TS, NT, PB, 2, BATCH>), dim3((a.T + 3) & ~3), dim3(NT), lds, st, ev, a);
     return hipGetLastError();
 }
 
@@ -1039,7 +1106,7 @@ hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr, int 
 // fuse of the previous frame + bin of this one (single sweeps on 16x16 tiles, no attributes)
 hipError_t launch_frame(hipStream_t st, const FuseArgs& fa, const BinArgs& ba, LaunchEvents ev)
 {
-    const dim3 grid(fa.T + (ba.B + 3) / 4), block(256);
+    const dim3 grid(((fa.T + 3) & ~3) + (ba.B + 3) / 4), block(256);
     GEM_LAUNCH((k_frame), grid, block, fuse_list_lds(256, 4, 1024, 0), st, ev, fa, ba);
     return hipGetLastError();
 }

@@ -64,6 +64,7 @@ struct FuseArgs {
     const int* sweep_unit0;            // [n_sweeps+1] (NULL when n_sweeps == 1: units [0, B_total))
     int   Bpad;                        // units of the longest sweep: row length of seg
     int   T, tiles_per_row, L;
+    int   center_tr, center_tc;        // tile holding the map centre (storage coordinates): blocks are mapped to tiles centre-first
     int   row0, row1;                  // owned storage rows
     float mahal, var_floor;
     int   dense;                       // 1: visit every tile (pending variance increments / floor not yet established)
