@@ -86,7 +86,7 @@ def pmc_traffic(kernel_prefix: str):
     return best
 
 
-def batched_c4(emap_cls, dev, torch, reps: int = 10):
+def batched_c4(emap_cls, dev, torch, reps: int = 20):
     """Secondary figure: BASELINE configs[3] -- 32 consecutive sweeps with a variance increment before each,
     one gem_add_batch_device call (the regime in which the path is bandwidth- rather than launch-bound)."""
     from gem_amd import synth
@@ -94,7 +94,7 @@ def batched_c4(emap_cls, dev, torch, reps: int = 10):
     cat = torch.from_numpy(np.concatenate(wl.clouds)).to(dev)
     off = np.concatenate([[0], np.cumsum([c.shape[0] for c in wl.clouds])])
     m = emap_cls(wl.length, wl.resolution, device=dev.index)
-    for _ in range(3):
+    for _ in range(6):
         m.add_batch(wl.frames, cat, off, wl.var_updates)
     m.synchronize()
     t0 = time.perf_counter()
