@@ -1,0 +1,79 @@
+"""Randomised call sequences against the oracle: the order of operations the caller sees must be the order the
+map sees, whatever the library does underneath (deferred fusion of the newest frame in k_frame, queued variance
+increments folded into the next pass, double-buffered arenas, big clouds cut into sweeps, batched calls)."""
+import numpy as np
+import pytest
+
+from gem_amd import ElevationMap, SensorModel, synth
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def lidar_like(rng, n, extent):
+    c = synth.random_cloud(int(rng.integers(1 << 30)), n, extent, z_sigma=0.2, dup_fraction=0.2)
+    return c
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_call_sequence(oracle_mod, seed):
+    import torch
+    rng = np.random.default_rng(seed)
+    L, res = (96, 0.1) if seed % 2 else (75, 0.2)
+    gpu, ref = ElevationMap(L, res), oracle_mod.OracleMap(L, res)
+    frame = synth._frame_for(synth.pose_matrix(0.1, -0.2, 0.0, yaw=0.3), SensorModel.velodyne())
+    extent = 0.5 * L * res * 1.1
+    checks = 0
+    for step in range(60):
+        op = rng.choice(["add_dev", "add_dev", "add_dev", "add_host", "fuse", "batch", "var", "move", "get", "feature", "optmove", "big"])
+        if op == "add_dev":
+            c = lidar_like(rng, int(rng.integers(1, 6000)), extent)
+            gpu.add(frame, torch.from_numpy(c).cuda()); ref.add(frame, c)
+        elif op == "add_host":
+            c = lidar_like(rng, int(rng.integers(0, 3000)), extent)
+            rgb = rng.integers(0, 1 << 24, c.shape[0]).astype(np.uint32) if rng.random() < 0.5 else None
+            gpu.add(frame, c, rgb=rgb); ref.add(frame, c, rgb=rgb)
+        elif op == "fuse":
+            c = lidar_like(rng, int(rng.integers(1, 2000)), extent)
+            g = gpu.process_points(frame, c[:, 0], c[:, 1], c[:, 2]); o = ref.process_points(frame, c[:, 0], c[:, 1], c[:, 2])
+            assert np.array_equal(g["index"], o["index"])
+            gpu.fuse(g["index"], g["height"], g["var"]); ref.fuse(o["index"], o["height"], o["var"])
+        elif op == "batch":
+            ns = int(rng.integers(2, 5))
+            clouds = [lidar_like(rng, int(rng.integers(0, 4000)), extent) for _ in range(ns)]
+            vu = [float(rng.uniform(0, 3e-5)) for _ in range(ns)] if rng.random() < 0.6 else None
+            off = np.concatenate([[0], np.cumsum([c.shape[0] for c in clouds])])
+            if off[-1] == 0:
+                continue
+            gpu.add_batch([frame] * ns, torch.from_numpy(np.concatenate(clouds)).cuda(), off, vu)
+            for k in range(ns):
+                if vu is not None:
+                    ref.mapvar_update(vu[k])
+                ref.add(frame, clouds[k])
+        elif op == "var":
+            u = float(rng.uniform(0, 5e-5))
+            gpu.mapvar_update(u); ref.mapvar_update(u)
+        elif op == "move":
+            p = np.array([rng.uniform(-1.0, 1.0), rng.uniform(-1.0, 1.0), 0.0], F32)
+            g = gpu.move(p); o = ref.move(p)
+            assert np.array_equal(np.asarray(g[0], F32), np.asarray(o[0], F32)) and tuple(g[1]) == tuple(o[1])
+        elif op == "optmove":
+            xy = [float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.5, 0.5))]
+            dz = float(rng.uniform(-0.05, 0.05))
+            assert np.array_equal(gpu.map_optmove(xy, dz), ref.map_optmove(xy, dz))
+        elif op == "feature":
+            g, o = gpu.map_feature(), ref.map_feature()
+            assert np.array_equal(g["traver"] == -10, o["traver"] == -10)
+            assert np.max(np.abs(g["slope"] - o["slope"])) <= 2e-3 and np.max(np.abs(g["rough"] - o["rough"])) <= 1e-6
+            gpu.set_layer("traver", o["traver"])            # keep the two maps bit-identical for the rest of the sequence
+        elif op == "big":
+            c = lidar_like(rng, 140_000, extent)            # > 131072 points: cut into sweeps internally
+            gpu.add(frame, torch.from_numpy(c).cuda()); ref.add(frame, c)
+        if op == "get" or step % 13 == 12:
+            for name in ("elevation", "variance"):
+                g, o = gpu.layer(name), ref.layer(name)
+                assert np.array_equal(g, o), f"seed {seed} step {step} ({op}): {name} differs in {np.count_nonzero(g != o)} cells"
+            checks += 1
+    for name in ("elevation", "variance", "intensity", "color_r"):
+        assert np.array_equal(gpu.layer(name), ref.layer(name)), name
+    assert checks >= 3

@@ -17,7 +17,13 @@ d = [torch.from_numpy(c).cuda() for c in wl.clouds]
 for k in range(3):
     m.add(wl.frames[k], d[k])
 lib.gem_debug_fuse_stamps(m._h, 1, None, 0)
-m.add(wl.frames[3], d[3])
+if len(sys.argv) > 1 and sys.argv[1] == "batch":     # first sweeps of a batched call (16 stamps per tile = ~3 sweeps)
+    import numpy as _np
+    cat = torch.from_numpy(_np.concatenate(wl.clouds)).cuda()
+    off = _np.concatenate([[0], _np.cumsum([c.shape[0] for c in wl.clouds])])
+    m.add_batch(wl.frames, cat, off, wl.var_updates)
+else:
+    m.add(wl.frames[3], d[3])
 T = 4096
 buf = np.zeros((T, 16), np.uint64)
 n = lib.gem_debug_fuse_stamps(m._h, 0, buf.ctypes.data_as(C.c_void_p), T)
@@ -33,7 +39,7 @@ for label, idx in (("slowest", order[:3]), ("median", order[len(order) // 2: len
     for i in idx:
         s = st[i, :nb[i]]
         print(label, "tile", i, "stamps", nb[i], "total", tot[i], "start@", s[0] - t0, "deltas", list(np.diff(s)))
-full = nb == 10
+full = nb == 99
 if full.any():
     dd = np.diff(st[full, :10], axis=1)
     print("mean deltas over single-batch tiles:", dict(zip(names[1:], dd.mean(0).astype(int))))
