@@ -236,8 +236,8 @@ __global__ __launch_bounds__(256) void k_bin_wave(BinArgs a) { bin_wave_body<SRC
 //      one wave instruction are chained by a ballot match), and the owner walks list(wave 0),
 //      list(wave 1), ... -- input order by construction, any multiplicity.
 // The tile's elevation / variance are read once and written once.  LDS is sized by the tile:
-// 16x16 tiles with PB = 1024 need ~26 KB (6 workgroups per CU, so the latencies of one tile's
-// phases hide behind other tiles), 32x32 tiles with PB = 4096 ~ 88 KB.
+// 16x16 tiles with PB = 1024 need ~31 KB (four workgroups per CU, VGPR-limited, so the latencies of
+// one tile's phases hide behind other tiles), 32x32 tiles with PB = 2048 ~ 69 KB (two per CU).
 constexpr int kChunkUnits = 2048;        // descriptor words scanned per block pass
 constexpr int kRankMax    = 7;           // fast path: records per cell and batch
 constexpr int fuse_list_max_batches(int pb) { return kChunkUnits * 64 / (pb - 64) + 2; }

@@ -135,6 +135,12 @@ int  gem_fuse(gem_handle* h, int n, const int* index, const int* R, const int* G
  *      Nothing returns to the host.  This is the ElevationMap::add-shaped entry.                  */
 int  gem_add(gem_handle* h, const gem_frame_params* p, int n, const float* xyzi,
              const uint32_t* rgb, const int* orig_index);
+/*      gem_add_device takes device pointers and only enqueues.  The buffers must be complete when the call is
+ *      made and stay untouched until gem_synchronize (or any call that returns map data) -- they are not ordered
+ *      against the handle's internal streams.  The order of operations the caller issues is the order the map sees;
+ *      underneath, a stream of single colourless sweeps runs as ONE launch per frame (binning of the new cloud next
+ *      to the fusion of the previous frame's records), the newest frame's fusion being launched by the next call
+ *      that needs it.                                                                                          */
 int  gem_add_device(gem_handle* h, const gem_frame_params* p, int n, const void* d_xyzi,
                     const void* d_rgb, const void* d_orig_index);
 
