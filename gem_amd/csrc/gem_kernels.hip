@@ -879,7 +879,7 @@ __global__ __launch_bounds__(256) void k_export_gridmap(const void* __restrict__
 
 // ------------------------------------------------------------------------------------------
 // k_map_feature : traversability stage that follows the fusion every frame (G_Mapfeature,
-// GPU:549-670, with the Jacobi eigen-solver computerEigenvalue, GPU:66-187).  One thread per cell:
+// GPU:549-670, with the Jacobi eigen-solver computerEigenvalue, GPU:66-187).  One thread per cell, one workgroup per 16x16 cells:
 // plane fit over the valid cells of the 5x5 neighbourhood (bounds in unrolled coordinates, wrapped
 // storage reads -- and, like the reference, STORAGE coordinates times the resolution as x / y), smallest
 // eigenvector -> slope, |h - mean z| -> roughness, traver = 0.5 (1 - slope/0.6) + 0.5 (1 - rough/0.2).
@@ -897,47 +897,62 @@ __global__ __launch_bounds__(256) void k_map_feature(const float* __restrict__ e
                                                      float* __restrict__ rough, float* __restrict__ slope,
                                                      int L, float res, int sx, int sy, int row0, int row1)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= L * L) return;
-    const int cell_x = idx / L, cell_y = idx - cell_x * L;
+    // one workgroup per 16x16 block of storage cells; the block and its 2-cell halo (storage wrap-around) are staged
+    // in LDS once: 400 loads per 256 cells instead of 50 per cell
+    __shared__ float zt[20 * 20];
+    const int tiles = (L + 15) >> 4;
+    const int tr_ = (int)blockIdx.x / tiles, tc_ = (int)blockIdx.x - tr_ * tiles;
+    const int R0 = tr_ << 4, C0 = tc_ << 4;
+    for (int t = (int)threadIdx.x; t < 400; t += 256) {
+        const int i = t / 20, j = t - i * 20;
+        int px = R0 - 2 + i; px = px < 0 ? px + L : (px >= L ? px - L : px); px = px >= L ? px - L : px;
+        int py = C0 - 2 + j; py = py < 0 ? py + L : (py >= L ? py - L : py); py = py >= L ? py - L : py;
+        zt[t] = elevation[px * L + py];
+    }
+    __syncthreads();
+    const int ly = (int)threadIdx.x >> 4, lx = (int)threadIdx.x & 15;
+    const int cell_x = R0 + ly, cell_y = C0 + lx;
+    if (cell_x >= L || cell_y >= L) return;
     if (cell_x < row0 || cell_x >= row1) return;                       // multi-GPU: only the owned strip
-    const float height = elevation[idx];
+    const int idx = cell_x * L + cell_y;
+    const float height = zt[(ly + 2) * 20 + lx + 2];
     float r_out = 0.0f, s_out = 0.0f;
     if (height != kEmptyElevation) {                                    // GPU:581
         int gx = cell_x + L - sx; if (gx >= L) gx -= L;                 // unrolled index of the cell, GPU:587-588
         int gy = cell_y + L - sy; if (gy >= L) gy -= L;
+        // per row / column of the window: inside the map in unrolled coordinates (GPU:587-593)?  storage coordinate
+        // (wrapped, GPU:596-600) times the resolution
+        bool rv[5], cv[5]; float xs[5], ys[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int ex = gx + k - 2, ey = gy + k - 2;
+            rv[k] = ex >= 0 && ex < L; cv[k] = ey >= 0 && ey < L;
+            int px = cell_x + k - 2; px = px < 0 ? px + L : (px >= L ? px - L : px);
+            int py = cell_y + k - 2; py = py < 0 ? py + L : (py >= L ? py - L : py);
+            xs[k] = (float)px * res; ys[k] = (float)py * res;
+        }
         float mx = 0.0f, my = 0.0f, mz = 0.0f;
         int n = 0;
 #pragma unroll
-        for (int i = -2; i < 3; ++i)
+        for (int i = 0; i < 5; ++i)
 #pragma unroll
-            for (int j = -2; j < 3; ++j) {
-                const int ex = gx + i, ey = gy + j;
-                if (ex >= 0 && ex < L && ey >= 0 && ey < L) {
-                    int px = cell_x + i; px = px < 0 ? px + L : (px >= L ? px - L : px);     // GPU:596-600
-                    int py = cell_y + j; py = py < 0 ? py + L : (py >= L ? py - L : py);
-                    const float z = elevation[px * L + py];
-                    if (z != kEmptyElevation) { mx = mx + (float)px * res; my = my + (float)py * res; mz = mz + z; ++n; }
-                }
+            for (int j = 0; j < 5; ++j) {
+                const float z = zt[(ly + i) * 20 + lx + j];
+                if (rv[i] && cv[j] && z != kEmptyElevation) { mx = mx + xs[i]; my = my + ys[j]; mz = mz + z; ++n; }
             }
         float tr = -10.0f;                                              // GPU:660-666
         if (n > 7) {
             mx = mx / (float)n; my = my / (float)n; mz = mz / (float)n;
             float a00 = 0.f, a11 = 0.f, a22 = 0.f, a01 = 0.f, a02 = 0.f, a12 = 0.f;
 #pragma unroll
-            for (int i = -2; i < 3; ++i)
+            for (int i = 0; i < 5; ++i)
 #pragma unroll
-                for (int j = -2; j < 3; ++j) {
-                    const int ex = gx + i, ey = gy + j;
-                    if (ex >= 0 && ex < L && ey >= 0 && ey < L) {
-                        int px = cell_x + i; px = px < 0 ? px + L : (px >= L ? px - L : px);
-                        int py = cell_y + j; py = py < 0 ? py + L : (py >= L ? py - L : py);
-                        const float z = elevation[px * L + py];
-                        if (z != kEmptyElevation) {                     // GPU:624-635
-                            const float dx = (float)px * res - mx, dy = (float)py * res - my, dz = z - mz;
-                            a00 = a00 + dx * dx; a11 = a11 + dy * dy; a22 = a22 + dz * dz;
-                            a01 = a01 + dx * dy; a02 = a02 + dx * dz; a12 = a12 + dy * dz;
-                        }
+                for (int j = 0; j < 5; ++j) {
+                    const float z = zt[(ly + i) * 20 + lx + j];
+                    if (rv[i] && cv[j] && z != kEmptyElevation) {       // GPU:624-635
+                        const float dx = xs[i] - mx, dy = ys[j] - my, dz = z - mz;
+                        a00 = a00 + dx * dx; a11 = a11 + dy * dy; a22 = a22 + dz * dz;
+                        a01 = a01 + dx * dy; a02 = a02 + dx * dz; a12 = a12 + dy * dz;
                     }
                 }
             // ---- computerEigenvalue (GPU:66-187), dbEps = 0.01, nJt = 30 ----
@@ -982,7 +997,8 @@ __global__ __launch_bounds__(256) void k_map_feature(const float* __restrict__ e
             float mn = a00, nz = v20;
             if (mn > a11) { mn = a11; nz = v21; }
             if (mn > a22) { mn = a22; nz = v22; }
-            const float Slope = nz > 0 ? f_acos(nz) : f_acos(-nz);     // GPU:647-650
+            const float anz = nz > 0 ? nz : -nz;                        // GPU:647-650; acos(1) is exactly 0: spare flat cells the double acos
+            const float Slope = anz == 1.0f ? 0.0f : f_acos(anz);
             const float Rough = fabsf(height - mz);
             tr = (float)(0.5 * (1.0 - (double)Slope / 0.6) + 0.5 * (1.0 - ((double)Rough / 0.2)));   // GPU:653
             s_out = Slope; r_out = Rough;
@@ -1143,7 +1159,8 @@ hipError_t launch_update_height(hipStream_t st, float* elevation, int cells, flo
 hipError_t launch_map_feature(hipStream_t st, const float* elevation, float* traver, float* rough, float* slope,
                               int L, float res, int sx, int sy, int row0, int row1)
 {
-    hipLaunchKernelGGL(k_map_feature, dim3((L * L + 255) / 256), dim3(256), 0, st, elevation, traver, rough, slope, L, res, sx, sy, row0, row1);
+    const int tiles = (L + 15) / 16;
+    hipLaunchKernelGGL(k_map_feature, dim3(tiles * tiles), dim3(256), 0, st, elevation, traver, rough, slope, L, res, sx, sy, row0, row1);
     return hipGetLastError();
 }
 
