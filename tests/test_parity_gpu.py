@@ -399,3 +399,27 @@ def test_big_single_cloud_is_cut_into_sweeps(oracle_mod):
     f2 = synth._frame_for(np.eye(4), SensorModel.velodyne())
     gpu2.add(f2, c2); ref2.add(f2, c2)
     assert_maps_match(gpu2, ref2)
+
+
+# ---- the one-launch-per-frame stream (k_frame: fuse of the previous sweep + binning of the new one) -----------------------
+def test_device_sweep_stream(oracle_mod):
+    import torch
+    wl = synth.config_c4(n_sweeps=6)
+    gpu, ref = make_pair(oracle_mod, wl.length, wl.resolution)
+    d = [torch.from_numpy(c).to("cuda:0") for c in wl.clouds]
+    gpu.set_timing(True)
+    for k in range(6):                                   # add, add, ... : the fuse of frame k runs inside the launch of frame k+1
+        if k == 3:
+            gpu.mapvar_update(2e-5); ref.mapvar_update(2e-5)
+        gpu.add(wl.frames[k], d[k]); ref.add(wl.frames[k], wl.clouds[k])
+        if k in (1, 4):
+            assert_maps_match(gpu, ref)                  # observing the map flushes the pending fuse
+    assert_maps_match(gpu, ref)
+    assert gpu.stats()["launches_frame"] >= 3            # the merged kernel is what ran
+    # dense clusters through the device path: more than 7 records per cell and batch
+    gpu, ref = make_pair(oracle_mod, 40, 0.1)
+    c = synth.random_cloud(23, 90_000, 2.2, z_sigma=0.05)
+    f = synth._frame_for(np.eye(4), SensorModel.velodyne())
+    for _ in range(2):
+        gpu.add(f, torch.from_numpy(c).to("cuda:0")); ref.add(f, c)
+    assert_maps_match(gpu, ref)
