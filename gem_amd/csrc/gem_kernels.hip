@@ -335,8 +335,7 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
     // the row words of a thread stay packed (one 16- or 8-byte register group) until they are needed: unpacking
     // at the load would make the compiler wait for the load right there
     using RowWords = typename std::conditional<UPT == 8, uint4, uint2>::type;
-    auto load_row = [&](int sweep, int cbase, uint32_t gf, bool& on) -> RowWords {
-        const int Bx = BATCH ? a.sweep_unit0[sweep + 1] - a.sweep_unit0[sweep] : a.B_total;
+    auto load_row = [&](int sweep, int Bx, int cbase, uint32_t gf, bool& on) -> RowWords {
         const uint16_t* segx = row_ptr(sweep);
         const int u0 = cbase + tid * UPT;                                // rows are padded to 32 units
         // clamped address instead of a branch around the load: the number of loads in flight stays known
@@ -360,6 +359,23 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
     uint32_t gfn = 0;
     int prefetched = -1;                                                 // sweep whose first chunk sits in evn
 
+    // Batched call: the per-sweep tables are fetched once per block of 64 sweeps, one entry per lane, and read back with
+    // v_readlane (a struct-of-pointers kernel argument carries no noalias information, so indexing them per sweep
+    // would be a VECTOR load followed by a full wait -- three memory latencies per sweep and tile)
+    int su0 = 0, su1 = 0; float vuv = 0.0f;
+    auto sweep_tables = [&](int sbase) {
+        if constexpr (BATCH) {
+            const int sidx = sbase + lane < NS ? sbase + lane : NS - 1;
+            su0 = a.sweep_unit0[sidx]; su1 = a.sweep_unit0[sidx + 1];
+            vuv = var_updates ? var_updates[sidx] : 0.0f;
+        }
+    };
+    auto units_of = [&](int sweep) -> int {                              // units of a sweep of the current block of 64
+        if constexpr (BATCH) return __builtin_amdgcn_readlane(su1, sweep & 63) - __builtin_amdgcn_readlane(su0, sweep & 63);
+        else return a.B_total;
+    };
+    sweep_tables(0);
+
     // does this tile receive any point of this pass?
     uint64_t smask = sweep_mask(0);
     {
@@ -371,10 +387,10 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
     // (larger, strided) tile loads do not sit in front of them in the memory pipeline
     if constexpr (!BATCH) {                                              // one sweep: no branch around the load (see load_row)
         prefetched = 0;
-        evn = load_row(0, 0, gf0, evn_on);
+        evn = load_row(0, a.B_total, 0, gf0, evn_on);
     } else if (smask != 0) {
         prefetched = __ffsll((unsigned long long)smask) - 1;
-        evn = load_row(prefetched, 0, prefetched == 0 ? gf0 : load_gflag(prefetched, 0), evn_on);
+        evn = load_row(prefetched, units_of(prefetched), 0, prefetched == 0 ? gf0 : load_gflag(prefetched, 0), evn_on);
     }
 
     // ---- the single read of the tile ---------------------------------------------------------------
@@ -401,13 +417,13 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
 
     uint32_t tmask = 0;                                                  // cells of this thread touched in this sweep (or pass)
     for (int sweep = 0; sweep < NS; ++sweep) {
-        if (sweep != 0 && (sweep & 63) == 0) smask = sweep_mask(sweep);
+        if (sweep != 0 && (sweep & 63) == 0) { smask = sweep_mask(sweep); sweep_tables(sweep); }
         const bool touched_sweep = (smask >> (sweep & 63)) & 1ull;       // block-uniform
         // a sweep that neither reaches this tile nor carries a variance increment changes nothing
         // (the floor below is idempotent and has been applied by an earlier sweep or is applied by a later one)
         if (!touched_sweep && !var_updates && sweep != 0 && sweep != NS - 1) continue;
-        const int ub = BATCH ? a.sweep_unit0[sweep] : 0;                 // multiple of 32 (host pads sweeps)
-        const int ue = BATCH ? a.sweep_unit0[sweep + 1] : a.B_total;
+        const int ub = BATCH ? __builtin_amdgcn_readlane(su0, sweep & 63) : 0;        // multiple of 32 (host pads sweeps)
+        const int ue = BATCH ? __builtin_amdgcn_readlane(su1, sweep & 63) : a.B_total;
         const int B = ue - ub;
 
         // ---- Mapvar_update increments queued before this sweep (GPU:540-547): applied lazily, right before
@@ -421,7 +437,7 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
             for (int q = 0; q < CPT; ++q) {
                 if (sweep == 0)
                     for (int k = 0; k < a.n_pending; ++k) if (cs[q] != kInitVariance) cs[q] += a.pending[k];
-                if (var_updates) { if (cs[q] != kInitVariance) cs[q] += var_updates[sweep]; }
+                if (var_updates) { const float u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vuv), sweep & 63)); if (cs[q] != kInitVariance) cs[q] += u; }
             }
         };
         if (a.counters && tid == 0 && (sweep == 0 || !a.count_per_pass)) misc[0] = 0;
@@ -436,7 +452,7 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
             const int u0 = cbase + tid * UPT;
             int next_sweep = -1;
             if (cbase == 0 && prefetched == sweep) unpack_row(evn, evn_on, ev);
-            else { bool on; const RowWords q = load_row(sweep, cbase, load_gflag(sweep, cbase), on); unpack_row(q, on, ev); }
+            else { bool on; const RowWords q = load_row(sweep, B, cbase, load_gflag(sweep, cbase), on); unpack_row(q, on, ev); }
             if (cbase == 0) {                                            // next touched sweep of this 64-block: its group flags start flying now,
                 const uint64_t later = (sweep & 63) == 63 ? 0ull : (smask >> ((sweep & 63) + 1));   // its row after the scan below
                 if (later != 0) { next_sweep = sweep + 1 + (__ffsll((unsigned long long)later) - 1); gfn = load_gflag(next_sweep, 0); }
@@ -463,7 +479,7 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
             uint32_t tot;
             const uint32_t run = block_exclusive_scan<NT>(packed, scratch, &tot);
             const uint32_t nd = tot >> 20, P = tot & 0xfffffu;
-            if (next_sweep >= 0) { evn = load_row(next_sweep, 0, gfn, evn_on); prefetched = next_sweep; }
+            if (next_sweep >= 0) { evn = load_row(next_sweep, units_of(next_sweep), 0, gfn, evn_on); prefetched = next_sweep; }
             if (P == 0) continue;                                        // block-uniform
             const uint32_t nb = (P - 1u) / Q + 1u;                       // batches 0 .. nb-2 are non-empty (a descriptor holds < Q records)
             if (nb > 1) {
