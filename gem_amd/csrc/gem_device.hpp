@@ -184,10 +184,18 @@ __device__ __forceinline__ bool fuse_step(float& e, float& s, float h, float v, 
 {
     const bool empty = e == kEmptyElevation;                                       // GPU:484
     const float sf = s < var_floor ? var_floor : s;                                // GPU:500-501 (written back)
-    const float m  = fabsf(h - e) / sqrtf(sf);                                     // GPU:502
+    // GPU:502 computes m = |h - e| / sqrt(sf) and only ever compares it with the threshold (GPU:504).  The
+    // correctly-rounded sqrt -> division chain is the longest dependency of the per-cell recurrence, so the
+    // decision is first taken from |h - e| * v_rsq_f32(sf) (error < 4 ulp against the reference's m) and
+    // the reference's own expression is evaluated only inside a +-1e-5 relative band around the threshold
+    // (or for a subnormal sf, which v_rsq_f32 flushes): the decision is the reference's in every case.
+    const float d  = fabsf(h - e);
+    const float mt = d * __builtin_amdgcn_rsqf(sf);
+    bool outlier = mt > mahal_thr;
+    if (__builtin_expect(fabsf(mt - mahal_thr) <= 1e-5f * fabsf(mahal_thr) || !(sf >= 1e-30f), 0))
+        outlier = d / sqrtf(sf) > mahal_thr;
     const float en = (sf * h + v * e) / (sf + v);                                  // GPU:518
     const float sn = (v * sf) / (v + sf);                                          // GPU:519
-    const bool outlier = m > mahal_thr;                                            // GPU:504
     const bool replace = empty || (outlier && e < h);                              // GPU:484-486, 505-507
     const bool fuse = !empty && !outlier;
     const float e_new = replace ? h : (fuse ? en : e);

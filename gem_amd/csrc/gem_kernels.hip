@@ -727,25 +727,38 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
                             for (int ww = NW - 1; ww >= 0; --ww) if (hdp[q][ww] != NIL) { cur[q] = hdp[q][ww]; wwq[q] = (uint32_t)ww; }
                             if (cur[q] != NIL) { tmask |= 1u << q; more = true; }
                         }
+                        // software-pipelined: the node after the current one is resolved from registers and its LDS
+                        // reads are issued before the current node's fusion step, so the two latencies overlap
+                        float nh[CPT], nv[CPT]; uint32_t nn[CPT], nsv[CPT];
+#pragma unroll
+                        for (int q = 0; q < CPT; ++q) {
+                            const uint32_t sl = cur[q] != NIL ? cur[q] : 0u;
+                            nh[q] = rec_h(sl); nv[q] = rec_v(sl); nn[q] = nxt[sl];
+                            if (ATTR) nsv[q] = rec_src(sl);
+                        }
                         while (__ballot(more) != 0) {                    // wave-uniform
                             more = false;
 #pragma unroll
                             for (int q = 0; q < CPT; ++q) {
                                 const bool live = cur[q] != NIL;
-                                const uint32_t sl = live ? cur[q] : 0u;
-                                const float h = rec_h(sl), v = rec_v(sl);
-                                uint32_t nx = nxt[sl];
-                                float e2 = ce[q], s2 = cs[q];
-                                const bool taken = fuse_step(e2, s2, h, v, a.mahal, a.var_floor);
-                                ce[q] = live ? e2 : ce[q]; cs[q] = live ? s2 : cs[q];
-                                if (ATTR) { const uint32_t sv = rec_src(sl); if (live && taken && (sv & 0x80000000u)) wl[q] = sv & 0x7fffffffu; }
+                                const float h = nh[q], v = nv[q];
+                                const uint32_t sv = ATTR ? nsv[q] : 0u;
+                                uint32_t nx = nn[q];
                                 if (live && nx == NIL) {                 // end of this wave's list: continue with the next non-empty one
                                     uint32_t nw_ = NW;
 #pragma unroll
                                     for (int ww = NW - 1; ww >= 0; --ww) if ((uint32_t)ww > wwq[q] && hdp[q][ww] != NIL) { nx = hdp[q][ww]; nw_ = (uint32_t)ww; }
                                     wwq[q] = nw_;
                                 }
-                                cur[q] = live ? nx : NIL;
+                                nx = live ? nx : NIL;
+                                const uint32_t sl2 = nx != NIL ? nx : 0u;
+                                nh[q] = rec_h(sl2); nv[q] = rec_v(sl2); nn[q] = nxt[sl2];
+                                if (ATTR) nsv[q] = rec_src(sl2);
+                                float e2 = ce[q], s2 = cs[q];
+                                const bool taken = fuse_step(e2, s2, h, v, a.mahal, a.var_floor);
+                                ce[q] = live ? e2 : ce[q]; cs[q] = live ? s2 : cs[q];
+                                if (ATTR) { if (live && taken && (sv & 0x80000000u)) wl[q] = sv & 0x7fffffffu; }
+                                cur[q] = nx;
                                 more |= cur[q] != NIL;
                             }
                         }

@@ -176,6 +176,36 @@ def test_fuse_arrays_parity(oracle_mod):
     assert_maps_match(gpu, ref)
 
 
+@pytest.mark.parametrize("thr", [5.0, 2.5, 0.75])
+def test_mahalanobis_decision_at_the_threshold(oracle_mod, thr):
+    """GPU:502-504: m = |h - e| / sqrt(s) > threshold.  The device takes the decision from a fast estimate and
+    replays the reference expression only inside a band around the threshold: sweep the second record of many
+    cells ulp by ulp across m == threshold (both signs of h - e) and require the oracle's result everywhere."""
+    L = 96
+    rng = np.random.default_rng(17)
+    n = L * L
+    e0 = rng.uniform(-2, 2, n).astype(F32)
+    s0 = (10.0 ** rng.uniform(-4, 0, n)).astype(F32)
+    sf = np.maximum(s0, F32(1e-4))
+    sign = np.where(np.arange(n) % 2 == 0, 1.0, -1.0).astype(F32)
+    h1 = (e0 + sign * F32(thr) * np.sqrt(sf, dtype=F32)).astype(F32)
+    k = (np.arange(n) % 129) - 64                                      # -64 .. 64 ulps around the estimate of the crossing
+    h1 = (h1.view(np.int32) + k.astype(np.int32)).view(F32)
+    v1 = (10.0 ** rng.uniform(-4, -1, n)).astype(F32)
+    idx = np.arange(n, dtype=np.int32)
+    gpu, ref = make_pair(oracle_mod, L, 0.1, mahalanobis_threshold=thr)
+    for m in (gpu, ref):
+        m.fuse(idx, e0, s0)                                            # first record of a cell: replace
+        m.fuse(idx, h1, v1)                                            # the one at the threshold
+    assert_maps_match(gpu, ref)
+    e1 = ref.layer("elevation").ravel()
+    outlier = (e1 == e0) | (e1 == h1)                                  # ignored / replaced; anything else was fused
+    assert 0.2 < outlier.mean() < 0.8                                  # the sweep straddles the crossing
+    for m in (gpu, ref):
+        m.fuse(idx, (h1 + F32(0.01)).astype(F32), v1)                  # and once more from the state that decision left
+    assert_maps_match(gpu, ref)
+
+
 def test_process_then_fuse_equals_add(oracle_mod):
     wl = synth.config_c2()
     a = ElevationMap(wl.length, wl.resolution); b = ElevationMap(wl.length, wl.resolution)

@@ -17,7 +17,13 @@ d = [torch.from_numpy(c).cuda() for c in wl.clouds]
 for k in range(3):
     m.add(wl.frames[k], d[k])
 lib.gem_debug_fuse_stamps(m._h, 1, None, 0)
-if len(sys.argv) > 1 and sys.argv[1] == "batch":     # first sweeps of a batched call (16 stamps per tile = ~3 sweeps)
+if len(sys.argv) > 1 and sys.argv[1] == "c3":          # dense depth image: generic (linked-list) path, many batches per tile
+    wl3 = synth.config_c3()
+    m = ElevationMap(wl3.length, wl3.resolution)
+    m.move(wl3.map_position)
+    lib.gem_debug_fuse_stamps(m._h, 1, None, 0)
+    m.add(wl3.frames[0], torch.from_numpy(wl3.clouds[0]).cuda())
+elif len(sys.argv) > 1 and sys.argv[1] == "batch":     # first sweeps of a batched call (16 stamps per tile = ~3 sweeps)
     import numpy as _np
     cat = torch.from_numpy(_np.concatenate(wl.clouds)).cuda()
     off = _np.concatenate([[0], _np.cumsum([c.shape[0] for c in wl.clouds])])
