@@ -54,7 +54,7 @@ struct gem_handle {
     // Pipeline intermediates, double-buffered: k_bin of pass p+1 runs on `bin_stream` while k_fuse of
     // pass p runs on `stream` (binning does not depend on the map, only on the cloud and the pose).
     struct PassBuffers {
-        Arena rec, seg, flag, gflag;   // records, descriptor table, touched stamps per (tile, sweep) and per (sweep, tile, 32 units)
+        Arena rec, srt, seg, flag, gflag;   // records, descriptor table, touched stamps per (tile, sweep) and per (sweep, tile, 32 units)
         Arena tables;                  // batched-call tables (frames, sweep_unit0, sweep_first, var_updates)
         hipEvent_t bin_done = nullptr, fuse_done = nullptr;
         bool fuse_recorded = false;
@@ -69,6 +69,7 @@ struct gem_handle {
     hipStream_t bin_stream = nullptr;
     bool overlap = true;
     long long overlap_min_points = 1000000;
+    unsigned dense_min = 2048;          // records of one sweep in one 16x16 tile above which the tile is counting-sorted (k_fuse_list, dense path)
     Arena scratch;      // layer export
     unsigned long long* d_counters = nullptr;
 
@@ -298,6 +299,7 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     hipStream_t sbin = overlap ? h->bin_stream : h->stream;
     int rc;
     if ((rc = ensure(h, pb.rec, (size_t)B * U * sizeof(uint4)))) return rc;
+    if ((rc = ensure(h, pb.srt, (size_t)B * U * sizeof(uint4) + 16))) return rc;     // sorted arena + its bump pointer (last 16 bytes)
     if (overlap && pb.fuse_recorded) GEM_HIP(h, hipStreamWaitEvent(sbin, pb.fuse_done, 0));   // k_fuse of pass p-2 has read these buffers
     {   // descriptor table [sweep][tile][unit in sweep]: k_fuse_list zeroes what it consumes, so the table only
         // has to be cleared when it is (re)allocated
@@ -358,6 +360,7 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     ba.epoch = pb.epoch;
     ba.rec = static_cast<uint4*>(pb.rec.p); ba.seg = static_cast<uint16_t*>(pb.seg.p); ba.flag = static_cast<uint32_t*>(pb.flag.p); ba.gflag = static_cast<uint32_t*>(pb.gflag.p);
     ba.counters = h->counting ? h->d_counters : nullptr;
+    ba.srt_top = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(pb.srt.p) + pb.srt.cap - 16);
 
     fa.epoch = pb.epoch;
     fa.rec = ba.rec; fa.seg = ba.seg; fa.flag = ba.flag; fa.gflag = ba.gflag; fa.B_total = B; fa.U = U; fa.n_sweeps = in.n_sweeps; fa.Bpad = bpad;
@@ -371,6 +374,7 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     fa.intensity = h->layers.intensity; fa.colorR = h->layers.colorR; fa.colorG = h->layers.colorG; fa.colorB = h->layers.colorB;
     fa.xyzi = in.xyzi; fa.rgb = in.rgb; fa.f_R = in.f_R; fa.f_G = in.f_G; fa.f_B = in.f_B; fa.f_I = in.f_I;
     fa.counters = ba.counters;
+    fa.srt = static_cast<uint4*>(pb.srt.p); fa.srt_top = ba.srt_top; fa.dense_min = h->dense_min;
     fa.count_per_pass = orig0.empty() ? 0 : 1;
     fa.dbg = nullptr;
     if (h->dbg_on) {
@@ -452,6 +456,7 @@ int gem_create(const gem_map_config* cfg, gem_handle** out)
         if ((e = hipEventCreateWithFlags(&b.fuse_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     }
     if (const char* s = getenv("GEM_DEFER")) h->defer = atoi(s) != 0;
+    if (const char* s = getenv("GEM_DENSE_MIN")) h->dense_min = (unsigned)atoi(s);
     if (const char* s = getenv("GEM_OVERLAP")) { h->overlap = atoi(s) != 0; if (atoi(s) > 1) h->overlap_min_points = 0; }
     // one allocation for the 8 layers (gpu_process.cu:954-961 uses 8 cudaMalloc)
     void* base = nullptr;
@@ -489,7 +494,7 @@ void gem_destroy(gem_handle* h)
     if (h->d_counters) hipFree(h->d_counters);
     for (Arena* a : {&h->stage, &h->scratch, &h->dbg}) if (a->p) hipFree(a->p);
     for (auto& b : h->pb) {
-        for (Arena* a : {&b.rec, &b.seg, &b.flag, &b.gflag, &b.tables}) if (a->p) hipFree(a->p);
+        for (Arena* a : {&b.rec, &b.srt, &b.seg, &b.flag, &b.gflag, &b.tables}) if (a->p) hipFree(a->p);
         if (b.bin_done) hipEventDestroy(b.bin_done);
         if (b.fuse_done) hipEventDestroy(b.fuse_done);
     }

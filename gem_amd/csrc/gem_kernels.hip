@@ -148,6 +148,7 @@ __device__ __forceinline__ void bin_wave_body(const BinArgs& a, int block)
     const int lane = lane_id();
     const int unit = (int)(block * 4 + (threadIdx.x >> 6));
     if (unit >= a.B) return;                               // whole wave leaves together
+    if (unit == 0 && lane == 0) *a.srt_top = 0u;            // bump pointer of the sorted arena (dense tiles of k_fuse_list, same pass)
 
     int sweep = 0, unit_first = 0, orig0 = 0;
     long long base, sweep_begin = 0, sweep_end = a.n;
@@ -242,10 +243,128 @@ constexpr int kChunkUnits = 2048;        // descriptor words scanned per block p
 constexpr int kRankMax    = 7;           // fast path: records per cell and batch
 constexpr int fuse_list_max_batches(int pb) { return kChunkUnits * 64 / (pb - 64) + 2; }
 
+// ------------------------------------------------------------------------------------------
+// dense_tile : k_fuse_list's path for a DENSE tile (a depth camera's near field: tens of thousands of records of one
+// sweep in 256 cells, chains of hundreds).  Batches in input order would keep only the few cells under the current
+// image rows busy, and the tile would take the sum over batches of the longest chain.  Instead the chunk's records are
+// counting-sorted by cell into the sorted arena -- stable: wave w takes the w-th contiguous share of the chunk's
+// descriptors, one descriptor (<= 64 consecutive records) per step, equal cells inside a step ranked by a ballot
+// match -- and every cell's owner streams its own contiguous run: the tile takes the LONGEST chain.
+// Out of line on purpose: its registers must not count against the LiDAR paths of the caller.
+// LDS on entry: dlc[nd] = {arena index of the first record, count} in input order, *gbase_p = the tile's base in the
+// sorted arena (both written by the caller, no barrier yet); wc = [NW][CELLS] words (the rank-row area, left zeroed).
+// ------------------------------------------------------------------------------------------
+struct DenseResult { float e, s; uint32_t n, last; };
+
+template <int TS, int NT, int ATTR>
+__device__ __noinline__ DenseResult dense_tile(const uint4* __restrict__ rec, uint4* __restrict__ srt_raw, uint32_t* wc, const uint2* dlc,
+                                               uint32_t* scratch, const uint32_t* gbase_p, uint32_t nd, float e, float s,
+                                               float mahal, float var_floor)
+{
+    constexpr int CELLS = 1 << (2 * TS), NW = NT / 64;
+    static_assert(CELLS == NT, "one cell per thread");
+    using SRec = typename std::conditional<ATTR != 0, uint4, uint2>::type;   // sorted record: {h, v} (+ colour flag, source index)
+    SRec* const srt = reinterpret_cast<SRec*>(srt_raw);
+    const int tid = (int)threadIdx.x, lane = lane_id(), w = tid >> 6;
+    const uint64_t lt = lanemask_lt();
+    for (int i = tid; i < NW * CELLS; i += NT) wc[i] = 0u;
+    __syncthreads();
+    const uint32_t dw0 = (nd * (uint32_t)w) / NW, dw1 = (nd * (uint32_t)(w + 1)) / NW;
+    uint32_t* wcw = wc + w * CELLS;
+    {   // count per (wave, cell); four descriptors' cell words in flight
+        constexpr int PFC = 4;
+        for (uint32_t d = dw0; d < dw1; d += PFC) {                      // wave-uniform
+            uint32_t z[PFC], cn[PFC];
+#pragma unroll
+            for (int x = 0; x < PFC; ++x) {
+                const uint2 de = dlc[min(d + x, dw1 - 1u)];
+                cn[x] = d + x < dw1 ? de.y : 0u;
+                z[x] = rec[de.x + ((uint32_t)lane < de.y ? (uint32_t)lane : 0u)].z;
+            }
+#pragma unroll
+            for (int x = 0; x < PFC; ++x) if ((uint32_t)lane < cn[x]) atomicAdd(&wcw[z[x] & 0xffffu], 1u);
+        }
+    }
+    __syncthreads();
+    const uint32_t gbase = *gbase_p;
+    uint32_t ctot = 0, cstart;
+    {   // cell c's run starts at the cells' exclusive prefix; wave w writes behind the waves before it
+        uint32_t cw[NW];
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) { cw[ww] = wc[ww * CELLS + tid]; ctot += cw[ww]; }
+        uint32_t all;
+        cstart = block_exclusive_scan<NT>(ctot, scratch, &all);
+        uint32_t acc = cstart;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) { wc[ww * CELLS + tid] = acc; acc += cw[ww]; }
+    }
+    __syncthreads();
+    {   // placement, four descriptors' records in flight
+        constexpr int PFP = 4;
+        for (uint32_t d = dw0; d < dw1; d += PFP) {                      // wave-uniform
+            uint4 r[PFP]; uint32_t cn[PFP];
+#pragma unroll
+            for (int x = 0; x < PFP; ++x) {
+                const uint2 de = dlc[min(d + x, dw1 - 1u)];
+                cn[x] = d + x < dw1 ? de.y : 0u;
+                r[x] = rec[de.x + ((uint32_t)lane < de.y ? (uint32_t)lane : 0u)];
+            }
+#pragma unroll
+            for (int x = 0; x < PFP; ++x) {
+                const bool on = (uint32_t)lane < cn[x];
+                const uint32_t cell = r[x].z & 0xffffu;
+                const uint64_t peers = wave_peers(on, cell, 2 * TS);
+                const uint32_t rank = (uint32_t)__popcll(peers & lt);
+                uint32_t old = 0;
+                if (on && rank == 0) { old = wcw[cell]; wcw[cell] = old + (uint32_t)__popcll(peers); }
+                old = (uint32_t)__shfl((int)old, on ? __ffsll((unsigned long long)peers) - 1 : lane);
+                if (on) { if constexpr (ATTR != 0) srt[gbase + old + rank] = r[x]; else srt[gbase + old + rank] = make_uint2(r[x].x, r[x].y); }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    DenseResult out; out.e = e; out.s = s; out.n = ctot; out.last = 0xffffffffu;
+    {   // walk the cell's run, the records four steps ahead in flight (clamped address: never a branch round a load)
+        constexpr int D = 4;
+        const uint32_t n = ctot, nm1 = n ? n - 1u : 0u;
+        const SRec* sp = srt + gbase + (n ? cstart : 0u);
+        auto ld = [&](uint32_t i) -> SRec { return sp[min(i, nm1)]; };
+        SRec pre[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) pre[k] = ld((uint32_t)k);
+        for (uint32_t i = 0; __ballot(i < n) != 0; i += D) {             // wave-uniform
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const SRec cur = pre[k];
+                const uint32_t idx = i + (uint32_t)k;
+                pre[k] = ld(idx + D);
+                float e2 = out.e, s2 = out.s;
+                const bool taken = fuse_step(e2, s2, __uint_as_float(cur.x), __uint_as_float(cur.y), mahal, var_floor);
+                const bool live = idx < n;
+                out.e = live ? e2 : out.e; out.s = live ? s2 : out.s;
+                if constexpr (ATTR != 0) { if (live && taken && (cur.z & 0x80000000u)) out.last = cur.w & 0x7fffffffu; }
+            }
+        }
+    }
+    __syncthreads();
+    {   // back to the fast path's invariant: every rank row has count 0
+        uint4* zr = reinterpret_cast<uint4*>(wc);
+        for (int c = tid; c < CELLS; c += NT) zr[c] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    return out;
+}
+
 #define GEM_CSWAP(a, b) do { const uint32_t lo_ = min(a, b), hi_ = max(a, b); a = lo_; b = hi_; } while (0)
 
-template <int TS, int NT, int PB, int ATTR, bool BATCH>
-__device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsigned char* lds_raw)
+// MODE 0: the LiDAR paths only (k_frame).  MODE 1: the same code, but a dense (tile, sweep) makes it hand the tile over --
+// state in `st`, return true -- to a MODE 2 copy, which resumes at that sweep and has the dense path.  Two copies in one
+// kernel keep the dense path's registers (and spills) out of the code every LiDAR tile runs.
+template <int CPT> struct TileState { float e[CPT], s[CPT]; uint32_t tmask; int sweep; };
+
+template <int TS, int NT, int PB, int ATTR, bool BATCH, int MODE>
+__device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsigned char* lds_raw, TileState<(1 << (2 * TS)) / NT>& st)
 {
     // BATCH = false: one sweep, no per-sweep tables in device memory, no variance increments between sweeps --
     // the sweep loop below collapses and none of its scalar bookkeeping is compiled in
@@ -299,14 +418,14 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
     if constexpr (!BATCH) {
         const int q4 = (a.T + 3) >> 2;
         const int rnk = (tile & 3) * q4 + (tile >> 2);
-        if (rnk >= a.T) return;
+        if (rnk >= a.T) return false;
         const int bi = rnk / tpr, bj = rnk - bi * tpr;
         const int oi = (bi & 1) ? -((bi + 1) >> 1) : (bi >> 1), oj = (bj & 1) ? -((bj + 1) >> 1) : (bj >> 1);
         tr = a.center_tr + oi; tr = tr < 0 ? tr + tpr : (tr >= tpr ? tr - tpr : tr);
         tc = a.center_tc + oj; tc = tc < 0 ? tc + tpr : (tc >= tpr ? tc - tpr : tc);
         tile = tr * tpr + tc;
     } else {
-        if (tile >= a.T) return;
+        if (tile >= a.T) return false;
         tr = tile / tpr; tc = tile - tr * tpr;
     }
     const int row_base = tr << TS, col_base = tc << TS;
@@ -374,21 +493,22 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
         if constexpr (BATCH) return __builtin_amdgcn_readlane(su1, sweep & 63) - __builtin_amdgcn_readlane(su0, sweep & 63);
         else return a.B_total;
     };
-    sweep_tables(0);
+    const int sweep0 = MODE == 2 ? st.sweep : 0;                         // MODE 2 resumes where the MODE 1 copy stopped
+    sweep_tables(sweep0 & ~63);
 
     // does this tile receive any point of this pass?
-    uint64_t smask = sweep_mask(0);
-    {
+    uint64_t smask = sweep_mask(sweep0 & ~63);
+    if constexpr (MODE != 2) {
         bool any_touched = smask != 0;
         for (int sb = 64; sb < NS && !any_touched; sb += 64) any_touched = sweep_mask(sb) != 0;
-        if (!any_touched && !a.dense) return;
+        if (!any_touched && !a.dense) return false;
     }
     // descriptor words of the first touched sweep: in flight before the tile itself is read, so that the
     // (larger, strided) tile loads do not sit in front of them in the memory pipeline
     if constexpr (!BATCH) {                                              // one sweep: no branch around the load (see load_row)
         prefetched = 0;
         evn = load_row(0, a.B_total, 0, gf0, evn_on);
-    } else if (smask != 0) {
+    } else if (MODE != 2 && smask != 0) {
         prefetched = __ffsll((unsigned long long)smask) - 1;
         evn = load_row(prefetched, units_of(prefetched), 0, prefetched == 0 ? gf0 : load_gflag(prefetched, 0), evn_on);
     }
@@ -405,7 +525,8 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
         // unknown to the compiler, which then waits for ALL of them wherever it needs the descriptor words
         // (cells outside the map or the strip read cell 0; they receive no records and are never written back)
         const size_t g = owned[q] ? (size_t)row * L + col : 0;
-        ce[q] = a.elevation[g]; cs[q] = a.variance[g];
+        if constexpr (MODE == 2) { ce[q] = st.e[q]; cs[q] = st.s[q]; }
+        else { ce[q] = a.elevation[g]; cs[q] = a.variance[g]; }
     }
 
     {   // fast-path rows start with count 0; the owner leaves every row it consumed at count 0 again
@@ -415,9 +536,25 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
     }
     GEM_STAMP();                                                         // 1: tile loads issued
 
-    uint32_t tmask = 0;                                                  // cells of this thread touched in this sweep (or pass)
-    for (int sweep = 0; sweep < NS; ++sweep) {
-        if (sweep != 0 && (sweep & 63) == 0) { smask = sweep_mask(sweep); sweep_tables(sweep); }
+    // colour / intensity of the last taken point with all four non-zero (GPU:487-494)
+    auto write_attr = [&](int q, uint32_t last) {
+        if constexpr (ATTR != 0) {
+            const int c = tid + NT * q;
+            const size_t g = (size_t)(row_base + (c >> TS)) * L + col_base + (c & (TE - 1));
+            if (ATTR == 1) {
+                const uint32_t cc = a.rgb[last];
+                a.intensity[g] = a.xyzi[last].w;
+                a.colorR[g] = (int)((cc >> 16) & 0xff); a.colorG[g] = (int)((cc >> 8) & 0xff); a.colorB[g] = (int)(cc & 0xff);
+            } else {
+                a.intensity[g] = a.f_I[last];
+                a.colorR[g] = a.f_R[last]; a.colorG[g] = a.f_G[last]; a.colorB[g] = a.f_B[last];
+            }
+        }
+    };
+
+    uint32_t tmask = MODE == 2 ? st.tmask : 0u;                          // cells of this thread touched in this sweep (or pass)
+    for (int sweep = sweep0; sweep < NS; ++sweep) {
+        if (sweep != sweep0 && (sweep & 63) == 0) { smask = sweep_mask(sweep); sweep_tables(sweep); }
         const bool touched_sweep = (smask >> (sweep & 63)) & 1ull;       // block-uniform
         // a sweep that neither reaches this tile nor carries a variance increment changes nothing
         // (the floor below is idempotent and has been applied by an earlier sweep or is applied by a later one)
@@ -467,13 +604,6 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
                     any |= ev[j];
                     packed += live ? ((1u << 20) | (ev[j] & kSegCountMask)) : 0u;
                 }
-                // consumed: one wide store of zeros over the words this thread read, so that the table is all-zero
-                // again after the pass (its other words already are)
-                if (any) {
-                    uint16_t* rowx = row_ptr(sweep) + u0;
-                    if constexpr (UPT == 8) *reinterpret_cast<uint4*>(rowx) = make_uint4(0, 0, 0, 0);
-                    else                    *reinterpret_cast<uint2*>(rowx) = make_uint2(0, 0);
-                }
             }
             if (a.dbg) { asm volatile("" :: "v"(packed)); GEM_STAMP(); }                      // 2: descriptor words arrived
             uint32_t tot;
@@ -481,6 +611,51 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
             const uint32_t nd = tot >> 20, P = tot & 0xfffffu;
             if (next_sweep >= 0) { evn = load_row(next_sweep, units_of(next_sweep), 0, gfn, evn_on); prefetched = next_sweep; }
             if (P == 0) continue;                                        // block-uniform
+            if constexpr (MODE == 1 && DMA && CPT == 1) {
+                if (ci == 0 && P > a.dense_min) {                        // block-uniform: a dense tile, nothing of this sweep consumed yet
+#pragma unroll
+                    for (int q = 0; q < CPT; ++q) { st.e[q] = ce[q]; st.s[q] = cs[q]; }
+                    st.tmask = tmask; st.sweep = sweep;
+                    return true;
+                }
+            }
+            {   // consumed: one wide store of zeros over the words this thread read, so that the table is all-zero
+                // again after the pass (its other words already are)
+                uint32_t any = 0;
+#pragma unroll
+                for (int j = 0; j < UPT; ++j) any |= ev[j];
+                if (any) {
+                    uint16_t* rowx = row_ptr(sweep) + u0;
+                    if constexpr (UPT == 8) *reinterpret_cast<uint4*>(rowx) = make_uint4(0, 0, 0, 0);
+                    else                    *reinterpret_cast<uint2*>(rowx) = make_uint2(0, 0);
+                }
+            }
+            if constexpr (MODE == 2 && DMA && CPT == 1) {
+                if (P > a.dense_min) {                                   // block-uniform
+                    // ---- DENSE TILE: see dense_tile().  The chunk's descriptor list goes to the stage area, the rest is
+                    //      an out-of-line call so that its registers do not count against the LiDAR paths below.
+                    static_assert(!DMA || PB * 16 >= kChunkUnits * 8, "the chunk's descriptor list lives in the stage area");
+                    uint2* dlc = reinterpret_cast<uint2*>(stage);        // [nd] {arena index of the first record, count}
+                    {
+                        uint32_t d = run >> 20;
+#pragma unroll
+                        for (int j = 0; j < UPT; ++j)
+                            if (ev[j] != 0) {
+                                dlc[d++] = make_uint2((uint32_t)(ub + u0 + j) * (uint32_t)a.U + ((ev[j] >> kSegCountBits) & kSegStartMask),
+                                                      ev[j] & kSegCountMask);
+                            }
+                        if (tid == 0) misc[2] = atomicAdd(a.srt_top, P);
+                    }
+                    apply_increments();
+                    const DenseResult dr = dense_tile<TS, NT, ATTR>(a.rec, a.srt, reinterpret_cast<uint32_t*>(rowp), dlc, scratch, misc + 2,
+                                                                    nd, ce[0], cs[0], a.mahal, a.var_floor);
+                    ce[0] = dr.e; cs[0] = dr.s;
+                    if (dr.n) tmask |= 1u;
+                    if (ATTR != 0 && dr.last != 0xffffffffu) write_attr(0, dr.last);
+                    GEM_STAMP();
+                    continue;
+                }
+            }
             const uint32_t nb = (P - 1u) / Q + 1u;                       // batches 0 .. nb-2 are non-empty (a descriptor holds < Q records)
             if (nb > 1) {
                 for (uint32_t i = tid; i < nb; i += NT) bstart[i] = 0xffffffffu;
@@ -654,23 +829,7 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
                     }
                     if (ATTR) {
 #pragma unroll
-                        for (int q = 0; q < CPT; ++q) {
-                            if (wlast[q] != 0xffffffffu) {
-                                // colour / intensity of the last taken point with all four non-zero (GPU:487-494)
-                                const int c = tid + NT * q;
-                                const int row_g = row_base + (c >> TS), col_g = col_base + (c & (TE - 1));
-                                const size_t g = (size_t)row_g * L + col_g;
-                                const uint32_t last = wlast[q];
-                                if (ATTR == 1) {
-                                    const uint32_t cc = a.rgb[last];
-                                    a.intensity[g] = a.xyzi[last].w;
-                                    a.colorR[g] = (int)((cc >> 16) & 0xff); a.colorG[g] = (int)((cc >> 8) & 0xff); a.colorB[g] = (int)(cc & 0xff);
-                                } else {
-                                    a.intensity[g] = a.f_I[last];
-                                    a.colorR[g] = a.f_R[last]; a.colorG[g] = a.f_G[last]; a.colorB[g] = a.f_B[last];
-                                }
-                            }
-                        }
+                        for (int q = 0; q < CPT; ++q) if (wlast[q] != 0xffffffffu) write_attr(q, wlast[q]);
                     }
                 } else {
                     // ---- 3b. generic path: per-wave in-order linked lists --------------------------
@@ -764,22 +923,7 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
                         }
                         if (ATTR) {
 #pragma unroll
-                            for (int q = 0; q < CPT; ++q) {
-                                if (wl[q] != 0xffffffffu) {
-                                    const int c = tid + NT * q;
-                                    const int row_g = row_base + (c >> TS), col_g = col_base + (c & (TE - 1));
-                                    const size_t g = (size_t)row_g * L + col_g;
-                                    const uint32_t last = wl[q];
-                                    if (ATTR == 1) {
-                                        const uint32_t cc = a.rgb[last];
-                                        a.intensity[g] = a.xyzi[last].w;
-                                        a.colorR[g] = (int)((cc >> 16) & 0xff); a.colorG[g] = (int)((cc >> 8) & 0xff); a.colorB[g] = (int)(cc & 0xff);
-                                    } else {
-                                        a.intensity[g] = a.f_I[last];
-                                        a.colorR[g] = a.f_R[last]; a.colorG[g] = a.f_G[last]; a.colorB[g] = a.f_B[last];
-                                    }
-                                }
-                            }
+                            for (int q = 0; q < CPT; ++q) if (wl[q] != 0xffffffffu) write_attr(q, wl[q]);
                         }
                     }
                     __syncthreads();
@@ -819,13 +963,22 @@ __device__ __forceinline__ void fuse_list_body(const FuseArgs& a, int tile, unsi
     }
     GEM_STAMP();                                                         // 6: stores issued
 #undef GEM_STAMP
+    return false;
 }
 
 template <int TS, int NT, int PB, int ATTR, bool BATCH>
 __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_list(FuseArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
-    fuse_list_body<TS, NT, PB, ATTR, BATCH>(a, (int)blockIdx.x, lds_dyn);
+    TileState<(1 << (2 * TS)) / NT> st;
+    if constexpr (TS == 4 && PB <= 1024) {                               // 16x16 tiles: dense tiles are handed to the second copy
+        if (fuse_list_body<TS, NT, PB, ATTR, BATCH, 1>(a, (int)blockIdx.x, lds_dyn, st)) {
+            __syncthreads();
+            fuse_list_body<TS, NT, PB, ATTR, BATCH, 2>(a, (int)blockIdx.x, lds_dyn, st);
+        }
+    } else {
+        fuse_list_body<TS, NT, PB, ATTR, BATCH, 0>(a, (int)blockIdx.x, lds_dyn, st);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -839,7 +992,7 @@ __global__ __launch_bounds__(256, 4) void k_frame(FuseArgs fa, BinArgs ba)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
     const int nf = (fa.T + 3) & ~3;                                      // fuse blocks (see the block -> tile mapping)
-    if ((int)blockIdx.x < nf) fuse_list_body<4, 256, 1024, 0, false>(fa, (int)blockIdx.x, lds_dyn);
+    if ((int)blockIdx.x < nf) { TileState<1> st; fuse_list_body<4, 256, 1024, 0, false, 0>(fa, (int)blockIdx.x, lds_dyn, st); }
     else bin_wave_body<0, 4, false>(ba, (int)blockIdx.x - nf);
 }
 

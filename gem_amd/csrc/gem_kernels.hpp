@@ -50,6 +50,7 @@ struct BinArgs {
     uint32_t* flag;                    // [T][n_sweeps]  == epoch when the sweep put a record into the tile
     uint32_t* gflag;                   // [n_sweeps][T][Bpad/32]  == epoch when that group of 32 units did
     unsigned long long* counters;      // optional: [0] += binned points
+    uint32_t*         srt_top;         // bump pointer of the sorted arena (reset here, used by the fuse of the same pass)
 };
 
 struct FuseArgs {
@@ -76,6 +77,9 @@ struct FuseArgs {
     const float4* xyzi; const uint32_t* rgb;
     const int* f_R; const int* f_G; const int* f_B; const float* f_I;
     unsigned long long* counters;      // optional: [1] += distinct touched cells per sweep (per pass when count_per_pass)
+    uint4*            srt;             // sorted arena (as many records as `rec`): dense tiles counting-sort their records by cell into it
+    uint32_t*         srt_top;         // its bump pointer (records), zeroed by the k_bin of the pass
+    uint32_t          dense_min;       // a (tile, sweep) with more records than this takes the dense path (16x16 tiles only)
     int   count_per_pass;              // the sweeps are one cloud cut into pieces: count a cell once
     unsigned long long* dbg;           // optional: [T][16] cycle-counter stamps of thread 0 (profiling aid)
 };

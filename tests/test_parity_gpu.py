@@ -377,6 +377,67 @@ def test_mixed_fast_and_generic_batches(oracle_mod):
         assert_maps_match(gpu, ref)
 
 
+# ---- dense tiles (k_fuse_list hands the tile to its second copy, which counting-sorts the sweep's records by cell) ----------
+@pytest.mark.parametrize("dense_min", [0, 300])
+def test_dense_tile_path(oracle_mod, monkeypatch, dense_min):
+    """GEM_DENSE_MIN lowers the records-per-(tile, sweep) threshold of the dense path, so that ordinary clouds take it:
+    mixed dense / LiDAR tiles, several sweeps per tile with variance increments in between, colour attributes,
+    the strip clipping, a single cell fed by a whole sweep."""
+    import torch
+    monkeypatch.setenv("GEM_DENSE_MIN", str(dense_min))
+    f = synth._frame_for(np.eye(4), SensorModel.velodyne())
+    # (a) collisions + attributes, twice (the second call fuses into non-empty cells)
+    gpu, ref = make_pair(oracle_mod, 100, 0.1)
+    rng = np.random.default_rng(9)
+    c = synth.random_cloud(9, 60000, 3.5)
+    rgb = (rng.integers(0, 3, (60000, 3)) * 100).astype(np.uint32)
+    packed = (rgb[:, 0] << 16) | (rgb[:, 1] << 8) | rgb[:, 2]
+    for _ in range(2):
+        gpu.add(f, c, rgb=packed); ref.add(f, c, rgb=packed)
+        assert_maps_match(gpu, ref, layers=("elevation", "variance", "intensity", "color_r", "color_g", "color_b"))
+    # (b) a batch: sweeps of very different density over the same tiles, Mapvar_update between them
+    wl = synth.config_c4(n_sweeps=4)
+    gpu, ref = make_pair(oracle_mod, wl.length, wl.resolution)
+    clouds = [wl.clouds[0], wl.clouds[1][:3000], wl.clouds[2], wl.clouds[3][:40000]]
+    off = np.concatenate([[0], np.cumsum([x.shape[0] for x in clouds])])
+    cat = torch.from_numpy(np.concatenate(clouds)).cuda()
+    for _ in range(2):
+        gpu.add_batch(wl.frames, cat, off, wl.var_updates)
+        for k in range(4):
+            ref.mapvar_update(wl.var_updates[k]); ref.add(wl.frames[k], clouds[k])
+        assert_maps_match(gpu, ref)
+    # (c) one cell fed by 10 000 points, inside a 300 000-point cloud that is cut into sweeps
+    gpu, ref = make_pair(oracle_mod, 64, 0.1)
+    big = synth.random_cloud(41, 300_000, 3.0)
+    big[100_000:110_000, 0] = 0.31 + rng.uniform(0, 0.05, 10_000).astype(F32)
+    big[100_000:110_000, 1] = -0.72 + rng.uniform(0, 0.05, 10_000).astype(F32)
+    gpu.add(f, big); ref.add(f, big)
+    assert_maps_match(gpu, ref)
+    # (d) fuse() with host arrays (records come from precomputed indices) incl. the h == -1 sentinel
+    gpu, ref = make_pair(oracle_mod, 50, 0.1)
+    n = 30000
+    idx = rng.integers(-1, 2500 + 5, n).astype(np.int32)
+    h = rng.normal(0, 0.2, n).astype(F32); h[rng.integers(0, n, 50)] = -1.0
+    v = rng.uniform(1e-6, 2e-3, n).astype(F32)
+    R, G, B = (rng.integers(0, 3, n).astype(np.int32) * 90 for _ in range(3))
+    I = rng.integers(0, 2, n).astype(F32)
+    for _ in range(2):
+        gpu.fuse(idx, h, v, R, G, B, I); ref.fuse(idx, h, v, R, G, B, I)
+        assert_maps_match(gpu, ref, layers=("elevation", "variance", "intensity", "color_r", "color_g", "color_b"))
+
+
+def test_dense_depth_image_default_threshold(oracle_mod):
+    # BASELINE config 3 (640x480 depth image) takes the dense path with the default threshold; fused twice
+    wl = synth.config_c3()
+    gpu, ref = make_pair(oracle_mod, wl.length, wl.resolution)
+    for m in (gpu, ref):
+        m.move(wl.map_position)
+    for _ in range(2):
+        gpu.add(wl.frames[0], wl.clouds[0]); ref.add(wl.frames[0], wl.clouds[0])
+        assert_maps_match(gpu, ref)
+        gpu.mapvar_update(3e-5); ref.mapvar_update(3e-5)
+
+
 # ---- aggregated cloud into the big map (BASELINE config 5, reduced) -----------------------------------------------------
 def test_c5_aggregated_batch_parity(oracle_mod):
     import torch
