@@ -377,6 +377,7 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     fa.srt = static_cast<uint4*>(pb.srt.p); fa.srt_top = ba.srt_top; fa.dense_min = h->dense_min;
     fa.count_per_pass = orig0.empty() ? 0 : 1;
     fa.dbg = nullptr;
+    fa.dbg_sweep = 0; if (const char* e = getenv("GEM_DBG_SWEEP")) fa.dbg_sweep = atoi(e);
     if (h->dbg_on) {
         if ((rc = ensure(h, h->dbg, (size_t)T * 16 * 8))) return rc;
         GEM_HIP(h, hipMemsetAsync(h->dbg.p, 0, (size_t)T * 16 * 8, h->stream));

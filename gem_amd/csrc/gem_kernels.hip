@@ -257,10 +257,12 @@ constexpr int fuse_list_max_batches(int pb) { return kChunkUnits * 64 / (pb - 64
 struct DenseResult { float e, s; uint32_t n, last; };
 
 template <int TS, int NT, int ATTR>
-__device__ __noinline__ DenseResult dense_tile(const uint4* __restrict__ rec, uint4* __restrict__ srt_raw, uint32_t* wc, const uint2* dlc,
+__device__ __forceinline__ DenseResult dense_tile(const uint4* __restrict__ rec, uint4* __restrict__ srt_raw, uint32_t* wc, const uint2* dlc,
                                                uint32_t* scratch, const uint32_t* gbase_p, uint32_t nd, float e, float s,
-                                               float mahal, float var_floor)
+                                               float mahal, float var_floor, unsigned long long* dbg)
 {
+#define GEM_DSTAMP(k) do { if (dbg && threadIdx.x == 0) dbg[k] = (unsigned long long)__builtin_readcyclecounter(); } while (0)
+    GEM_DSTAMP(0);
     constexpr int CELLS = 1 << (2 * TS), NW = NT / 64;
     static_assert(CELLS == NT, "one cell per thread");
     using SRec = typename std::conditional<ATTR != 0, uint4, uint2>::type;   // sorted record: {h, v} (+ colour flag, source index)
@@ -271,21 +273,33 @@ __device__ __noinline__ DenseResult dense_tile(const uint4* __restrict__ rec, ui
     __syncthreads();
     const uint32_t dw0 = (nd * (uint32_t)w) / NW, dw1 = (nd * (uint32_t)(w + 1)) / NW;
     uint32_t* wcw = wc + w * CELLS;
-    {   // count per (wave, cell); four descriptors' cell words in flight
-        constexpr int PFC = 4;
-        for (uint32_t d = dw0; d < dw1; d += PFC) {                      // wave-uniform
-            uint32_t z[PFC], cn[PFC];
+    {   // count per (wave, cell): the cell words of the next eight descriptors are in flight while the current eight are counted
+        constexpr int PFC = 8;
+        uint32_t zA[PFC], cA[PFC], zB[PFC], cB[PFC];
+        auto fetch = [&](uint32_t d, uint32_t (&z)[PFC], uint32_t (&cn)[PFC]) {
 #pragma unroll
             for (int x = 0; x < PFC; ++x) {
-                const uint2 de = dlc[min(d + x, dw1 - 1u)];
+                const uint2 de = dlc[min(d + x, nd - 1u)];
                 cn[x] = d + x < dw1 ? de.y : 0u;
                 z[x] = rec[de.x + ((uint32_t)lane < de.y ? (uint32_t)lane : 0u)].z;
             }
+        };
+        auto count = [&](const uint32_t (&z)[PFC], const uint32_t (&cn)[PFC]) {
 #pragma unroll
             for (int x = 0; x < PFC; ++x) if ((uint32_t)lane < cn[x]) atomicAdd(&wcw[z[x] & 0xffffu], 1u);
+        };
+        if (dw0 < dw1) {
+            fetch(dw0, zA, cA);
+            for (uint32_t d = dw0; d < dw1; d += 2 * PFC) {              // wave-uniform
+                fetch(d + PFC, zB, cB);
+                count(zA, cA);
+                fetch(d + 2 * PFC, zA, cA);
+                count(zB, cB);
+            }
         }
     }
     __syncthreads();
+    GEM_DSTAMP(1);                                                      // counted
     const uint32_t gbase = *gbase_p;
     uint32_t ctot = 0, cstart;
     {   // cell c's run starts at the cells' exclusive prefix; wave w writes behind the waves before it
@@ -299,31 +313,45 @@ __device__ __noinline__ DenseResult dense_tile(const uint4* __restrict__ rec, ui
         for (int ww = 0; ww < NW; ++ww) { wc[ww * CELLS + tid] = acc; acc += cw[ww]; }
     }
     __syncthreads();
-    {   // placement, four descriptors' records in flight
+    GEM_DSTAMP(2);                                                      // cursors
+    {   // placement: the records of the next four descriptors are in flight while the current four are ranked and stored
         constexpr int PFP = 4;
-        for (uint32_t d = dw0; d < dw1; d += PFP) {                      // wave-uniform
-            uint4 r[PFP]; uint32_t cn[PFP];
+        uint4 rA[PFP], rB[PFP]; uint32_t cA[PFP], cB[PFP];
+        auto fetch = [&](uint32_t d, uint4 (&r)[PFP], uint32_t (&cn)[PFP]) {
 #pragma unroll
             for (int x = 0; x < PFP; ++x) {
-                const uint2 de = dlc[min(d + x, dw1 - 1u)];
+                const uint2 de = dlc[min(d + x, nd - 1u)];
                 cn[x] = d + x < dw1 ? de.y : 0u;
                 r[x] = rec[de.x + ((uint32_t)lane < de.y ? (uint32_t)lane : 0u)];
             }
+        };
+        auto place = [&](const uint4 (&r)[PFP], const uint32_t (&cn)[PFP]) {
 #pragma unroll
             for (int x = 0; x < PFP; ++x) {
                 const bool on = (uint32_t)lane < cn[x];
                 const uint32_t cell = r[x].z & 0xffffu;
+                // per-bit match: a descriptor's 64 points spread over more cells than wave_peers_few's eight (measured: 70k vs 120k cycles)
                 const uint64_t peers = wave_peers(on, cell, 2 * TS);
                 const uint32_t rank = (uint32_t)__popcll(peers & lt);
                 uint32_t old = 0;
-                if (on && rank == 0) { old = wcw[cell]; wcw[cell] = old + (uint32_t)__popcll(peers); }
+                if (on && rank == 0) old = atomicAdd(&wcw[cell], (uint32_t)__popcll(peers));   // the wave's LDS operations execute in order
                 old = (uint32_t)__shfl((int)old, on ? __ffsll((unsigned long long)peers) - 1 : lane);
                 if (on) { if constexpr (ATTR != 0) srt[gbase + old + rank] = r[x]; else srt[gbase + old + rank] = make_uint2(r[x].x, r[x].y); }
+            }
+        };
+        if (dw0 < dw1) {
+            fetch(dw0, rA, cA);
+            for (uint32_t d = dw0; d < dw1; d += 2 * PFP) {              // wave-uniform
+                fetch(d + PFP, rB, cB);
+                place(rA, cA);
+                fetch(d + 2 * PFP, rA, cA);
+                place(rB, cB);
             }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    GEM_DSTAMP(3);                                                      // placed
     DenseResult out; out.e = e; out.s = s; out.n = ctot; out.last = 0xffffffffu;
     {   // walk the cell's run, the records four steps ahead in flight (clamped address: never a branch round a load)
         constexpr int D = 4;
@@ -347,7 +375,10 @@ __device__ __noinline__ DenseResult dense_tile(const uint4* __restrict__ rec, ui
             }
         }
     }
+    GEM_DSTAMP(4);                                                      // this thread's chain done
     __syncthreads();
+    GEM_DSTAMP(5);                                                      // all chains done
+#undef GEM_DSTAMP
     {   // back to the fast path's invariant: every rank row has count 0
         uint4* zr = reinterpret_cast<uint4*>(wc);
         for (int c = tid; c < CELLS; c += NT) zr[c] = make_uint4(0, 0, 0, 0);
@@ -648,7 +679,8 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
                     }
                     apply_increments();
                     const DenseResult dr = dense_tile<TS, NT, ATTR>(a.rec, a.srt, reinterpret_cast<uint32_t*>(rowp), dlc, scratch, misc + 2,
-                                                                    nd, ce[0], cs[0], a.mahal, a.var_floor);
+                                                                    nd, ce[0], cs[0], a.mahal, a.var_floor,
+                                                                    a.dbg && sweep == a.dbg_sweep ? a.dbg + (size_t)tile * 16 + 8 : nullptr);
                     ce[0] = dr.e; cs[0] = dr.s;
                     if (dr.n) tmask |= 1u;
                     if (ATTR != 0 && dr.last != 0xffffffffu) write_attr(0, dr.last);

@@ -79,6 +79,7 @@ struct FuseArgs {
     unsigned long long* counters;      // optional: [1] += distinct touched cells per sweep (per pass when count_per_pass)
     uint4*            srt;             // sorted arena (as many records as `rec`): dense tiles counting-sort their records by cell into it
     uint32_t*         srt_top;         // its bump pointer (records), zeroed by the k_bin of the pass
+    int               dbg_sweep;       // debug stamps of the dense path: which sweep
     uint32_t          dense_min;       // a (tile, sweep) with more records than this takes the dense path (16x16 tiles only)
     int   count_per_pass;              // the sweeps are one cloud cut into pieces: count a cell once
     unsigned long long* dbg;           // optional: [T][16] cycle-counter stamps of thread 0 (profiling aid)

@@ -33,6 +33,14 @@ else:
 T = 4096
 buf = np.zeros((T, 16), np.uint64)
 n = lib.gem_debug_fuse_stamps(m._h, 0, buf.ctypes.data_as(C.c_void_p), T)
+if len(sys.argv) > 1 and sys.argv[1] == "c3":          # stamps 8..13 of a tile: the dense path of sweep GEM_DBG_SWEEP
+    d = buf[:n, 8:14].astype(np.int64)
+    dn = d[d[:, 0] > 0]
+    dur = dn[:, 5] - dn[:, 0]
+    print("dense tiles", len(dn), "of", n)
+    for i in np.argsort(-dur)[:6]:
+        print("dense tile: total", dur[i], "count/cursors/place/walk(thread 0)/walk(all)", list(np.diff(dn[i])))
+    buf[:, 8:] = 0
 st = buf[:n].astype(np.int64)
 names = ["start", "tile_ld", "heads", "filled+rec_issue", "rec+count", "cellscan", "placed", "walked", "stores", "x"]
 t0 = st[:, 0].min()
