@@ -56,6 +56,10 @@ struct gem_handle {
     struct PassBuffers {
         Arena rec, srt, seg, flag, gflag;   // records, descriptor table, touched stamps per (tile, sweep) and per (sweep, tile, 32 units)
         Arena tables;                  // batched-call tables (frames, sweep_unit0, sweep_first, var_updates)
+        void* host_tables = nullptr;   // their pinned staging copy: the upload is asynchronous, `tables_done` guards its reuse
+        size_t host_cap = 0;
+        hipEvent_t tables_done = nullptr;
+        bool tables_recorded = false;
         hipEvent_t bin_done = nullptr, fuse_done = nullptr;
         bool fuse_recorded = false;
         uint32_t epoch = 0;            // touched-flag stamp of the last pass (0 = the flag table holds no live stamps)
@@ -289,8 +293,10 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     // must be complete when the call is made (they are not ordered against the handle's streams).
     // The cross-stream event pair costs ~3 us per pass (measured), so it only pays for big passes
     // (batches / aggregated clouds: C4 379 -> 313 us); single sweeps stay on one stream.
-    const bool overlap = h->overlap && in.n >= h->overlap_min_points && h->stream == h->own_stream && h->bin_stream &&
-                         !h->counting && !h->dbg_on;
+    bool overlap = h->overlap && in.n >= h->overlap_min_points && h->stream == h->own_stream && !h->counting && !h->dbg_on;
+    if (overlap && !h->bin_stream && hipStreamCreateWithFlags(&h->bin_stream, hipStreamNonBlocking) != hipSuccess) {
+        h->bin_stream = nullptr; overlap = false; (void)hipGetLastError();
+    }
     // one launch per frame for a stream of single sweeps (k_frame): needs the other half of the double buffer
     const bool defer = h->defer && in.device_input && in.src == 0 && !batched && attr == 0 && ts == 4 && !overlap &&
                        !h->counting && !h->dbg_on;
@@ -300,7 +306,10 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     int rc;
     if ((rc = ensure(h, pb.rec, (size_t)B * U * sizeof(uint4)))) return rc;
     if ((rc = ensure(h, pb.srt, (size_t)B * U * sizeof(uint4) + 16))) return rc;     // sorted arena + its bump pointer (last 16 bytes)
-    if (overlap && pb.fuse_recorded) GEM_HIP(h, hipStreamWaitEvent(sbin, pb.fuse_done, 0));   // k_fuse of pass p-2 has read these buffers
+    // k_fuse of pass p-2 has read these buffers.  Waited for on the HOST: a hipStreamWaitEvent on an event that is still
+    // far from complete delayed the start of k_bin behind it (C5: 1.52 -> 1.64-1.81 ms per pass, the overlap mostly lost);
+    // the host stays at most two (big) passes ahead of the device, which costs nothing.
+    if (overlap && pb.fuse_recorded) GEM_HIP(h, hipEventSynchronize(pb.fuse_done));
     {   // descriptor table [sweep][tile][unit in sweep]: k_fuse_list zeroes what it consumes, so the table only
         // has to be cleared when it is (re)allocated
         const size_t need = (size_t)in.n_sweeps * T * bpad * sizeof(uint16_t);
@@ -333,14 +342,26 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
         const size_t o_var = o_orig + sizeof(int) * in.n_sweeps;
         const size_t total = o_var + sizeof(float) * in.n_sweeps;
         if ((rc = ensure(h, pb.tables, total))) return rc;
-        std::vector<unsigned char> host(total, 0);
-        for (int s = 0; s < in.n_sweeps; ++s) fill_frame(h, &in.params[s], reinterpret_cast<FrameConst*>(host.data() + o_frames)[s]);
-        memcpy(host.data() + o_unit0, unit0.data(), sizeof(int) * (in.n_sweeps + 1));
-        memcpy(host.data() + o_first, in.offsets, sizeof(long long) * (in.n_sweeps + 1));
-        if (!orig0.empty()) memcpy(host.data() + o_orig, orig0.data(), sizeof(int) * in.n_sweeps);
-        if (in.var_updates) memcpy(host.data() + o_var, in.var_updates, sizeof(float) * in.n_sweeps);
-        GEM_HIP(h, hipMemcpyAsync(pb.tables.p, host.data(), total, hipMemcpyHostToDevice, sbin));
-        GEM_HIP(h, hipStreamSynchronize(sbin));           // `host` is a local
+        // staged in pinned memory so that the upload does not make the host wait for the stream (a pageable source would:
+        // the call then cost a whole k_bin of host time, 240 us per C4 batch)
+        if (total > pb.host_cap) {
+            if (pb.tables_recorded) GEM_HIP(h, hipEventSynchronize(pb.tables_done));
+            if (pb.host_tables) GEM_HIP(h, hipHostFree(pb.host_tables));
+            pb.host_tables = nullptr; pb.host_cap = 0;
+            GEM_HIP(h, hipHostMalloc(&pb.host_tables, total * 2, hipHostMallocDefault));
+            pb.host_cap = total * 2;
+        }
+        if (!pb.tables_done) GEM_HIP(h, hipEventCreateWithFlags(&pb.tables_done, hipEventDisableTiming));
+        if (pb.tables_recorded) GEM_HIP(h, hipEventSynchronize(pb.tables_done));     // the previous upload from this buffer has been read
+        unsigned char* host = static_cast<unsigned char*>(pb.host_tables);
+        memset(host, 0, total);
+        for (int s = 0; s < in.n_sweeps; ++s) fill_frame(h, &in.params[s], reinterpret_cast<FrameConst*>(host + o_frames)[s]);
+        memcpy(host + o_unit0, unit0.data(), sizeof(int) * (in.n_sweeps + 1));
+        memcpy(host + o_first, in.offsets, sizeof(long long) * (in.n_sweeps + 1));
+        if (!orig0.empty()) memcpy(host + o_orig, orig0.data(), sizeof(int) * in.n_sweeps);
+        if (in.var_updates) memcpy(host + o_var, in.var_updates, sizeof(float) * in.n_sweeps);
+        GEM_HIP(h, hipMemcpyAsync(pb.tables.p, host, total, hipMemcpyHostToDevice, sbin));
+        GEM_HIP(h, hipEventRecord(pb.tables_done, sbin)); pb.tables_recorded = true;
         unsigned char* d = static_cast<unsigned char*>(pb.tables.p);
         ba.frames = reinterpret_cast<const FrameConst*>(d + o_frames);
         ba.sweep_unit0 = reinterpret_cast<const int*>(d + o_unit0);
@@ -451,7 +472,9 @@ int gem_create(const gem_map_config* cfg, gem_handle** out)
     if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     h->stream = h->own_stream;
     if ((e = hipEventCreateWithFlags(&h->copy_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-    if ((e = hipStreamCreateWithFlags(&h->bin_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    // (the second stream, for the bin / fuse overlap of big passes, is created by the first pass that is big enough: ROCm maps
+    //  streams onto four hardware queues, and streams that share one serialise -- a handle that only ever fuses single sweeps
+    //  should not take a queue from its neighbours.  Measured: a batched C4 call 263 -> 345 us with a second handle alive.)
     for (auto& b : h->pb) {
         if ((e = hipEventCreateWithFlags(&b.bin_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&b.fuse_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
@@ -496,6 +519,8 @@ void gem_destroy(gem_handle* h)
     for (Arena* a : {&h->stage, &h->scratch, &h->dbg}) if (a->p) hipFree(a->p);
     for (auto& b : h->pb) {
         for (Arena* a : {&b.rec, &b.srt, &b.seg, &b.flag, &b.gflag, &b.tables}) if (a->p) hipFree(a->p);
+        if (b.host_tables) hipHostFree(b.host_tables);
+        if (b.tables_done) hipEventDestroy(b.tables_done);
         if (b.bin_done) hipEventDestroy(b.bin_done);
         if (b.fuse_done) hipEventDestroy(b.fuse_done);
     }

