@@ -3,7 +3,8 @@
  *
  * Plain C restatement of the reference's CUDA hot path.  Every function cites the reference
  * lines it follows (GPU = elevation_mapping/elevation_mapping/cuda/gpu_process.cu).
- * PARITY UNPINNED by the reference (it has no tests / golden vectors); pinned by our own KATs.
+ * Pinned against the reference's own gpu_process.cu compiled for the CPU (oracle/ref_build, tests/test_reference_compiled.py)
+ * and by our own KATs; the reference itself has no tests / golden vectors.  See gem_oracle.h.
  *
  * Third-party arithmetic restated here: Eigen fixed-size products / norm used inside
  * G_pointsprocess (GPU:403-425).  Eigen is not vendored and its version is unpinned

@@ -10,10 +10,17 @@
  * Citations use GPU = elevation_mapping/elevation_mapping/cuda/gpu_process.cu,
  * SPB.cpp = .../src/sensor_processors/SensorProcessorBase.cpp, RMU.cpp = .../src/RobotMotionMapUpdater.cpp.
  *
- * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures and cannot be
- * built in this environment (needs nvcc, Eigen, ROS, PCL, kindr).  The oracle is pinned only
- * by the hand-derived known-answer tests in tests/test_oracle_kat.py and by the golden
- * fixtures it generated itself (tests/golden/, scripts committed).
+ * PINNING: the reference ships no tests, golden vectors or fixtures, and its own build (nvcc, Eigen,
+ * ROS, PCL, kindr) is not possible in this environment.  The oracle is pinned
+ *   (1) against the reference's OWN gpu_process.cu compiled for the CPU (oracle/ref_build/ -> oracle/_ref/libgem_ref.so:
+ *       kernels run sequentially over their grids, CUDA runtime + Eigen are stand-ins, nothing else of its text is
+ *       touched) -- tests/test_reference_compiled.py: indices, variances, fused layers, Move, loop-closure shifts bit
+ *       for bit; slope / traversability up to the C library's float trigonometry;
+ *   (2) by the hand-derived known-answer tests in tests/test_oracle_kat.py;
+ *   (3) by the golden fixtures it generated itself (tests/golden/, scripts committed).
+ * Not covered by (1): Eigen's internal evaluation order (restated identically in the stand-in and here), nvcc's FMA
+ * contraction (a build-flag effect; source-level arithmetic is what is replayed), the structured-light / stereo /
+ * perfect sensor models and the motion updater (CPU-side C++ of the reference that needs kindr + ROS).
  *
  * Build with -ffp-contract=off: every float product and sum below is individually rounded.
  */

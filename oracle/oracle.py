@@ -1,8 +1,8 @@
 """ctypes binding of the CPU ORACLE (oracle/gem_oracle.c).
 
 TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
-cpu_baseline leg.  Nothing under gem_amd/ imports this module.  PARITY UNPINNED by the reference
-(no tests / golden vectors there); pinned by tests/test_oracle_kat.py.
+cpu_baseline leg.  Nothing under gem_amd/ imports this module.  Pinned against the reference's own
+gpu_process.cu compiled for the CPU (oracle/ref.py, tests/test_reference_compiled.py) and by tests/test_oracle_kat.py.
 """
 from __future__ import annotations
 

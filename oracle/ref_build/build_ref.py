@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Builds oracle/_ref/libgem_ref.so: the REFERENCE's own gpu_process.cu, compiled for the CPU.
+
+TEST INFRASTRUCTURE ONLY.  The source is read where it lies (/root/reference/...), nothing of it is copied into the
+repository: the only textual change is the kernel-launch syntax (`k<<<g, b>>>(args)` -> `GEMREF_LAUNCH(g, b, k(args))`,
+which g++ can parse), made in a temporary file that is deleted after the compile.  CUDA runtime calls, `__global__`,
+threadIdx ... come from cuda_runtime.h next to this script (kernels run sequentially over the grid), Eigen from the
+stand-in under Eigen/ (Eigen is not installed here; its fixed-size product order is restated there, see its header).
+Compiled with -ffp-contract=off: the comparison is with the reference's source-level arithmetic (nvcc would
+contract a*b+c into FMAs, a build-flag effect that no CPU build of the reference shares either).
+
+    python oracle/ref_build/build_ref.py [--reference /root/reference] [--force]
+"""
+from __future__ import annotations
+
+import argparse
+import re
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+OUT = HERE.parent / "_ref" / "libgem_ref.so"
+REL = "elevation_mapping/elevation_mapping/cuda/gpu_process.cu"
+
+
+def rewrite_launches(text: str) -> tuple[str, int]:
+    """`name<<<grid, block>>>(args)` -> `GEMREF_LAUNCH(grid, block, name(args))` (arguments may span lines)."""
+    out, pos, n = [], 0, 0
+    for m in re.finditer(r"(\w+)\s*<<<([^<>]*?)>>>\s*\(", text):
+        if m.start() < pos:
+            continue
+        line_start = text.rfind("\n", 0, m.start()) + 1
+        if "//" in text[line_start:m.start()]:             # a commented-out launch
+            continue
+        depth, i = 1, m.end()
+        while depth:
+            depth += {"(": 1, ")": -1}.get(text[i], 0)
+            i += 1
+        grid, block = [s.strip() for s in m.group(2).split(",")]
+        out.append(text[pos:m.start()])
+        out.append(f"GEMREF_LAUNCH({grid}, {block}, {m.group(1)}({text[m.end():i - 1]}))")
+        pos, n = i, n + 1
+    out.append(text[pos:])
+    return "".join(out), n
+
+
+def build(reference: Path = Path("/root/reference"), force: bool = False, verbose: bool = False) -> Path | None:
+    src = reference / REL
+    if not src.exists():
+        return OUT if OUT.exists() else None                # e.g. on the GPU box: use the prebuilt library
+    deps = [src, HERE / "cuda_runtime.h", HERE / "ref_exports.inc", HERE / "Eigen" / "Core", Path(__file__)]
+    if OUT.exists() and not force and all(OUT.stat().st_mtime >= d.stat().st_mtime for d in deps):
+        return OUT
+    text, n = rewrite_launches(src.read_text(errors="replace"))
+    if n < 10:
+        raise RuntimeError(f"only {n} kernel launches found in {src}")
+    OUT.parent.mkdir(exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        tu = Path(tmp) / "gem_ref_tu.cpp"
+        tu.write_text(text + f'\n#include "{HERE / "ref_exports.inc"}"\n')
+        cmd = ["g++", "-O2", "-ffp-contract=off", "-fno-fast-math", "-std=c++14", "-w", "-fPIC", "-shared",
+               f"-I{HERE}", str(tu), "-o", str(OUT)]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("g++ failed on the reference translation unit:\n" + res.stderr[-4000:])
+    return OUT
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default="/root/reference")
+    ap.add_argument("--force", action="store_true")
+    a = ap.parse_args()
+    p = build(Path(a.reference), a.force, verbose=True)
+    print(p if p else "reference not found and no prebuilt library", file=sys.stderr if not p else sys.stdout)

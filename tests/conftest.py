@@ -44,3 +44,12 @@ def oracle_mod():
     import oracle as om
     om.build()
     return om
+
+
+@pytest.fixture(scope="session")
+def ref_mod():
+    """oracle/_ref/libgem_ref.so: the reference's own gpu_process.cu compiled for the CPU (oracle/ref_build)."""
+    import ref
+    if ref.lib() is None:
+        pytest.skip("no /root/reference to build from and no prebuilt oracle/_ref/libgem_ref.so")
+    return ref

@@ -377,6 +377,38 @@ def test_mixed_fast_and_generic_batches(oracle_mod):
         assert_maps_match(gpu, ref)
 
 
+# ---- the HIP path against the reference's own code (no oracle in between) ---------------------------------------------
+def test_hip_path_against_the_compiled_reference(ref_mod):
+    """libgem_hip (through the C ABI) vs oracle/_ref/libgem_ref.so, the reference's gpu_process.cu compiled for the CPU:
+    Move, then per frame Mapvar_update + Process_points + Fuse on the reference side, gem_mapvar_update + gem_add on ours
+    (BASELINE config 1 geometry, the reference's hard-coded reject filter), then the traversability stage."""
+    L, res = 200, 0.1
+    gpu, ref = ElevationMap(L, res), ref_mod.RefMap(L, res)
+    rng = np.random.default_rng(77)
+    pos = np.zeros(3)
+    for step in range(4):
+        pos[:2] += rng.uniform(-1.5, 1.5, 2)
+        pg, pr = gpu.move(pos), ref.move(pos)
+        f = synth._frame_for(synth.pose_matrix(pos[0] + 0.1, pos[1], 0.55, 0.4 * step, 0.01, -0.02), SensorModel.velodyne())
+        f.filter = RejectFilter.reference()
+        c = synth.random_cloud(70 + step, 12_000, 9.0, z_sigma=0.08)
+        gpu.mapvar_update(1e-5 * step); ref.mapvar_update(1e-5 * step)
+        out = ref.process_points(f, c[:, 0], c[:, 1], c[:, 2])
+        ref.fuse(out["index"], out["height"], out["var"])
+        gpu.add(f, c)
+        assert (out["index"] >= 0).mean() > 0.05
+        for name in ("elevation", "variance"):
+            g, r = gpu.layer(name), ref.layer(name)
+            bad = np.flatnonzero(g.ravel() != r.ravel())
+            assert bad.size == 0, f"step {step} {name}: {bad.size} cells differ: ours {g.ravel()[bad[:4]]} reference {r.ravel()[bad[:4]]}"
+    fg, fr = gpu.map_feature(), ref.map_feature()
+    live = ref.layer("elevation") != -10
+    assert live.sum() > 2000
+    assert np.array_equal(fg["rough"][live], fr["rough"][live])
+    for k in ("slope", "traver"):
+        assert np.max(np.abs(fg[k][live] - fr[k][live])) <= 1e-4, k          # float trigonometry: implementation-defined last bits
+
+
 # ---- dense tiles (k_fuse_list hands the tile to its second copy, which counting-sorts the sweep's records by cell) ----------
 @pytest.mark.parametrize("dense_min", [0, 300])
 def test_dense_tile_path(oracle_mod, monkeypatch, dense_min):
