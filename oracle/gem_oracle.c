@@ -51,6 +51,7 @@ gemo_map* gemo_create(int length, float resolution, float mahalanobis, float var
     m->center[0] = m->center[1] = 0.0f;
     m->start[0] = m->start[1] = 0;
     m->sensor_z = 0.0f;
+    m->obstacle_threshold = 0.7f;
     return m;
 }
 
@@ -315,7 +316,16 @@ static int process_one(const gemo_map* m, const gemo_frame* f, float x, float y,
     return 0;
 }
 
-int gemo_process_points(const gemo_map* m, const gemo_frame* f, int n,
+/* GPU:430-439: the lowest scan point of the (geographic) cell, with the reference's 3 * var (not 3 * sigma) margin */
+static void lowest_update(gemo_map* m, float xt, float yt, float h, float var)
+{
+    int g = gemo_points_to_index(m, xt, yt);                                  /* GPU:430 */
+    if (g == -1) return;
+    m->lowest[g] = fminf(h, m->lowest[g]);                                    /* GPU:434 atomicMin (GPU:372-382) */
+    if (h == m->lowest[g]) m->lowest[g] = m->lowest[g] + 3 * var;             /* GPU:435-438 */
+}
+
+int gemo_process_points(gemo_map* m, const gemo_frame* f, int n,
                         float* x, float* y, float* z, const int* orig_index,
                         int* map_index, float* var, float* x_ts, float* y_ts, float* z_ts)
 {
@@ -324,6 +334,7 @@ int gemo_process_points(const gemo_map* m, const gemo_frame* f, int n,
         int ok = process_one(m, f, x[i], y[i], z[i], orig_index ? orig_index[i] : i,
                              &map_index[i], &var[i], &x_ts[i], &y_ts[i], &z_ts[i]);
         if (!ok) { x[i] = -1.0f; y[i] = -1.0f; z[i] = -1.0f; }               /* GPU:443-446 */
+        else lowest_update(m, x_ts[i], y_ts[i], z_ts[i], var[i]);
         accepted += ok;
     }
     return accepted;
@@ -410,6 +421,7 @@ int gemo_add(gemo_map* m, const gemo_frame* f, int n, const float* xyzi, const u
         int idx; float v, xt, yt, zt;
         int ok = process_one(m, f, x, y, z, orig_index ? orig_index[i] : i, &idx, &v, &xt, &yt, &zt);
         accepted += ok;
+        if (ok) lowest_update(m, xt, yt, zt, v);
         if (idx < 0 || zt == -1.0f) continue;                                 /* GPU:482 */
         int r = 0, g = 0, b = 0;
         if (rgb) { r = (rgb[i] >> 16) & 0xff; g = (rgb[i] >> 8) & 0xff; b = rgb[i] & 0xff; }

@@ -62,6 +62,7 @@ typedef struct gemo_map {
     float center[2];              /* GPU:30 */
     int   start[2];               /* GPU:31 */
     float sensor_z;               /* GPU:33 */
+    float obstacle_threshold;     /* GPU:37; 0.7 unless gemo_set_obstacle_threshold() (elevation_map.yaml)     */
 } gemo_map;
 
 gemo_map* gemo_create(int length, float resolution, float mahalanobis, float var_floor);
@@ -74,10 +75,14 @@ int  gemo_move(gemo_map* m, const float pos[3], float out_center[2], int out_sta
 int  gemo_points_to_index(const gemo_map* m, float px, float py);
 int  gemo_points_to_map_index(const gemo_map* m, float px, float py);
 
-/* GPU:384-455 (G_pointsprocess) minus the racy map_lowest side effect.  x,y,z are overwritten with
+/* GPU:384-455 (G_pointsprocess), including its map_lowest side effect (GPU:432-439) in the schedule in which point i
+ * finishes before point i + 1 starts: lowest[g] = min(lowest[g], h); if (h == lowest[g]) lowest[g] += 3 * var.
+ * (On a GPU the read-modify-write races; this schedule is what the reference's code produces when its grid is run
+ * sequentially, and it is the one libgem_hip reproduces.)  map_lowest is indexed by the GEOGRAPHIC cell, not by the
+ * circular-buffer cell (GPU:430 PointsToIndex).  x,y,z are overwritten with
  * -1 for rejected points exactly as the reference does to its device copies (GPU:443-446).
  * orig_index may be NULL (stereo model only).  Returns number of accepted points. */
-int  gemo_process_points(const gemo_map* m, const gemo_frame* f, int n,
+int  gemo_process_points(gemo_map* m, const gemo_frame* f, int n,
                          float* x, float* y, float* z, const int* orig_index,
                          int* map_index, float* var, float* x_ts, float* y_ts, float* z_ts);
 
@@ -121,6 +126,10 @@ typedef struct gemo_motion_state {
 void   gemo_motion_init(gemo_motion_state* s, double covariance_scale);
 double gemo_motion_update(gemo_motion_state* s, const double pos[3], const double R_IB[9],
                           const double cov6x6[36], const double map_R[9]);
+
+/* GPU:1304-1318 (Raytracing): G_Raytracing (GPU:708-891) then G_Clear_maplowest (GPU:232-239).  gem_oracle_raytrace.c */
+void gemo_raytracing(gemo_map* m);
+void gemo_set_obstacle_threshold(gemo_map* m, float t);
 
 #ifdef __cplusplus
 }

@@ -30,7 +30,7 @@ class OMap(C.Structure):
                 ("elevation", POINTER(c_float)), ("variance", POINTER(c_float)), ("intensity", POINTER(c_float)),
                 ("traver", POINTER(c_float)), ("lowest", POINTER(c_float)),
                 ("colorR", POINTER(c_int)), ("colorG", POINTER(c_int)), ("colorB", POINTER(c_int)),
-                ("center", c_float * 2), ("start", c_int * 2), ("sensor_z", c_float)]
+                ("center", c_float * 2), ("start", c_int * 2), ("sensor_z", c_float), ("obstacle_threshold", c_float)]
 
 
 class OMotion(C.Structure):
@@ -39,7 +39,8 @@ class OMotion(C.Structure):
 
 
 def build(force: bool = False) -> Path:
-    srcs = [HERE / "gem_oracle.c", HERE / "gem_oracle_motion.c", HERE / "gem_oracle.h"]
+    srcs = [HERE / "gem_oracle.c", HERE / "gem_oracle_motion.c", HERE / "gem_oracle_feature.c", HERE / "gem_oracle_raytrace.c",
+            HERE / "gem_oracle.h"]
     if force or not LIB.exists() or any(s.stat().st_mtime > LIB.stat().st_mtime for s in srcs):
         subprocess.run(["make", "-C", str(HERE), "-B" if force else "-s", "libgem_oracle.so"], check=True,
                        capture_output=True)
@@ -67,6 +68,8 @@ def lib() -> C.CDLL:
         l.gemo_map_feature.argtypes = [POINTER(OMap), c_void_p, c_void_p, c_void_p]
         l.gemo_map_optmove.argtypes = [POINTER(OMap), POINTER(c_float), c_float, POINTER(c_float)]
         l.gemo_map_closeloop.argtypes = [POINTER(OMap), POINTER(c_float), c_float]
+        l.gemo_raytracing.argtypes = [POINTER(OMap)]
+        l.gemo_set_obstacle_threshold.argtypes = [POINTER(OMap), c_float]
         l.gemo_add.restype = c_int
         l.gemo_add.argtypes = [POINTER(OMap), POINTER(OFrame), c_int, c_void_p, c_void_p, c_void_p, POINTER(c_longlong)]
         l.gemo_motion_init.argtypes = [POINTER(OMotion), c_double]
@@ -168,6 +171,13 @@ class OracleMap:
     def map_closeloop(self, xy, height_update: float):
         p = (c_float * 2)(float(xy[0]), float(xy[1]))
         self._l.gemo_map_closeloop(self._m, p, c_float(height_update))
+
+    def raytracing(self):
+        """Raytracing (gpu_process.cu:1304-1318): visibility clean-up, then lowest = 10 everywhere."""
+        self._l.gemo_raytracing(self._m)
+
+    def set_obstacle_threshold(self, t: float):
+        self._l.gemo_set_obstacle_threshold(self._m, c_float(t))
 
     def map_feature(self):
         """G_Mapfeature (gpu_process.cu:549-670): returns dict(rough, slope, traver) and updates the traver layer."""

@@ -38,6 +38,7 @@ def lib():
         l.gemref_map_optmove.argtypes = [POINTER(c_float), c_float, c_float, c_int, POINTER(c_float)]
         l.gemref_map_closeloop.argtypes = [POINTER(c_float), c_float, c_int, c_float]
         l.gemref_map_feature.argtypes = [c_int] + [c_void_p] * 9
+        l.gemref_raytracing.argtypes = [c_int]
         l.gemref_get_layer.argtypes = [c_int, c_void_p]; l.gemref_get_layer.restype = c_int
         l.gemref_set_layer.argtypes = [c_int, c_void_p]; l.gemref_set_layer.restype = c_int
         l.gemref_get_pose.argtypes = [POINTER(c_float), POINTER(c_int)]
@@ -106,6 +107,9 @@ class RefMap:
     def map_closeloop(self, xy, height_update: float):
         p = (c_float * 2)(float(xy[0]), float(xy[1]))
         self._l.gemref_map_closeloop(p, float(height_update), self.length, self.resolution)
+
+    def raytracing(self):
+        self._l.gemref_raytracing(self.length)
 
     def map_feature(self):
         n = self.length * self.length

@@ -190,3 +190,37 @@ def test_add_equals_reference_process_then_fuse(ref_mod, oracle_mod):
         assert_layers_equal(r, o, ("elevation", "variance"))
         r.mapvar_update(2e-5); o.mapvar_update(2e-5)
     assert (o.layer("elevation") != -10).sum() > 500
+
+
+@pytest.mark.parametrize("L,res", [(100, 0.1), (75, 0.2)])
+def test_lowest_scan_point_and_raytracing_match_the_reference(ref_mod, oracle_mod, L, res):
+    """The map_lowest side output of Process_points (GPU:430-439, in the schedule a sequential run of the grid produces)
+    and the visibility clean-up Raytracing (GPU:708-891, 1304-1318) that consumes it."""
+    from gem_amd import synth
+    r, o = pair(ref_mod, oracle_mod, L, res)
+    rng = np.random.default_rng(L)
+    deleted = 0
+    for step in range(4):
+        pos = [float(rng.uniform(-1, 1)) * (step + 1), float(rng.uniform(-1, 1)) * (step + 1), 0.45 + 0.1 * step]
+        assert all(np.array_equal(a, b) for a, b in zip(r.move(pos), o.move(pos)))
+        f = reference_frame(synth.pose_matrix(pos[0], pos[1], pos[2], 0.7 * step, 0.01, 0.02))
+        f.lower, f.upper = -3.0, 3.0
+        c = synth.random_cloud(200 + step, 30_000, 0.5 * L * res, z_sigma=0.25)
+        a, b = r.process_points(f, c[:, 0], c[:, 1], c[:, 2]), o.process_points(f, c[:, 0], c[:, 1], c[:, 2])
+        assert np.array_equal(a["index"], b["index"])
+        assert_layers_equal(r, o, ("lowest",))
+        assert (o.layer("lowest") != (100.0 if step == 0 else 10.0)).mean() > 0.05
+        r.fuse(a["index"], a["height"], a["var"]); o.fuse(b["index"], b["height"], b["var"])
+        # an obstacle field on top: walls that the line of sight over the scanned ground can and cannot explain
+        e = o.layer("elevation").copy()
+        walls = (rng.random((L, L)) < 0.08) & (e != -10)
+        e[walls] += rng.uniform(0.2, 2.5, walls.sum()).astype(F32)
+        t = np.where(walls, F32(0.2), F32(0.9)).astype(F32); t[rng.random((L, L)) < 0.05] = F32(0.1)
+        for m in (r, o):
+            m.set_layer("elevation", e); m.set_layer("traver", t)
+        before = (e != -10).sum()
+        r.raytracing(); o.raytracing()
+        assert_layers_equal(r, o, ("elevation", "variance", "lowest"))
+        deleted += before - (o.layer("elevation") != -10).sum()
+        assert np.all(o.layer("lowest") == 10.0)
+    assert deleted > 20                                      # the clean-up did delete cells, and not all of them
