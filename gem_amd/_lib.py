@@ -65,6 +65,8 @@ SIGNATURES = {
     "gem_map_feature": (c_int, [c_void_p] + [c_void_p] * 9),
     "gem_map_optmove": (c_int, [c_void_p, POINTER(c_float), c_float, POINTER(c_float)]),
     "gem_map_closeloop": (c_int, [c_void_p, POINTER(c_float), c_float]),
+    "gem_set_lowest_tracking": (c_int, [c_void_p, c_int]),
+    "gem_raytracing": (c_int, [c_void_p]),
     "gem_set_timing": (c_int, [c_void_p, c_int]),
     "gem_set_counting": (c_int, [c_void_p, c_int]),
     "gem_get_stats": (c_int, [c_void_p, POINTER(Stats), c_int]),

@@ -25,7 +25,7 @@ from . import _lib
 # GridMap layer names of the reference (ElevationMap.cpp:43-44) -> device layers (gpu_process.cu:20-28)
 LAYER_BY_NAME = {
     "elevation": _lib.LAYER_ELEVATION, "variance": _lib.LAYER_VARIANCE, "intensity": _lib.LAYER_INTENSITY,
-    "traver": _lib.LAYER_TRAVER, "lowest_scan_point": _lib.LAYER_LOWEST,
+    "traver": _lib.LAYER_TRAVER, "lowest_scan_point": _lib.LAYER_LOWEST, "lowest": _lib.LAYER_LOWEST,
     "color_r": _lib.LAYER_COLOR_R, "color_g": _lib.LAYER_COLOR_G, "color_b": _lib.LAYER_COLOR_B,
     "rough": _lib.LAYER_ROUGH, "slope": _lib.LAYER_SLOPE,
 }
@@ -219,10 +219,10 @@ class ElevationMap:
     """
 
     def __init__(self, length: int, resolution: float, mahalanobis_threshold: float = 5.0,
-                 variance_floor: float = 1e-4, strip: tuple = (0, 0), device: int = -1):
+                 variance_floor: float = 1e-4, strip: tuple = (0, 0), device: int = -1, obstacle_threshold: float = 0.7):
         self._lib = _lib.load()
         cfg = _lib.MapConfig(int(length), float(resolution), float(mahalanobis_threshold), float(variance_floor),
-                             0.7, int(strip[0]), int(strip[1]), int(device))
+                             float(obstacle_threshold), int(strip[0]), int(strip[1]), int(device))
         h = C.c_void_p()
         rc = self._lib.gem_create(C.byref(cfg), C.byref(h))
         if rc != _lib.GEM_OK:
@@ -343,6 +343,14 @@ class ElevationMap:
         self._check(self._lib.gem_map_closeloop(self._h, p, float(height_update)), "gem_map_closeloop")
 
     # -- Map_feature (EMg.cpp:410): traversability stage on the fused map --------------------------------------
+    # -- visibility clean-up (Raytracing, EMg.cpp:421) --------------------------------------------------------------
+    def set_lowest_tracking(self, on: bool) -> None:
+        """Maintain the lowest-scan-point layer (gpu_process.cu:430-439) in the fuse kernels; needed by raytracing()."""
+        self._check(self._lib.gem_set_lowest_tracking(self._h, int(bool(on))), "gem_set_lowest_tracking")
+
+    def raytracing(self) -> None:
+        self._check(self._lib.gem_raytracing(self._h), "gem_raytracing")
+
     def map_feature(self, fetch: bool = True):
         """Computes the rough / slope / traver layers on the device (gem_map_feature).  With fetch=True returns
         dict(rough, slope, traver) as host arrays; with fetch=False it only enqueues the kernel."""

@@ -73,6 +73,7 @@ struct gem_handle {
     hipStream_t bin_stream = nullptr;
     bool overlap = true;
     long long overlap_min_points = 1000000;
+    bool track_lowest = false;          // also maintain map_lowest in the fuse kernels (gem_set_lowest_tracking, for gem_raytracing)
     unsigned dense_min = 2048;          // records of one sweep in one 16x16 tile above which the tile is counting-sorted (k_fuse_list, dense path)
     Arena scratch;      // layer export
     unsigned long long* d_counters = nullptr;
@@ -274,6 +275,7 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     int attr = 0;
     if (in.src == 0 && in.rgb) attr = 1;
     if (in.src == 1 && in.f_R && in.f_G && in.f_B && in.f_I) attr = 2;
+    if (h->track_lowest) attr |= 4;                  // the kernel variants that also maintain map_lowest (16x16 tiles)
     // tile size of this pass: 16x16 cells (more, lighter workgroups: better balance and latency hiding)
     // unless the [sweep][tile][unit] descriptor table would get too big, then 32x32
     int ts = h->ts;
@@ -285,7 +287,8 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     const int tiles_per_row = (h->L + te - 1) / te;
     const int T = tiles_per_row * tiles_per_row;
     h->T = T;
-    if (fuse_lds_bytes(ts, h->fuse_variant, attr) > 160 * 1024) return fail(h, GEM_ERR_INVALID, "fuse kernel geometry exceeds the LDS");
+    if (h->track_lowest) ts = 4;
+    if (fuse_lds_bytes(ts, h->fuse_variant, attr & 3) > 160 * 1024) return fail(h, GEM_ERR_INVALID, "fuse kernel geometry exceeds the LDS");
 
     // k_bin of this pass may run on its own stream, concurrently with the k_fuse of the previous pass
     // (it depends on the cloud and the pose, not on the map).  Only with the handle's own stream:
@@ -396,6 +399,7 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     fa.xyzi = in.xyzi; fa.rgb = in.rgb; fa.f_R = in.f_R; fa.f_G = in.f_G; fa.f_B = in.f_B; fa.f_I = in.f_I;
     fa.counters = ba.counters;
     fa.srt = static_cast<uint4*>(pb.srt.p); fa.srt_top = ba.srt_top; fa.dense_min = h->dense_min;
+    fa.lowest = h->layers.lowest; fa.start0 = h->start[0]; fa.start1 = h->start[1];
     fa.count_per_pass = orig0.empty() ? 0 : 1;
     fa.dbg = nullptr;
     fa.dbg_sweep = 0; if (const char* e = getenv("GEM_DBG_SWEEP")) fa.dbg_sweep = atoi(e);
@@ -873,6 +877,28 @@ int gem_map_feature(gem_handle* h, float* elevation, float* variance, int* color
     bool any = false;
     for (auto& o : out) if (o.dst) { GEM_HIP(h, hipMemcpyAsync(o.dst, o.src, bytes, hipMemcpyDeviceToHost, h->stream)); any = true; }
     if (any) GEM_HIP(h, hipStreamSynchronize(h->stream));
+    return GEM_OK;
+}
+
+int gem_set_lowest_tracking(gem_handle* h, int enabled)
+{
+    if (!h) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
+    h->track_lowest = enabled != 0;
+    return GEM_OK;
+}
+
+int gem_raytracing(gem_handle* h)
+{
+    if (!h) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    int rc = flush_pending(h, false);               // the queued variance increments are part of what the kernel reads
+    if (rc) return rc;
+    GEM_HIP(h, launch_raytracing(h->stream, h->layers, h->L, h->start[0], h->start[1], h->sensor_z, h->cfg.obstacle_threshold,
+                                 h->row0, h->row1));
     return GEM_OK;
 }
 

@@ -254,13 +254,22 @@ constexpr int fuse_list_max_batches(int pb) { return kChunkUnits * 64 / (pb - 64
 // LDS on entry: dlc[nd] = {arena index of the first record, count} in input order, *gbase_p = the tile's base in the
 // sorted arena (both written by the caller, no barrier yet); wc = [NW][CELLS] words (the rank-row area, left zeroed).
 // ------------------------------------------------------------------------------------------
-struct DenseResult { float e, s; uint32_t n, last; };
+struct DenseResult { float e, s, lw; uint32_t n, last; };
 
-template <int TS, int NT, int ATTR>
+// the map_lowest side output (GPU:432-439) in input order: lowest = min(lowest, h); if (h == lowest) lowest += 3 * var
+__device__ __forceinline__ float lowest_step(float lw, float h, float v)
+{
+    const float l2 = fminf(h, lw);                                                  // GPU:434 atomicMin (GPU:372-382)
+    return h == l2 ? l2 + 3.0f * v : l2;                                            // GPU:435-438
+}
+
+template <int TS, int NT, int FLAGS>
 __device__ __forceinline__ DenseResult dense_tile(const uint4* __restrict__ rec, uint4* __restrict__ srt_raw, uint32_t* wc, const uint2* dlc,
-                                               uint32_t* scratch, const uint32_t* gbase_p, uint32_t nd, float e, float s,
+                                               uint32_t* scratch, const uint32_t* gbase_p, uint32_t nd, float e, float s, float lw,
                                                float mahal, float var_floor, unsigned long long* dbg)
 {
+    constexpr int ATTR = FLAGS & 3;
+    constexpr bool LOWEST = (FLAGS & 4) != 0;
 #define GEM_DSTAMP(k) do { if (dbg && threadIdx.x == 0) dbg[k] = (unsigned long long)__builtin_readcyclecounter(); } while (0)
     GEM_DSTAMP(0);
     constexpr int CELLS = 1 << (2 * TS), NW = NT / 64;
@@ -352,7 +361,7 @@ __device__ __forceinline__ DenseResult dense_tile(const uint4* __restrict__ rec,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     GEM_DSTAMP(3);                                                      // placed
-    DenseResult out; out.e = e; out.s = s; out.n = ctot; out.last = 0xffffffffu;
+    DenseResult out; out.e = e; out.s = s; out.lw = lw; out.n = ctot; out.last = 0xffffffffu;
     {   // walk the cell's run, the records four steps ahead in flight (clamped address: never a branch round a load)
         constexpr int D = 4;
         const uint32_t n = ctot, nm1 = n ? n - 1u : 0u;
@@ -371,6 +380,7 @@ __device__ __forceinline__ DenseResult dense_tile(const uint4* __restrict__ rec,
                 const bool taken = fuse_step(e2, s2, __uint_as_float(cur.x), __uint_as_float(cur.y), mahal, var_floor);
                 const bool live = idx < n;
                 out.e = live ? e2 : out.e; out.s = live ? s2 : out.s;
+                if constexpr (LOWEST) { const float l2 = lowest_step(out.lw, __uint_as_float(cur.x), __uint_as_float(cur.y)); out.lw = live ? l2 : out.lw; }
                 if constexpr (ATTR != 0) { if (live && taken && (cur.z & 0x80000000u)) out.last = cur.w & 0x7fffffffu; }
             }
         }
@@ -392,11 +402,15 @@ __device__ __forceinline__ DenseResult dense_tile(const uint4* __restrict__ rec,
 // MODE 0: the LiDAR paths only (k_frame).  MODE 1: the same code, but a dense (tile, sweep) makes it hand the tile over --
 // state in `st`, return true -- to a MODE 2 copy, which resumes at that sweep and has the dense path.  Two copies in one
 // kernel keep the dense path's registers (and spills) out of the code every LiDAR tile runs.
-template <int CPT> struct TileState { float e[CPT], s[CPT]; uint32_t tmask; int sweep; };
+template <int CPT> struct TileState { float e[CPT], s[CPT], lw[CPT]; uint32_t tmask; int sweep; };
 
-template <int TS, int NT, int PB, int ATTR, bool BATCH, int MODE>
+// FLAGS: bits 0-1 = ATTR (0 none, 1 colours from the cloud, 2 colours from gem_fuse's arrays), bit 2 = LOWEST (also maintain the
+// map_lowest layer, GPU:432-439, for gem_raytracing)
+template <int TS, int NT, int PB, int FLAGS, bool BATCH, int MODE>
 __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsigned char* lds_raw, TileState<(1 << (2 * TS)) / NT>& st)
 {
+    constexpr int ATTR = FLAGS & 3;
+    constexpr bool LOWEST = (FLAGS & 4) != 0;
     // BATCH = false: one sweep, no per-sweep tables in device memory, no variance increments between sweeps --
     // the sweep loop below collapses and none of its scalar bookkeeping is compiled in
     const int NS = BATCH ? a.n_sweeps : 1;
@@ -545,7 +559,8 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
     }
 
     // ---- the single read of the tile ---------------------------------------------------------------
-    float ce[CPT], cs[CPT];
+    float ce[CPT], cs[CPT], lw[CPT];
+    size_t lgeo[CPT];
     bool  owned[CPT];
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
@@ -558,6 +573,13 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
         const size_t g = owned[q] ? (size_t)row * L + col : 0;
         if constexpr (MODE == 2) { ce[q] = st.e[q]; cs[q] = st.s[q]; }
         else { ce[q] = a.elevation[g]; cs[q] = a.variance[g]; }
+        if constexpr (LOWEST) {
+            // map_lowest is indexed by the GEOGRAPHIC cell (GPU:430 PointsToIndex), not by the circular-buffer cell
+            int gr = row - a.start0, gc = col - a.start1;
+            gr += gr < 0 ? L : 0; gc += gc < 0 ? L : 0;
+            lgeo[q] = owned[q] ? (size_t)gr * L + gc : 0;
+            if constexpr (MODE == 2) lw[q] = st.lw[q]; else lw[q] = a.lowest[lgeo[q]];
+        }
     }
 
     {   // fast-path rows start with count 0; the owner leaves every row it consumed at count 0 again
@@ -645,7 +667,7 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
             if constexpr (MODE == 1 && DMA && CPT == 1) {
                 if (ci == 0 && P > a.dense_min) {                        // block-uniform: a dense tile, nothing of this sweep consumed yet
 #pragma unroll
-                    for (int q = 0; q < CPT; ++q) { st.e[q] = ce[q]; st.s[q] = cs[q]; }
+                    for (int q = 0; q < CPT; ++q) { st.e[q] = ce[q]; st.s[q] = cs[q]; if constexpr (LOWEST) st.lw[q] = lw[q]; }
                     st.tmask = tmask; st.sweep = sweep;
                     return true;
                 }
@@ -678,10 +700,11 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
                         if (tid == 0) misc[2] = atomicAdd(a.srt_top, P);
                     }
                     apply_increments();
-                    const DenseResult dr = dense_tile<TS, NT, ATTR>(a.rec, a.srt, reinterpret_cast<uint32_t*>(rowp), dlc, scratch, misc + 2,
-                                                                    nd, ce[0], cs[0], a.mahal, a.var_floor,
+                    const DenseResult dr = dense_tile<TS, NT, FLAGS>(a.rec, a.srt, reinterpret_cast<uint32_t*>(rowp), dlc, scratch, misc + 2,
+                                                                    nd, ce[0], cs[0], LOWEST ? lw[0] : 0.0f, a.mahal, a.var_floor,
                                                                     a.dbg && sweep == a.dbg_sweep ? a.dbg + (size_t)tile * 16 + 8 : nullptr);
                     ce[0] = dr.e; cs[0] = dr.s;
+                    if constexpr (LOWEST) lw[0] = dr.lw;
                     if (dr.n) tmask |= 1u;
                     if (ATTR != 0 && dr.last != 0xffffffffu) write_attr(0, dr.last);
                     GEM_STAMP();
@@ -856,6 +879,7 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
                             const bool taken = fuse_step(e2, s2, hh[q][i], vv[q][i], a.mahal, a.var_floor);
                             const bool live = (uint32_t)i < n[q];
                             ce[q] = live ? e2 : ce[q]; cs[q] = live ? s2 : cs[q];
+                            if constexpr (LOWEST) { const float l2 = lowest_step(lw[q], hh[q][i], vv[q][i]); lw[q] = live ? l2 : lw[q]; }
                             if (ATTR) { if (live && taken && (sv[q][i] & 0x80000000u)) wlast[q] = sv[q][i] & 0x7fffffffu; }
                         }
                     }
@@ -948,6 +972,7 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
                                 float e2 = ce[q], s2 = cs[q];
                                 const bool taken = fuse_step(e2, s2, h, v, a.mahal, a.var_floor);
                                 ce[q] = live ? e2 : ce[q]; cs[q] = live ? s2 : cs[q];
+                                if constexpr (LOWEST) { const float l2 = lowest_step(lw[q], h, v); lw[q] = live ? l2 : lw[q]; }
                                 if (ATTR) { if (live && taken && (sv & 0x80000000u)) wl[q] = sv & 0x7fffffffu; }
                                 cur[q] = nx;
                                 more |= cur[q] != NIL;
@@ -991,6 +1016,7 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
             const size_t g = (size_t)(row_base + (c >> TS)) * L + col_base + (c & (TE - 1));
             a.elevation[g] = ce[q];
             a.variance[g] = cs[q];
+            if constexpr (LOWEST) a.lowest[lgeo[q]] = lw[q];
         }
     }
     GEM_STAMP();                                                         // 6: stores issued
@@ -1318,6 +1344,18 @@ static hipError_t launch_fuse_list_b(hipStream_t st, const FuseArgs& a, int attr
     return hipGetLastError();
 }
 
+// the variants that also maintain map_lowest (16x16 tiles only)
+template <bool BATCH>
+static hipError_t launch_fuse_list_lowest(hipStream_t st, const FuseArgs& a, int attr, LaunchEvents ev)
+{
+    const size_t lds = fuse_list_lds(256, 4, 1024, attr & 3);
+    const dim3 grid((a.T + 3) & ~3), block(256);
+    if ((attr & 3) == 0)      GEM_LAUNCH((k_fuse_list<4, 256, 1024, 4, BATCH>), grid, block, lds, st, ev, a);
+    else if ((attr & 3) == 1) GEM_LAUNCH((k_fuse_list<4, 256, 1024, 5, BATCH>), grid, block, lds, st, ev, a);
+    else                      GEM_LAUNCH((k_fuse_list<4, 256, 1024, 6, BATCH>), grid, block, lds, st, ev, a);
+    return hipGetLastError();
+}
+
 template <int TS, int NT, int PB>
 static hipError_t launch_fuse_list(hipStream_t st, const FuseArgs& a, int attr, LaunchEvents ev)
 {
@@ -1327,6 +1365,10 @@ static hipError_t launch_fuse_list(hipStream_t st, const FuseArgs& a, int attr, 
 hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr, int variant, LaunchEvents ev)
 {
     if (a.T <= 0) return hipSuccess;
+    if (attr & 4) {
+        if (ts != 4) return hipErrorInvalidValue;
+        return a.n_sweeps > 1 ? launch_fuse_list_lowest<true>(st, a, attr, ev) : launch_fuse_list_lowest<false>(st, a, attr, ev);
+    }
     if (ts == 4) return launch_fuse_list<4, 256, 1024>(st, a, attr, ev);
     if (variant == 10) return launch_fuse_list<5, 256, 4096>(st, a, attr, ev);
     if (variant == 11) return launch_fuse_list<5, 512, 4096>(st, a, attr, ev);
@@ -1338,6 +1380,81 @@ hipError_t launch_frame(hipStream_t st, const FuseArgs& fa, const BinArgs& ba, L
 {
     const dim3 grid(((fa.T + 3) & ~3) + (ba.B + 3) / 4), block(256);
     GEM_LAUNCH((k_frame), grid, block, fuse_list_lds(256, 4, 1024, 0), st, ev, fa, ba);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// k_raytracing : the visibility clean-up, G_Raytracing (GPU:708-891; helpers GPU:672-706).  One thread per cell.
+// A cell that holds an elevation and whose traversability is below the obstacle threshold walks AWAY from the map centre
+// along the centre->cell ray (a DDA over cell borders); every crossed cell with a lowest scan point this frame bounds the
+// obstacle's height by the line of sight from the sensor over that point; if elevation - 3 sigma is above the tightest
+// bound the cell is deleted.  Quirks kept: map_lowest in GEOGRAPHIC cell order, the
+// int robot_index, centre row / column cells never deleted, x-only abscissae, "no scan point" == 10.
+// A thread writes only its own cell's elevation and reads only its own cell's elevation / variance: no ordering issue.
+// The walks diverge (up to L steps); at 600 x 600 the kernel is a few tens of microseconds, once per frame.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_raytracing(LayerPtrs m, int L, int start0, int start1, float sensor_z, float obstacle_threshold,
+                                                   int row0, int row1)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L * L) return;
+    const int cell_x = i / L, cell_y = i - cell_x * L;
+    if (cell_x < row0 || cell_x >= row1) return;
+    const float obstacle_ele = m.elevation[i];
+    if (!(m.traver[i] < obstacle_threshold && obstacle_ele != kEmptyElevation)) return;         // GPU:712
+    int ob0 = cell_x + L - start0; ob0 -= ob0 >= L ? L : 0;                                      // GPU:672-675 (% L)
+    int ob1 = cell_y + L - start1; ob1 -= ob1 >= L ? L : 0;
+    const int robot_index = (L % 2 == 0) ? (int)(float)(L / 2 - 0.5) : (int)(float)(L / 2);     // GPU:733, 739: float -> int
+    const float inc0 = (float)(ob0 - robot_index), inc1 = (float)(ob1 - robot_index);
+    const int inc_x = inc0 > 0 ? 1 : (inc0 == 0 ? 0 : -1), inc_y = inc1 > 0 ? 1 : (inc1 == 0 ? 0 : -1);
+    if (inc_x == 0 || inc_y == 0) return;                                                        // GPU:760-791: bound computed, never applied
+    const float dis = sqrtf(inc0 * inc0 + inc1 * inc1);                                          // GPU:793
+    const float dir0 = inc0 / dis, dir1 = inc1 / dis;
+    float threshold;                                                                             // GPU:798-802, double arithmetic
+    if (fabsf(inc0) > fabsf(inc1)) { const double t = 0.5 / (double)inc0 * (double)inc1; threshold = (float)sqrt(0.5 * 0.5 + t * t); }
+    else                           { const double t = 0.5 / (double)inc1 * (double)inc0; threshold = (float)sqrt(0.5 * 0.5 + t * t); }
+    float bound_x = (float)inc_x / 2, bound_y = (float)inc_y / 2;                               // GPU:808-809
+    float dir_num_x = bound_x / dir0, dir_num_y = bound_y / dir1, later = 0.0f;
+    float restrict_ele = obstacle_ele;
+    const float robot_f = (float)robot_index;
+    int c0 = ob0, c1 = ob1;
+    auto look = [&](float step) {                                                                // GPU:823-830 and twins
+        if (step - later > threshold && c0 != ob0 && c1 != ob1) {
+            const float low = m.lowest[(size_t)c0 * L + c1];
+            if (low != 10.0f) {                                                                  // GPU:681-689
+                const float x1 = (float)(c0 - ob0), x2 = (float)c0 - robot_f;                    // GPU:691-706
+                const float e = low + (sensor_z - low) / x2 * x1;
+                if (e < restrict_ele) restrict_ele = e;
+            }
+        }
+    };
+    while (c0 >= 0 && c0 < L && c1 >= 0 && c1 < L) {                                             // GPU:819-880
+        if (dir_num_x > dir_num_y) {
+            look(dir_num_y);
+            c1 += inc_y; bound_y += (float)inc_y; later = dir_num_y; dir_num_y = bound_y / dir1;
+        } else if (dir_num_x < dir_num_y) {
+            look(dir_num_x);
+            c0 += inc_x; bound_x += (float)inc_x; later = dir_num_x; dir_num_x = bound_x / dir0;
+        } else {
+            look(dir_num_x);
+            c0 += inc_x; c1 += inc_y; bound_x += (float)inc_x; bound_y += (float)inc_y;
+            later = dir_num_x; dir_num_x = bound_x / dir0; dir_num_y = bound_y / dir1;
+        }
+    }
+    if (obstacle_ele - 3 * sqrtf(m.variance[i]) > restrict_ele) m.elevation[i] = kEmptyElevation;   // GPU:884-885
+}
+
+// G_Clear_maplowest (GPU:232-239)
+__global__ __launch_bounds__(256) void k_fill(float* p, int n, float v)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
+}
+
+hipError_t launch_raytracing(hipStream_t st, const LayerPtrs& m, int L, int start0, int start1, float sensor_z, float obstacle_threshold,
+                             int row0, int row1)
+{
+    hipLaunchKernelGGL(k_raytracing, dim3((L * L + 255) / 256), dim3(256), 0, st, m, L, start0, start1, sensor_z, obstacle_threshold, row0, row1);
+    hipLaunchKernelGGL(k_fill, dim3(grid_for(L * L, 256)), dim3(256), 0, st, m.lowest, L * L, 10.0f);
     return hipGetLastError();
 }
 

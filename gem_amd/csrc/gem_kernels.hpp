@@ -79,6 +79,8 @@ struct FuseArgs {
     unsigned long long* counters;      // optional: [1] += distinct touched cells per sweep (per pass when count_per_pass)
     uint4*            srt;             // sorted arena (as many records as `rec`): dense tiles counting-sort their records by cell into it
     uint32_t*         srt_top;         // its bump pointer (records), zeroed by the k_bin of the pass
+    float*            lowest;          // map_lowest layer (GEOGRAPHIC cell order), maintained by the LOWEST kernel variants
+    int               start0, start1;  // circular-buffer start (storage -> geographic cell)
     int               dbg_sweep;       // debug stamps of the dense path: which sweep
     uint32_t          dense_min;       // a (tile, sweep) with more records than this takes the dense path (16x16 tiles only)
     int   count_per_pass;              // the sweeps are one cloud cut into pieces: count a cell once
@@ -94,6 +96,8 @@ hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr, int 
 hipError_t launch_frame(hipStream_t st, const FuseArgs& fuse_prev, const BinArgs& bin_this, LaunchEvents ev);
 size_t     fuse_lds_bytes(int ts, int variant, int attr);
 hipError_t launch_init(hipStream_t st, const LayerPtrs& m, int cells, int clear_lowest);
+hipError_t launch_raytracing(hipStream_t st, const LayerPtrs& m, int L, int start0, int start1, float sensor_z, float obstacle_threshold,
+                             int row0, int row1);
 hipError_t launch_clear_strip(hipStream_t st, const LayerPtrs& m, int L, int start, int count, int is_row);
 hipError_t launch_dense_variance(hipStream_t st, float* variance, int cells, int n_pending, const float* pending,
                                  int apply_floor, float var_floor);

@@ -225,6 +225,10 @@ public:
     void mapFeature(float* rough = nullptr, float* slope = nullptr, float* traver = nullptr)
     { check(gem_map_feature(h_, nullptr, nullptr, nullptr, nullptr, nullptr, rough, slope, traver, nullptr), "gem_map_feature"); }
 
+    // Raytracing(length) (ElevationMapping.cpp:421): visibility clean-up; needs trackLowest(true) while the frame is fused
+    void trackLowest(bool on) { check(gem_set_lowest_tracking(h_, on ? 1 : 0), "gem_set_lowest_tracking"); }
+    void raytracing() { check(gem_raytracing(h_), "gem_raytracing"); }
+
     // flat [storage_x * length + storage_y] array, the layout ElevationMap::show indexes (ElevationMap.cpp:98-111)
     std::vector<float> layer(int which) const
     {

@@ -12,9 +12,8 @@
 // (by-value Matrix4f / Matrix3f / RowVector3f arguments), which exists in the ROS workspace but not in
 // this repository's build container -- tests/cpp compiles it against a minimal stand-in.
 //
-// Hot-path symbols and Map_feature (the traversability stage) are complete.  Raytracing /
-// Map_optmove / Map_closeloop belong to later post-processing stages; they are provided so
-// the node links, with the behaviour documented on each.
+// All nine run on the device: the hot-path symbols, Map_feature (the traversability stage),
+// Raytracing (the visibility clean-up, 8f #3) and the loop-closure shifts Map_optmove / Map_closeloop (8f #4).
 #pragma once
 
 #include <Eigen/Core>
@@ -51,7 +50,9 @@ void Init_GPU_elevationmap(int length, float resolution, float h_mahalanobisDist
     cfg.mahalanobis_threshold = 5.0f; cfg.variance_floor = 0.0001f;
     cfg.obstacle_threshold = h_obstacle_threshold; cfg.device = -1;
     const int rc = gem_create(&cfg, &gem_compat::handle());
-    if (rc != GEM_OK) std::fprintf(stderr, "Init_GPU_elevationmap failed (%d): %s\n", rc, gem_last_error(nullptr));
+    if (rc != GEM_OK) { std::fprintf(stderr, "Init_GPU_elevationmap failed (%d): %s\n", rc, gem_last_error(nullptr)); return; }
+    // the node calls Raytracing every frame (ElevationMapping.cpp:421): keep the lowest scan points (gpu_process.cu:430-439)
+    gem_compat::report(gem_set_lowest_tracking(gem_compat::handle(), 1), "gem_set_lowest_tracking");
 }
 
 // gpu_process.cu:1004-1083
@@ -114,8 +115,12 @@ void Map_feature(int length, float* elevation, float* var, int* colorR, int* col
                        "Map_feature");
 }
 
-// gpu_process.cu:1304-1318 -- visibility clean-up, outside the hot path: no-op.
-void Raytracing(int length) { (void)length; }
+// gpu_process.cu:1304-1318 -- visibility clean-up: G_Raytracing, then the lowest scan points are reset (gem_raytracing).
+void Raytracing(int length)
+{
+    (void)length;
+    gem_compat::report(gem_raytracing(gem_compat::handle()), "Raytracing");
+}
 
 // gpu_process.cu:1215-1233 -- loop-closure re-anchoring: the centre is relabelled to the optimised
 // position snapped to the cell lattice and every valid elevation moves by height_update (gem_map_optmove).

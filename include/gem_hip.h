@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GEM_ABI_VERSION 3
+#define GEM_ABI_VERSION 4
 
 typedef enum gem_status {
     GEM_OK = 0,
@@ -60,7 +60,7 @@ typedef struct gem_map_config {
     float resolution;              /* metres per cell (GPU:36)                                                 */
     float mahalanobis_threshold;   /* the reference uploads one (GPU:977) but uses the literal 5 (GPU:504): pass 5 */
     float variance_floor;          /* literal 0.0001 in the reference (GPU:500,533)                            */
-    float obstacle_threshold;      /* GPU:940 4th argument; not used on this path                              */
+    float obstacle_threshold;      /* GPU:940 4th argument: cells with traversability below it are ray-traced (GPU:712)     */
     int   strip_row0, strip_rows;  /* storage-row strip this handle owns (multi-GPU tiling); 0,0 = whole map   */
     int   device;                  /* HIP device ordinal; -1 = current device                                  */
 } gem_map_config;
@@ -176,6 +176,19 @@ int  gem_map_feature(gem_handle* h, float* elevation, float* variance, int* colo
  *      Map_closeloop (GPU:1235-1254) moves the centre by the aligned shift instead.                         */
 int  gem_map_optmove(gem_handle* h, const float opt_position[2], float height_update, float out_aligned_position[2]);
 int  gem_map_closeloop(gem_handle* h, const float update_position[2], float height_update);
+
+/* ---- visibility clean-up: Raytracing (GPU:1304-1318, called EMg.cpp:421) = G_Raytracing (GPU:708-891):
+ *      every cell with traversability below obstacle_threshold walks away from the map centre along the centre->cell
+ *      ray; crossed cells with a lowest scan point this frame bound its height by the sensor's line of sight, and the
+ *      cell is deleted (elevation = -10) if elevation - 3 sigma exceeds the tightest bound -- then G_Clear_maplowest
+ *      (GPU:232-239) resets the LOWEST layer to 10.
+ *      The LOWEST layer is the side output of G_pointsprocess (GPU:430-439: lowest = min(lowest, h); if (h == lowest)
+ *      lowest += 3 * var, per GEOGRAPHIC cell).  It is maintained -- in input order per cell, the result of running the
+ *      reference's grid sequentially -- by the fuse kernels of gem_fuse / gem_add* ONLY while lowest tracking is on
+ *      (default off: the LiDAR hot path is not slowed down); gem_process_points alone does not touch it.
+ *      Not reproduced: a point whose height is exactly -1.0f (skipped by the fusion, GPU:482) does not update LOWEST.  */
+int  gem_set_lowest_tracking(gem_handle* h, int enabled);
+int  gem_raytracing(gem_handle* h);
 
 /* ---- statistics / timing (bench harness) --------------------------------------------------------- */
 int  gem_set_timing(gem_handle* h, int enabled);      /* record hipEvents around each pipeline kernel */

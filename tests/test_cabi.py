@@ -42,7 +42,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in gem_hip.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes prototype"
-    assert lib.gem_abi_version() == 3
+    assert lib.gem_abi_version() == 4
 
 
 def test_struct_layouts_match_the_header(tmp_path):
