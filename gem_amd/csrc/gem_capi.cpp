@@ -384,6 +384,7 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     ba.epoch = pb.epoch;
     ba.rec = static_cast<uint4*>(pb.rec.p); ba.seg = static_cast<uint16_t*>(pb.seg.p); ba.flag = static_cast<uint32_t*>(pb.flag.p); ba.gflag = static_cast<uint32_t*>(pb.gflag.p);
     ba.counters = h->counting ? h->d_counters : nullptr;
+    ba.keep_sentinel = h->track_lowest ? 1 : 0;
     ba.srt_top = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(pb.srt.p) + pb.srt.cap - 16);
 
     fa.epoch = pb.epoch;

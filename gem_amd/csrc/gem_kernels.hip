@@ -184,7 +184,8 @@ __device__ __forceinline__ void bin_wave_body(const BinArgs& a, int block)
             if (a.f_R) colour_ok = a.f_R[i] != 0 && a.f_G[i] != 0 && a.f_B[i] != 0 && a.f_I[i] != 0.0f;
         }
         // GPU:482: "point_index[i] != map_index || points_h[i] == -1" -> the point is skipped
-        if (row >= fc.row0 && row < fc.row1 && h != -1.0f) {
+        // (kept when the lowest scan points are tracked: GPU:430-439 sees the point, the LOWEST fuse variants skip its fusion)
+        if (row >= fc.row0 && row < fc.row1 && (h != -1.0f || a.keep_sentinel)) {
             valid = true;
             tile = (uint32_t)((row >> TS) * a.tiles_per_row + (col >> TS));
             cl = (uint32_t)(((row & (TE - 1)) << TS) | (col & (TE - 1))) | (colour_ok ? 0x80000000u : 0u);
@@ -379,9 +380,10 @@ __device__ __forceinline__ DenseResult dense_tile(const uint4* __restrict__ rec,
                 float e2 = out.e, s2 = out.s;
                 const bool taken = fuse_step(e2, s2, __uint_as_float(cur.x), __uint_as_float(cur.y), mahal, var_floor);
                 const bool live = idx < n;
-                out.e = live ? e2 : out.e; out.s = live ? s2 : out.s;
+                const bool fl = live && (!LOWEST || __uint_as_float(cur.x) != -1.0f);      // GPU:482 (only LOWEST passes carry such records)
+                out.e = fl ? e2 : out.e; out.s = fl ? s2 : out.s;
                 if constexpr (LOWEST) { const float l2 = lowest_step(out.lw, __uint_as_float(cur.x), __uint_as_float(cur.y)); out.lw = live ? l2 : out.lw; }
-                if constexpr (ATTR != 0) { if (live && taken && (cur.z & 0x80000000u)) out.last = cur.w & 0x7fffffffu; }
+                if constexpr (ATTR != 0) { if (fl && taken && (cur.z & 0x80000000u)) out.last = cur.w & 0x7fffffffu; }
             }
         }
     }
@@ -878,9 +880,10 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
                             float e2 = ce[q], s2 = cs[q];
                             const bool taken = fuse_step(e2, s2, hh[q][i], vv[q][i], a.mahal, a.var_floor);
                             const bool live = (uint32_t)i < n[q];
-                            ce[q] = live ? e2 : ce[q]; cs[q] = live ? s2 : cs[q];
+                            const bool fl = live && (!LOWEST || hh[q][i] != -1.0f);      // GPU:482 (only LOWEST passes carry such records)
+                            ce[q] = fl ? e2 : ce[q]; cs[q] = fl ? s2 : cs[q];
                             if constexpr (LOWEST) { const float l2 = lowest_step(lw[q], hh[q][i], vv[q][i]); lw[q] = live ? l2 : lw[q]; }
-                            if (ATTR) { if (live && taken && (sv[q][i] & 0x80000000u)) wlast[q] = sv[q][i] & 0x7fffffffu; }
+                            if (ATTR) { if (fl && taken && (sv[q][i] & 0x80000000u)) wlast[q] = sv[q][i] & 0x7fffffffu; }
                         }
                     }
                     if (ATTR) {
@@ -971,9 +974,10 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
                                 if (ATTR) nsv[q] = rec_src(sl2);
                                 float e2 = ce[q], s2 = cs[q];
                                 const bool taken = fuse_step(e2, s2, h, v, a.mahal, a.var_floor);
-                                ce[q] = live ? e2 : ce[q]; cs[q] = live ? s2 : cs[q];
+                                const bool fl = live && (!LOWEST || h != -1.0f);          // GPU:482 (only LOWEST passes carry such records)
+                                ce[q] = fl ? e2 : ce[q]; cs[q] = fl ? s2 : cs[q];
                                 if constexpr (LOWEST) { const float l2 = lowest_step(lw[q], h, v); lw[q] = live ? l2 : lw[q]; }
-                                if (ATTR) { if (live && taken && (sv & 0x80000000u)) wl[q] = sv & 0x7fffffffu; }
+                                if (ATTR) { if (fl && taken && (sv & 0x80000000u)) wl[q] = sv & 0x7fffffffu; }
                                 cur[q] = nx;
                                 more |= cur[q] != NIL;
                             }

@@ -51,6 +51,7 @@ struct BinArgs {
     uint32_t* gflag;                   // [n_sweeps][T][Bpad/32]  == epoch when that group of 32 units did
     unsigned long long* counters;      // optional: [0] += binned points
     uint32_t*         srt_top;         // bump pointer of the sorted arena (reset here, used by the fuse of the same pass)
+    int               keep_sentinel;   // keep records with h == -1 (GPU:482) for the LOWEST fuse variants
 };
 
 struct FuseArgs {

@@ -185,8 +185,7 @@ int  gem_map_closeloop(gem_handle* h, const float update_position[2], float heig
  *      The LOWEST layer is the side output of G_pointsprocess (GPU:430-439: lowest = min(lowest, h); if (h == lowest)
  *      lowest += 3 * var, per GEOGRAPHIC cell).  It is maintained -- in input order per cell, the result of running the
  *      reference's grid sequentially -- by the fuse kernels of gem_fuse / gem_add* ONLY while lowest tracking is on
- *      (default off: the LiDAR hot path is not slowed down); gem_process_points alone does not touch it.
- *      Not reproduced: a point whose height is exactly -1.0f (skipped by the fusion, GPU:482) does not update LOWEST.  */
+ *      (default off: the LiDAR hot path is not slowed down); gem_process_points alone does not touch it.              */
 int  gem_set_lowest_tracking(gem_handle* h, int enabled);
 int  gem_raytracing(gem_handle* h);
 

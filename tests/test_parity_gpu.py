@@ -456,6 +456,20 @@ def test_lowest_tracking_and_raytracing(oracle_mod, ref_mod, monkeypatch, L, res
     assert deleted > 20
 
 
+def test_lowest_sees_the_minus_one_sentinel(oracle_mod):
+    # a point whose height is exactly -1 is skipped by the fusion (GPU:482) but still counts as a scan point (GPU:430-439)
+    L = 40
+    gpu, ora = make_pair(oracle_mod, L, 0.1)
+    gpu.set_lowest_tracking(True)
+    f = synth._frame_for(np.eye(4), SensorModel.velodyne()); f.lower, f.upper = -5.0, 5.0
+    rng = np.random.default_rng(4)
+    c = synth.random_cloud(12, 20_000, 1.9, z_sigma=0.3)
+    c[rng.integers(0, c.shape[0], 4000), 2] = -1.0
+    for _ in range(2):
+        gpu.add(f, c); ora.add(f, c)
+        assert_maps_match(gpu, ora, layers=("elevation", "variance", "lowest"))
+
+
 def test_lowest_tracking_batched_and_off(oracle_mod):
     import torch
     wl = synth.config_c4(n_sweeps=3)
