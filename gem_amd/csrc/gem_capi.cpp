@@ -896,6 +896,8 @@ int gem_raytracing(gem_handle* h)
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
+    // the walks read the lowest scan points of the whole map, which a row strip (multi-GPU tiling) only holds for its own cells
+    if (h->row0 != 0 || h->row1 != h->L) return fail(h, GEM_ERR_INVALID, "gem_raytracing: not available on a row-strip handle");
     int rc = flush_pending(h, false);               // the queued variance increments are part of what the kernel reads
     if (rc) return rc;
     GEM_HIP(h, launch_raytracing(h->stream, h->layers, h->L, h->start[0], h->start[1], h->sensor_z, h->cfg.obstacle_threshold,
