@@ -83,6 +83,21 @@ def main():
         print(json.dumps({"config": "Map_feature on the fused C2 map (600x600), device-resident", "wall_us": dt * 1e6,
                           "cells_per_s": cells / dt, "alg_MB": cells * 16 / 1e6, "alg_GBps_wall": cells * 16 / dt / 1e9,
                           "note": "B_alg = 4 B elevation read + 12 B rough/slope/traver written per cell"}), flush=True)
+        # the per-frame sequence of the unmodified node (adapter): fuse with lowest tracking, Map_feature, Raytracing
+        m.set_lowest_tracking(True)
+        def g():
+            f(); m.map_feature(fetch=False); m.raytracing()
+        for _ in range(16): g()
+        m.synchronize(); t0 = time.perf_counter()
+        for _ in range(args.reps * 2): g()
+        m.synchronize(); dt = (time.perf_counter() - t0) / (args.reps * 2)
+        for _ in range(8): f()
+        m.synchronize(); t0 = time.perf_counter()
+        for _ in range(args.reps * 2): f()
+        m.synchronize(); dtf = (time.perf_counter() - t0) / (args.reps * 2)
+        print(json.dumps({"config": "C2 node sequence: add (lowest tracking on) + Map_feature + Raytracing, device-resident",
+                          "wall_us": dt * 1e6, "add_with_lowest_tracking_us": dtf * 1e6,
+                          "note": "tracking on: k_bin_wave + k_fuse_list<LOWEST> (two launches, no deferred k_frame)"}), flush=True)
         m.close()
 
     if "c3" in want:
