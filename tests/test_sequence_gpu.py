@@ -15,17 +15,21 @@ def lidar_like(rng, n, extent):
     return c
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4])
-def test_random_call_sequence(oracle_mod, seed):
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_call_sequence(oracle_mod, monkeypatch, seed):
     import torch
     rng = np.random.default_rng(seed)
     L, res = (96, 0.1) if seed % 2 else (75, 0.2)
+    if seed >= 5:
+        monkeypatch.setenv("GEM_DENSE_MIN", "40")          # most tiles of these small clouds take the dense (counting-sort) path
     gpu, ref = ElevationMap(L, res), oracle_mod.OracleMap(L, res)
+    tracking = False                                        # lowest scan points kept by the fuse kernels (for raytracing)
     frame = synth._frame_for(synth.pose_matrix(0.1, -0.2, 0.0, yaw=0.3), SensorModel.velodyne())
     extent = 0.5 * L * res * 1.1
     checks = 0
     for step in range(60):
-        op = rng.choice(["add_dev", "add_dev", "add_dev", "add_host", "fuse", "batch", "var", "move", "get", "feature", "optmove", "big"])
+        op = rng.choice(["add_dev", "add_dev", "add_dev", "add_host", "fuse", "batch", "var", "move", "get", "feature", "optmove", "big",
+                         "track", "raytrace"])
         if op == "add_dev":
             c = lidar_like(rng, int(rng.integers(1, 6000)), extent)
             gpu.add(frame, torch.from_numpy(c).cuda()); ref.add(frame, c)
@@ -66,11 +70,27 @@ def test_random_call_sequence(oracle_mod, seed):
             assert np.array_equal(g["traver"] == -10, o["traver"] == -10)
             assert np.max(np.abs(g["slope"] - o["slope"])) <= 2e-3 and np.max(np.abs(g["rough"] - o["rough"])) <= 1e-6
             gpu.set_layer("traver", o["traver"])            # keep the two maps bit-identical for the rest of the sequence
+        elif op == "track":
+            # switching the tracking on: the oracle always tracks, so start both sides from the same layer
+            tracking = not tracking
+            gpu.set_lowest_tracking(tracking)
+            if tracking:
+                gpu.set_layer("lowest", ref.layer("lowest"))
+        elif op == "raytrace":
+            if not tracking:
+                gpu.set_layer("lowest", ref.layer("lowest"))
+            pos = [float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.3, 0.3)), float(rng.uniform(0.3, 0.8))]
+            gpu.move(pos); ref.move(pos)                    # sets the sensor height the rays start from
+            t = rng.uniform(0.0, 1.0, (L, L)).astype(F32)
+            gpu.set_layer("traver", t); ref.set_layer("traver", t)
+            gpu.raytracing(); ref.raytracing()
+            assert np.array_equal(gpu.layer("lowest"), ref.layer("lowest"))
+            assert np.array_equal(gpu.layer("elevation"), ref.layer("elevation")), f"seed {seed} step {step}: raytracing"
         elif op == "big":
             c = lidar_like(rng, 140_000, extent)            # > 131072 points: cut into sweeps internally
             gpu.add(frame, torch.from_numpy(c).cuda()); ref.add(frame, c)
         if op == "get" or step % 13 == 12:
-            for name in ("elevation", "variance"):
+            for name in ("elevation", "variance") + (("lowest",) if tracking else ()):
                 g, o = gpu.layer(name), ref.layer(name)
                 assert np.array_equal(g, o), f"seed {seed} step {step} ({op}): {name} differs in {np.count_nonzero(g != o)} cells"
             checks += 1
