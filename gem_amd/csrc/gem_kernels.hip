@@ -1422,28 +1422,28 @@ __global__ __launch_bounds__(256) void k_raytracing(LayerPtrs m, int L, int star
     float restrict_ele = obstacle_ele;
     const float robot_f = (float)robot_index;
     int c0 = ob0, c1 = ob1;
-    auto look = [&](float step) {                                                                // GPU:823-830 and twins
-        if (step - later > threshold && c0 != ob0 && c1 != ob1) {
+    // GPU:819-880.  The reference's three branches (step in y / step in x / step in both when the two border distances tie)
+    // are one straight-line body here: the crossed-cell test uses the smaller distance (dir_num_x when they tie, as in the
+    // reference's last branch), and each axis advances under a select.  Every value is computed by the reference's own
+    // expression; lanes of a wave do not serialise over the three variants (measured: no faster than the branchy form -- the
+    // kernel is bound by the two IEEE divisions per step -- but one body instead of three).
+    while (c0 >= 0 && c0 < L && c1 >= 0 && c1 < L) {
+        const bool step_y = dir_num_x > dir_num_y;                 // GPU:821
+        const bool step_x = dir_num_x < dir_num_y;                 // GPU:838; neither: both axes (GPU:855)
+        const float step = step_y ? dir_num_y : dir_num_x;
+        if (step - later > threshold && c0 != ob0 && c1 != ob1) {  // GPU:823-830 and twins
             const float low = m.lowest[(size_t)c0 * L + c1];
-            if (low != 10.0f) {                                                                  // GPU:681-689
+            if (low != 10.0f) {                                    // GPU:681-689
                 const float x1 = (float)(c0 - ob0), x2 = (float)c0 - robot_f;                    // GPU:691-706
                 const float e = low + (sensor_z - low) / x2 * x1;
                 if (e < restrict_ele) restrict_ele = e;
             }
         }
-    };
-    while (c0 >= 0 && c0 < L && c1 >= 0 && c1 < L) {                                             // GPU:819-880
-        if (dir_num_x > dir_num_y) {
-            look(dir_num_y);
-            c1 += inc_y; bound_y += (float)inc_y; later = dir_num_y; dir_num_y = bound_y / dir1;
-        } else if (dir_num_x < dir_num_y) {
-            look(dir_num_x);
-            c0 += inc_x; bound_x += (float)inc_x; later = dir_num_x; dir_num_x = bound_x / dir0;
-        } else {
-            look(dir_num_x);
-            c0 += inc_x; c1 += inc_y; bound_x += (float)inc_x; bound_y += (float)inc_y;
-            later = dir_num_x; dir_num_x = bound_x / dir0; dir_num_y = bound_y / dir1;
-        }
+        later = step;
+        const float nbx = bound_x + (float)inc_x, nby = bound_y + (float)inc_y;
+        const float ndx = nbx / dir0, ndy = nby / dir1;
+        if (!step_y) { c0 += inc_x; bound_x = nbx; dir_num_x = ndx; }
+        if (!step_x) { c1 += inc_y; bound_y = nby; dir_num_y = ndy; }
     }
     if (obstacle_ele - 3 * sqrtf(m.variance[i]) > restrict_ele) m.elevation[i] = kEmptyElevation;   // GPU:884-885
 }
