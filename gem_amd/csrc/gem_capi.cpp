@@ -73,6 +73,7 @@ struct gem_handle {
     hipStream_t bin_stream = nullptr;
     bool overlap = true;
     long long overlap_min_points = 1000000;
+    int dbg_sweep = 0;                  // debug stamps of the dense path: which sweep (GEM_DBG_SWEEP)
     bool track_lowest = false;          // also maintain map_lowest in the fuse kernels (gem_set_lowest_tracking, for gem_raytracing)
     unsigned dense_min = 2048;          // records of one sweep in one 16x16 tile above which the tile is counting-sorted (k_fuse_list, dense path)
     Arena scratch;      // layer export
@@ -403,7 +404,7 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     fa.lowest = h->layers.lowest; fa.start0 = h->start[0]; fa.start1 = h->start[1];
     fa.count_per_pass = orig0.empty() ? 0 : 1;
     fa.dbg = nullptr;
-    fa.dbg_sweep = 0; if (const char* e = getenv("GEM_DBG_SWEEP")) fa.dbg_sweep = atoi(e);
+    fa.dbg_sweep = h->dbg_sweep;
     if (h->dbg_on) {
         if ((rc = ensure(h, h->dbg, (size_t)T * 16 * 8))) return rc;
         GEM_HIP(h, hipMemsetAsync(h->dbg.p, 0, (size_t)T * 16 * 8, h->stream));
@@ -486,6 +487,7 @@ int gem_create(const gem_map_config* cfg, gem_handle** out)
     }
     if (const char* s = getenv("GEM_DEFER")) h->defer = atoi(s) != 0;
     if (const char* s = getenv("GEM_DENSE_MIN")) h->dense_min = (unsigned)atoi(s);
+    if (const char* s = getenv("GEM_DBG_SWEEP")) h->dbg_sweep = atoi(s);
     if (const char* s = getenv("GEM_OVERLAP")) { h->overlap = atoi(s) != 0; if (atoi(s) > 1) h->overlap_min_points = 0; }
     // one allocation for the 8 layers (gpu_process.cu:954-961 uses 8 cudaMalloc)
     void* base = nullptr;
