@@ -404,7 +404,7 @@ __device__ __forceinline__ DenseResult dense_tile(const uint4* __restrict__ rec,
 // MODE 0: the LiDAR paths only (k_frame).  MODE 1: the same code, but a dense (tile, sweep) makes it hand the tile over --
 // state in `st`, return true -- to a MODE 2 copy, which resumes at that sweep and has the dense path.  Two copies in one
 // kernel keep the dense path's registers (and spills) out of the code every LiDAR tile runs.
-template <int CPT> struct TileState { float e[CPT], s[CPT], lw[CPT]; uint32_t tmask; int sweep; };
+template <int CPT> struct TileState { float e[CPT], s[CPT], lw[CPT]; uint32_t tmask, acc_nd, acc_P; int sweep; };
 
 // FLAGS: bits 0-1 = ATTR (0 none, 1 colours from the cloud, 2 colours from gem_fuse's arrays), bit 2 = LOWEST (also maintain the
 // map_lowest layer, GPU:432-439, for gem_raytracing)
@@ -608,6 +608,14 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
     };
 
     uint32_t tmask = MODE == 2 ? st.tmask : 0u;                          // cells of this thread touched in this sweep (or pass)
+    // Accumulate mode: when no variance increment separates the sweeps of a batched call (an aggregated cloud cut into sweeps,
+    // or a batch without var_updates) the descriptors of consecutive sweeps are collected into ONE batch until it is full, so
+    // that a tile that gets a few records from each of many sweeps pays the gather / rank / walk latencies once per PB records
+    // instead of once per sweep (C5, 77 sweeps: k_fuse_list 1.46 ms -> see DESIGN.md).  Input order is preserved (sweep, unit).
+    // Per-sweep cell counts need the sweeps apart, so counting per sweep turns it off.
+    const bool acc_mode = BATCH && !var_updates && (!a.counters || a.count_per_pass);
+    uint32_t acc_nd = MODE == 2 ? st.acc_nd : 0u, acc_P = MODE == 2 ? st.acc_P : 0u;   // descriptors / records collected so far (block-uniform)
+    bool pend_done = MODE == 2 && sweep0 > 0;                            // queued Mapvar_update increments: applied once, before the first record
     for (int sweep = sweep0; sweep < NS; ++sweep) {
         if (sweep != sweep0 && (sweep & 63) == 0) { smask = sweep_mask(sweep); sweep_tables(sweep); }
         const bool touched_sweep = (smask >> (sweep & 63)) & 1ull;       // block-uniform
@@ -625,15 +633,268 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
         auto apply_increments = [&]() {
             if (incs_applied) return;
             incs_applied = true;
+            const bool pend_applied = pend_done;
+            pend_done = true;
 #pragma unroll
             for (int q = 0; q < CPT; ++q) {
-                if (sweep == 0)
+                if (!pend_applied)
                     for (int k = 0; k < a.n_pending; ++k) if (cs[q] != kInitVariance) cs[q] += a.pending[k];
                 if (var_updates) { const float u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vuv), sweep & 63)); if (cs[q] != kInitVariance) cs[q] += u; }
             }
         };
         if (a.counters && tid == 0 && (sweep == 0 || !a.count_per_pass)) misc[0] = 0;
         if (!a.count_per_pass) tmask = 0;
+
+        // one batch: m descriptors in dl_addr / dl_rc (written, barrier passed), records [slot0, slot0 + PB) -> LDS, then the chains
+        auto run_batch = [&](const uint32_t m, const uint32_t slot0) {
+            // ---- 2 + 3a. gather into LDS in input order (record k -> slot k - slot0) and take an
+            //      arrival rank per cell for the fast path.  Wave w takes the w-th contiguous share of
+            //      the batch's descriptors, one descriptor per step (lanes < count).
+            const uint32_t dw0 = (m * (uint32_t)w) / NW, dw1 = (m * (uint32_t)(w + 1)) / NW;
+            auto rank_one = [&](uint32_t cell, uint32_t sl) {
+                const uint32_t old = atomicAdd(reinterpret_cast<uint32_t*>(rowp) + cell * 4 + 3, 0x10000u);
+                const uint32_t rk = old >> 16;
+                if (rk < (uint32_t)kRankMax) rowp[cell * 8 + rk] = (uint16_t)sl;
+                else misc[1] = 1u;
+            };
+            if constexpr (DMA) {
+                // lane i fetches the wave's i-th descriptor; each is then broadcast (v_readlane) and turned into ONE
+                // global_load_lds_dwordx4 whose LDS base is the descriptor's first slot: nothing waits until all are issued
+                for (uint32_t dbase = dw0; dbase < dw1; dbase += 64) {             // wave-uniform
+                    const uint32_t nhere = min(64u, dw1 - dbase);
+                    uint32_t my_rc = 0, my_addr = 0;
+                    if ((uint32_t)lane < nhere) { my_rc = dl_rc[dbase + lane]; my_addr = dl_addr[dbase + lane]; }
+                    for (uint32_t i = 0; i < nhere; ++i) {
+                        const uint32_t rc = (uint32_t)__builtin_amdgcn_readlane((int)my_rc, (int)i);
+                        const uint32_t adr = (uint32_t)__builtin_amdgcn_readlane((int)my_addr, (int)i);
+                        if ((uint32_t)lane < (rc & 0x1ffu))
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.rec + adr + (uint32_t)lane),
+                                                             (__attribute__((address_space(3))) void*)(stage + ((rc >> 9) - slot0)), 16, 0, 0);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                const uint32_t first = (dl_rc[0] >> 9) - slot0;                     // slots of the batch: [first, first + Pb)
+                const uint32_t Pb = (dl_rc[m - 1] >> 9) + (dl_rc[m - 1] & 0x1ffu) - (dl_rc[0] >> 9);
+                // PB / NT slots per thread: all cell reads, then all rank atomics, then all row writes in flight together
+                constexpr int RK = PB / NT;
+                uint32_t rcell[RK], rold[RK];
+#pragma unroll
+                for (int r = 0; r < RK; ++r) { const uint32_t k = (uint32_t)(tid + r * NT); rcell[r] = k < Pb ? (stage[first + k].z & 0xffffu) : 0u; }
+#pragma unroll
+                for (int r = 0; r < RK; ++r) { const uint32_t k = (uint32_t)(tid + r * NT); rold[r] = 0; if (k < Pb) rold[r] = atomicAdd(reinterpret_cast<uint32_t*>(rowp) + rcell[r] * 4 + 3, 0x10000u); }
+#pragma unroll
+                for (int r = 0; r < RK; ++r) {
+                    const uint32_t k = (uint32_t)(tid + r * NT);
+                    if (k < Pb) { const uint32_t rk = rold[r] >> 16; if (rk < (uint32_t)kRankMax) rowp[rcell[r] * 8 + rk] = (uint16_t)(first + k); else misc[1] = 1u; }
+                }
+            } else {
+                // through registers, the loads of the next PF descriptors in flight while the current PF are being filed
+                constexpr int PF = 4;
+                uint4 rA[PF], rB[PF]; uint32_t sA[PF], sB[PF];       // slot == ~0: lane inactive
+                auto fetch = [&](uint32_t dd, uint4 (&rr)[PF], uint32_t (&sl)[PF]) {
+#pragma unroll
+                    for (int x = 0; x < PF; ++x) {
+                        sl[x] = 0xffffffffu; rr[x] = make_uint4(0, 0, 0, 0);
+                        if (dd + x < dw1) {                          // wave-uniform
+                            const uint32_t rc = dl_rc[dd + x];
+                            if ((uint32_t)lane < (rc & 0x1ffu)) {
+                                sl[x] = (rc >> 9) - slot0 + (uint32_t)lane;
+                                rr[x] = a.rec[dl_addr[dd + x] + (uint32_t)lane];
+                            }
+                        }
+                    }
+                };
+                auto file = [&](const uint4 (&rr)[PF], const uint32_t (&sl)[PF]) {
+#pragma unroll
+                    for (int x = 0; x < PF; ++x) {
+                        if (sl[x] != 0xffffffffu) {
+                            const uint32_t cell = rr[x].z & 0xffffu;
+                            s_h[sl[x]] = __uint_as_float(rr[x].x); s_v[sl[x]] = __uint_as_float(rr[x].y);
+                            if (ATTR) s_src[sl[x]] = (rr[x].w & 0x7fffffffu) | (rr[x].z & 0x80000000u);
+                            nxt[sl[x]] = (uint16_t)cell;             // the generic path reads the cell from here
+                            rank_one(cell, sl[x]);
+                        }
+                    }
+                };
+                if (dw0 < dw1) {
+                    fetch(dw0, rA, sA);
+                    for (uint32_t dd = dw0; dd < dw1; dd += 2 * PF) {   // wave-uniform
+                        fetch(dd + PF, rB, sB);
+                        file(rA, sA);
+                        fetch(dd + 2 * PF, rA, sA);
+                        file(rB, sB);
+                    }
+                }
+            }
+            __syncthreads();
+            GEM_STAMP();                                             // 4: records in LDS, ranked
+
+            apply_increments();
+            if (misc[1] == 0) {
+                // ---- 3a. owner: sort <= 7 slot numbers, run the chains from registers.  The CPT cells
+                //      of a thread are independent chains: everything is straight-line with selects so
+                //      that their sorting networks and IEEE divisions interleave.
+                uint4 row[CPT]; uint32_t n[CPT], nmax = 0;
+#pragma unroll
+                for (int q = 0; q < CPT; ++q) row[q] = *reinterpret_cast<const uint4*>(rowp + (tid + NT * q) * 8);
+                uint32_t ps[CPT][kRankMax];
+#pragma unroll
+                for (int q = 0; q < CPT; ++q) {
+                    n[q] = row[q].w >> 16;
+                    nmax = max(nmax, n[q]);
+                    if (n[q] != 0) { reinterpret_cast<uint32_t*>(rowp + (tid + NT * q) * 8)[3] = 0u; tmask |= 1u << q; }
+                    uint32_t p0 = row[q].x & 0xffffu, p1 = row[q].x >> 16, p2 = row[q].y & 0xffffu, p3 = row[q].y >> 16,
+                             p4 = row[q].z & 0xffffu, p5 = row[q].z >> 16, p6 = row[q].w & 0xffffu, p7 = NIL;
+                    if (n[q] < 1) p0 = NIL; if (n[q] < 2) p1 = NIL; if (n[q] < 3) p2 = NIL; if (n[q] < 4) p3 = NIL;
+                    if (n[q] < 5) p4 = NIL; if (n[q] < 6) p5 = NIL; if (n[q] < 7) p6 = NIL;
+                    GEM_CSWAP(p0, p1); GEM_CSWAP(p2, p3); GEM_CSWAP(p4, p5); GEM_CSWAP(p6, p7);
+                    GEM_CSWAP(p0, p2); GEM_CSWAP(p1, p3); GEM_CSWAP(p4, p6); GEM_CSWAP(p5, p7);
+                    GEM_CSWAP(p1, p2); GEM_CSWAP(p5, p6); GEM_CSWAP(p0, p4); GEM_CSWAP(p3, p7);
+                    GEM_CSWAP(p1, p5); GEM_CSWAP(p2, p6);
+                    GEM_CSWAP(p1, p4); GEM_CSWAP(p3, p6);
+                    GEM_CSWAP(p2, p4); GEM_CSWAP(p3, p5);
+                    GEM_CSWAP(p3, p4);
+                    ps[q][0] = p0; ps[q][1] = p1; ps[q][2] = p2; ps[q][3] = p3; ps[q][4] = p4; ps[q][5] = p5; ps[q][6] = p6;
+                }
+                float hh[CPT][kRankMax], vv[CPT][kRankMax]; uint32_t sv[CPT][kRankMax];
+#pragma unroll
+                for (int i = 0; i < kRankMax; ++i) {
+                    if (__ballot((uint32_t)i < nmax) == 0) break;    // wave-uniform
+#pragma unroll
+                    for (int q = 0; q < CPT; ++q) {
+                        const uint32_t sl = (uint32_t)i < n[q] ? ps[q][i] : 0u;       // slot 0 is always a valid address
+                        hh[q][i] = rec_h(sl); vv[q][i] = rec_v(sl);
+                        if (ATTR) sv[q][i] = rec_src(sl);
+                    }
+                }
+                uint32_t wlast[CPT];
+#pragma unroll
+                for (int q = 0; q < CPT; ++q) wlast[q] = 0xffffffffu;
+#pragma unroll
+                for (int i = 0; i < kRankMax; ++i) {
+                    if (__ballot((uint32_t)i < nmax) == 0) break;    // wave-uniform
+#pragma unroll
+                    for (int q = 0; q < CPT; ++q) {
+                        float e2 = ce[q], s2 = cs[q];
+                        const bool taken = fuse_step(e2, s2, hh[q][i], vv[q][i], a.mahal, a.var_floor);
+                        const bool live = (uint32_t)i < n[q];
+                        const bool fl = live && (!LOWEST || hh[q][i] != -1.0f);      // GPU:482 (only LOWEST passes carry such records)
+                        ce[q] = fl ? e2 : ce[q]; cs[q] = fl ? s2 : cs[q];
+                        if constexpr (LOWEST) { const float l2 = lowest_step(lw[q], hh[q][i], vv[q][i]); lw[q] = live ? l2 : lw[q]; }
+                        if (ATTR) { if (fl && taken && (sv[q][i] & 0x80000000u)) wlast[q] = sv[q][i] & 0x7fffffffu; }
+                    }
+                }
+                if (ATTR) {
+#pragma unroll
+                    for (int q = 0; q < CPT; ++q) if (wlast[q] != 0xffffffffu) write_attr(q, wlast[q]);
+                }
+            } else {
+                // ---- 3b. generic path: per-wave in-order linked lists --------------------------
+                const uint32_t k_lo = dl_rc[0] >> 9;
+                const uint32_t Pb = (dl_rc[m - 1] >> 9) + (dl_rc[m - 1] & 0x1ffu) - k_lo;      // records of this batch
+                {
+                    uint4* z = reinterpret_cast<uint4*>(head);
+                    for (int c = tid; c < CELLS * NW / 8; c += NT) z[c] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+                }
+                __syncthreads();
+                if (tid == 0) misc[1] = 0u;
+                {   // wave w appends records [w * per, (w + 1) * per) of the batch, 64 consecutive records per step
+                    const uint32_t per = ((Pb + NW * 64u - 1u) / (NW * 64u)) * 64u;
+                    const uint32_t kbeg = (uint32_t)w * per, kend = min(Pb, kbeg + per);
+                    for (uint32_t kc = kbeg; kc < kend; kc += 64) {   // wave-uniform
+                        const bool on = kc + (uint32_t)lane < kend;
+                        const uint32_t sl = k_lo - slot0 + kc + (uint32_t)lane;
+                        uint32_t cell = 0u;
+                        if (on) { if constexpr (DMA) cell = stage[sl].z & 0xffffu; else cell = nxt[sl]; }
+                        const uint64_t peers = wave_peers(on, cell, 2 * TS);
+                        const uint64_t above = lane == 63 ? 0ull : (peers & (~0ull << (lane + 1)));
+                        if (on) {
+                            nxt[sl] = above ? (uint16_t)(sl + (uint32_t)(__ffsll((unsigned long long)above) - 1 - lane)) : (uint16_t)NIL;
+                            const uint32_t hi = cell * NW + (uint32_t)w;
+                            if ((peers & lt) == 0) {                  // first of its group: link behind the wave's list of this cell
+                                if (head[hi] == NIL) head[hi] = (uint16_t)sl;
+                                else nxt[tail[hi]] = (uint16_t)sl;
+                            }
+                            if (above == 0) tail[hi] = (uint16_t)sl;
+                        }
+                    }
+                }
+                __syncthreads();
+                // walk: the CPT cells of a thread advance together (independent chains), one node per
+                // cell and iteration, through list(wave 0), list(wave 1), ...
+                {
+                    uint32_t cur[CPT], wwq[CPT], wl[CPT], hdp[CPT][NW];
+                    bool more = false;
+#pragma unroll
+                    for (int q = 0; q < CPT; ++q) {
+                        const int c = tid + NT * q;
+                        if constexpr (NW == 4) {
+                            const uint2 hv = *reinterpret_cast<const uint2*>(head + c * NW);
+                            hdp[q][0] = hv.x & 0xffffu; hdp[q][1] = hv.x >> 16; hdp[q][2] = hv.y & 0xffffu; hdp[q][3] = hv.y >> 16;
+                        } else {
+                            const uint4 hv = *reinterpret_cast<const uint4*>(head + c * NW);
+                            hdp[q][0] = hv.x & 0xffffu; hdp[q][1] = hv.x >> 16; hdp[q][2] = hv.y & 0xffffu; hdp[q][3] = hv.y >> 16;
+                            hdp[q][4] = hv.z & 0xffffu; hdp[q][5] = hv.z >> 16; hdp[q][6] = hv.w & 0xffffu; hdp[q][7] = hv.w >> 16;
+                        }
+                        // chain the wave lists of the cell: cur = first non-empty head, and each list's
+                        // successor is the next non-empty head (resolved when its NIL end is reached)
+                        cur[q] = NIL; wwq[q] = NW; wl[q] = 0xffffffffu;
+#pragma unroll
+                        for (int ww = NW - 1; ww >= 0; --ww) if (hdp[q][ww] != NIL) { cur[q] = hdp[q][ww]; wwq[q] = (uint32_t)ww; }
+                        if (cur[q] != NIL) { tmask |= 1u << q; more = true; }
+                    }
+                    // software-pipelined: the node after the current one is resolved from registers and its LDS
+                    // reads are issued before the current node's fusion step, so the two latencies overlap
+                    float nh[CPT], nv[CPT]; uint32_t nn[CPT], nsv[CPT];
+#pragma unroll
+                    for (int q = 0; q < CPT; ++q) {
+                        const uint32_t sl = cur[q] != NIL ? cur[q] : 0u;
+                        nh[q] = rec_h(sl); nv[q] = rec_v(sl); nn[q] = nxt[sl];
+                        if (ATTR) nsv[q] = rec_src(sl);
+                    }
+                    while (__ballot(more) != 0) {                    // wave-uniform
+                        more = false;
+#pragma unroll
+                        for (int q = 0; q < CPT; ++q) {
+                            const bool live = cur[q] != NIL;
+                            const float h = nh[q], v = nv[q];
+                            const uint32_t sv = ATTR ? nsv[q] : 0u;
+                            uint32_t nx = nn[q];
+                            if (live && nx == NIL) {                 // end of this wave's list: continue with the next non-empty one
+                                uint32_t nw_ = NW;
+#pragma unroll
+                                for (int ww = NW - 1; ww >= 0; --ww) if ((uint32_t)ww > wwq[q] && hdp[q][ww] != NIL) { nx = hdp[q][ww]; nw_ = (uint32_t)ww; }
+                                wwq[q] = nw_;
+                            }
+                            nx = live ? nx : NIL;
+                            const uint32_t sl2 = nx != NIL ? nx : 0u;
+                            nh[q] = rec_h(sl2); nv[q] = rec_v(sl2); nn[q] = nxt[sl2];
+                            if (ATTR) nsv[q] = rec_src(sl2);
+                            float e2 = ce[q], s2 = cs[q];
+                            const bool taken = fuse_step(e2, s2, h, v, a.mahal, a.var_floor);
+                            const bool fl = live && (!LOWEST || h != -1.0f);          // GPU:482 (only LOWEST passes carry such records)
+                            ce[q] = fl ? e2 : ce[q]; cs[q] = fl ? s2 : cs[q];
+                            if constexpr (LOWEST) { const float l2 = lowest_step(lw[q], h, v); lw[q] = live ? l2 : lw[q]; }
+                            if (ATTR) { if (fl && taken && (sv & 0x80000000u)) wl[q] = sv & 0x7fffffffu; }
+                            cur[q] = nx;
+                            more |= cur[q] != NIL;
+                        }
+                    }
+                    if (ATTR) {
+#pragma unroll
+                        for (int q = 0; q < CPT; ++q) if (wl[q] != 0xffffffffu) write_attr(q, wl[q]);
+                    }
+                }
+                __syncthreads();
+                {   // back to the fast path's invariant: every row has count 0
+                    uint4* z = reinterpret_cast<uint4*>(rowp);
+                    for (int c = tid; c < CELLS; c += NT) z[c] = make_uint4(0, 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            GEM_STAMP();                                             // 5: walked
+        };
 
         // a single sweep holds at most kChunkUnits units (longer clouds are cut into sweeps): exactly one chunk, and no
         // loop header at which the compiler would have to wait for every load in flight
@@ -670,7 +931,7 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
                 if (ci == 0 && P > a.dense_min) {                        // block-uniform: a dense tile, nothing of this sweep consumed yet
 #pragma unroll
                     for (int q = 0; q < CPT; ++q) { st.e[q] = ce[q]; st.s[q] = cs[q]; if constexpr (LOWEST) st.lw[q] = lw[q]; }
-                    st.tmask = tmask; st.sweep = sweep;
+                    st.tmask = tmask; st.sweep = sweep; st.acc_nd = acc_nd; st.acc_P = acc_P;
                     return true;
                 }
             }
@@ -685,8 +946,56 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
                     else                    *reinterpret_cast<uint2*>(rowx) = make_uint2(0, 0);
                 }
             }
+            const uint32_t nb = (P - 1u) / Q + 1u;                       // batches 0 .. nb-2 are non-empty (a descriptor holds < Q records)
+            if (nb > 1) {
+                for (uint32_t i = tid; i < nb; i += NT) bstart[i] = 0xffffffffu;
+                if (tid == 0) bstart[nb] = nd;
+                __syncthreads();
+                uint32_t d = run >> 20, rs = run & 0xfffffu;
+#pragma unroll
+                for (int j = 0; j < UPT; ++j)
+                    if (ev[j] != 0) { atomicMin(&bstart[rs / Q], d); ++d; rs += ev[j] & kSegCountMask; }
+                __syncthreads();
+            }
+
+            // ---- batches.  In accumulate mode a batch first collects the descriptors of several sweeps (see acc_mode above):
+            //      b == -1 runs the accumulated batch when this sweep cannot join it (too many records, or a dense tile);
+            //      b >= 0 are this sweep's own batches, unless it was appended or takes the dense path.
+            bool dense_now = false, fits = false;
+            if constexpr (MODE == 2 && DMA && CPT == 1) dense_now = P > a.dense_min;
+            if (acc_mode) fits = !dense_now && acc_P + P <= Q && acc_nd + nd <= (uint32_t)DCAP;
+            const int b_first = (acc_P != 0 && !fits) ? -1 : 0;
+            const int b_end = (dense_now || fits) ? 0 : (int)nb;
+            for (int b = b_first; b < b_end; ++b) {
+                uint32_t m, slot0;
+                if (b < 0) {
+                    m = acc_nd; slot0 = 0u; acc_nd = 0u; acc_P = 0u;     // the list already sits in dl_addr / dl_rc
+                } else {
+                    // (the last batch is empty when the final descriptor merely extends past a multiple of Q)
+                    const uint32_t d_lo = nb > 1 ? bstart[b] : 0u;
+                    if (d_lo == 0xffffffffu) break;                      // block-uniform
+                    const uint32_t d_hi = nb > 1 ? min(bstart[b + 1], nd) : nd;
+                    m = d_hi - d_lo; slot0 = (uint32_t)b * Q;
+                    // this batch's descriptors, in order
+                    uint32_t d = run >> 20, rs = run & 0xfffffu;
+#pragma unroll
+                    for (int j = 0; j < UPT; ++j) {
+                        if (ev[j] != 0) {
+                            const uint32_t cnt = ev[j] & kSegCountMask;
+                            if (d >= d_lo && d < d_hi) {
+                                dl_addr[d - d_lo] = (uint32_t)(ub + u0 + j) * (uint32_t)a.U + ((ev[j] >> kSegCountBits) & kSegStartMask);
+                                dl_rc[d - d_lo] = (rs << 9) | cnt;
+                            }
+                            ++d; rs += cnt;
+                        }
+                    }
+                }
+                __syncthreads();
+                GEM_STAMP();                                             // 3: descriptor list built
+                run_batch(m, slot0);
+            }
             if constexpr (MODE == 2 && DMA && CPT == 1) {
-                if (P > a.dense_min) {                                   // block-uniform
+                if (dense_now) {                                         // block-uniform
                     // ---- DENSE TILE: see dense_tile().  The chunk's descriptor list goes to the stage area, the rest is
                     //      an out-of-line call so that its registers do not count against the LiDAR paths below.
                     static_assert(!DMA || PB * 16 >= kChunkUnits * 8, "the chunk's descriptor list lives in the stage area");
@@ -713,289 +1022,26 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
                     continue;
                 }
             }
-            const uint32_t nb = (P - 1u) / Q + 1u;                       // batches 0 .. nb-2 are non-empty (a descriptor holds < Q records)
-            if (nb > 1) {
-                for (uint32_t i = tid; i < nb; i += NT) bstart[i] = 0xffffffffu;
-                if (tid == 0) bstart[nb] = nd;
-                __syncthreads();
-                uint32_t d = run >> 20, rs = run & 0xfffffu;
+            if (fits) {
+                // this sweep's descriptors join the accumulated batch (record prefixes continue where the batch stands)
+                uint32_t d = acc_nd + (run >> 20), rs = acc_P + (run & 0xfffffu);
 #pragma unroll
-                for (int j = 0; j < UPT; ++j)
-                    if (ev[j] != 0) { atomicMin(&bstart[rs / Q], d); ++d; rs += ev[j] & kSegCountMask; }
-                __syncthreads();
+                for (int j = 0; j < UPT; ++j) {
+                    if (ev[j] != 0) {
+                        const uint32_t cnt = ev[j] & kSegCountMask;
+                        dl_addr[d] = (uint32_t)(ub + u0 + j) * (uint32_t)a.U + ((ev[j] >> kSegCountBits) & kSegStartMask);
+                        dl_rc[d] = (rs << 9) | cnt;
+                        ++d; rs += cnt;
+                    }
+                }
+                acc_nd += nd; acc_P += P;
             }
-
-            for (uint32_t b = 0; b < nb; ++b) {
-                // (the last batch is empty when the final descriptor merely extends past a multiple of Q)
-                const uint32_t d_lo = nb > 1 ? bstart[b] : 0u;
-                if (d_lo == 0xffffffffu) break;                          // block-uniform
-                const uint32_t d_hi = nb > 1 ? min(bstart[b + 1], nd) : nd, m = d_hi - d_lo;
-                const uint32_t slot0 = b * Q;
-                {   // this batch's descriptors, in order
-                    uint32_t d = run >> 20, rs = run & 0xfffffu;
-#pragma unroll
-                    for (int j = 0; j < UPT; ++j) {
-                        if (ev[j] != 0) {
-                            const uint32_t cnt = ev[j] & kSegCountMask;
-                            if (d >= d_lo && d < d_hi) {
-                                dl_addr[d - d_lo] = (uint32_t)(ub + u0 + j) * (uint32_t)a.U + ((ev[j] >> kSegCountBits) & kSegStartMask);
-                                dl_rc[d - d_lo] = (rs << 9) | cnt;
-                            }
-                            ++d; rs += cnt;
-                        }
-                    }
-                }
-                __syncthreads();
-                GEM_STAMP();                                             // 3: descriptor list built
-
-                // ---- 2 + 3a. gather into LDS in input order (record k -> slot k - slot0) and take an
-                //      arrival rank per cell for the fast path.  Wave w takes the w-th contiguous share of
-                //      the batch's descriptors, one descriptor per step (lanes < count).
-                const uint32_t dw0 = (m * (uint32_t)w) / NW, dw1 = (m * (uint32_t)(w + 1)) / NW;
-                auto rank_one = [&](uint32_t cell, uint32_t sl) {
-                    const uint32_t old = atomicAdd(reinterpret_cast<uint32_t*>(rowp) + cell * 4 + 3, 0x10000u);
-                    const uint32_t rk = old >> 16;
-                    if (rk < (uint32_t)kRankMax) rowp[cell * 8 + rk] = (uint16_t)sl;
-                    else misc[1] = 1u;
-                };
-                if constexpr (DMA) {
-                    // lane i fetches the wave's i-th descriptor; each is then broadcast (v_readlane) and turned into ONE
-                    // global_load_lds_dwordx4 whose LDS base is the descriptor's first slot: nothing waits until all are issued
-                    for (uint32_t dbase = dw0; dbase < dw1; dbase += 64) {             // wave-uniform
-                        const uint32_t nhere = min(64u, dw1 - dbase);
-                        uint32_t my_rc = 0, my_addr = 0;
-                        if ((uint32_t)lane < nhere) { my_rc = dl_rc[dbase + lane]; my_addr = dl_addr[dbase + lane]; }
-                        for (uint32_t i = 0; i < nhere; ++i) {
-                            const uint32_t rc = (uint32_t)__builtin_amdgcn_readlane((int)my_rc, (int)i);
-                            const uint32_t adr = (uint32_t)__builtin_amdgcn_readlane((int)my_addr, (int)i);
-                            if ((uint32_t)lane < (rc & 0x1ffu))
-                                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.rec + adr + (uint32_t)lane),
-                                                                 (__attribute__((address_space(3))) void*)(stage + ((rc >> 9) - slot0)), 16, 0, 0);
-                        }
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();
-                    const uint32_t first = (dl_rc[0] >> 9) - slot0;                     // slots of the batch: [first, first + Pb)
-                    const uint32_t Pb = (dl_rc[m - 1] >> 9) + (dl_rc[m - 1] & 0x1ffu) - (dl_rc[0] >> 9);
-                    // PB / NT slots per thread: all cell reads, then all rank atomics, then all row writes in flight together
-                    constexpr int RK = PB / NT;
-                    uint32_t rcell[RK], rold[RK];
-#pragma unroll
-                    for (int r = 0; r < RK; ++r) { const uint32_t k = (uint32_t)(tid + r * NT); rcell[r] = k < Pb ? (stage[first + k].z & 0xffffu) : 0u; }
-#pragma unroll
-                    for (int r = 0; r < RK; ++r) { const uint32_t k = (uint32_t)(tid + r * NT); rold[r] = 0; if (k < Pb) rold[r] = atomicAdd(reinterpret_cast<uint32_t*>(rowp) + rcell[r] * 4 + 3, 0x10000u); }
-#pragma unroll
-                    for (int r = 0; r < RK; ++r) {
-                        const uint32_t k = (uint32_t)(tid + r * NT);
-                        if (k < Pb) { const uint32_t rk = rold[r] >> 16; if (rk < (uint32_t)kRankMax) rowp[rcell[r] * 8 + rk] = (uint16_t)(first + k); else misc[1] = 1u; }
-                    }
-                } else {
-                    // through registers, the loads of the next PF descriptors in flight while the current PF are being filed
-                    constexpr int PF = 4;
-                    uint4 rA[PF], rB[PF]; uint32_t sA[PF], sB[PF];       // slot == ~0: lane inactive
-                    auto fetch = [&](uint32_t dd, uint4 (&rr)[PF], uint32_t (&sl)[PF]) {
-#pragma unroll
-                        for (int x = 0; x < PF; ++x) {
-                            sl[x] = 0xffffffffu; rr[x] = make_uint4(0, 0, 0, 0);
-                            if (dd + x < dw1) {                          // wave-uniform
-                                const uint32_t rc = dl_rc[dd + x];
-                                if ((uint32_t)lane < (rc & 0x1ffu)) {
-                                    sl[x] = (rc >> 9) - slot0 + (uint32_t)lane;
-                                    rr[x] = a.rec[dl_addr[dd + x] + (uint32_t)lane];
-                                }
-                            }
-                        }
-                    };
-                    auto file = [&](const uint4 (&rr)[PF], const uint32_t (&sl)[PF]) {
-#pragma unroll
-                        for (int x = 0; x < PF; ++x) {
-                            if (sl[x] != 0xffffffffu) {
-                                const uint32_t cell = rr[x].z & 0xffffu;
-                                s_h[sl[x]] = __uint_as_float(rr[x].x); s_v[sl[x]] = __uint_as_float(rr[x].y);
-                                if (ATTR) s_src[sl[x]] = (rr[x].w & 0x7fffffffu) | (rr[x].z & 0x80000000u);
-                                nxt[sl[x]] = (uint16_t)cell;             // the generic path reads the cell from here
-                                rank_one(cell, sl[x]);
-                            }
-                        }
-                    };
-                    if (dw0 < dw1) {
-                        fetch(dw0, rA, sA);
-                        for (uint32_t dd = dw0; dd < dw1; dd += 2 * PF) {   // wave-uniform
-                            fetch(dd + PF, rB, sB);
-                            file(rA, sA);
-                            fetch(dd + 2 * PF, rA, sA);
-                            file(rB, sB);
-                        }
-                    }
-                }
-                __syncthreads();
-                GEM_STAMP();                                             // 4: records in LDS, ranked
-
-                apply_increments();
-                if (misc[1] == 0) {
-                    // ---- 3a. owner: sort <= 7 slot numbers, run the chains from registers.  The CPT cells
-                    //      of a thread are independent chains: everything is straight-line with selects so
-                    //      that their sorting networks and IEEE divisions interleave.
-                    uint4 row[CPT]; uint32_t n[CPT], nmax = 0;
-#pragma unroll
-                    for (int q = 0; q < CPT; ++q) row[q] = *reinterpret_cast<const uint4*>(rowp + (tid + NT * q) * 8);
-                    uint32_t ps[CPT][kRankMax];
-#pragma unroll
-                    for (int q = 0; q < CPT; ++q) {
-                        n[q] = row[q].w >> 16;
-                        nmax = max(nmax, n[q]);
-                        if (n[q] != 0) { reinterpret_cast<uint32_t*>(rowp + (tid + NT * q) * 8)[3] = 0u; tmask |= 1u << q; }
-                        uint32_t p0 = row[q].x & 0xffffu, p1 = row[q].x >> 16, p2 = row[q].y & 0xffffu, p3 = row[q].y >> 16,
-                                 p4 = row[q].z & 0xffffu, p5 = row[q].z >> 16, p6 = row[q].w & 0xffffu, p7 = NIL;
-                        if (n[q] < 1) p0 = NIL; if (n[q] < 2) p1 = NIL; if (n[q] < 3) p2 = NIL; if (n[q] < 4) p3 = NIL;
-                        if (n[q] < 5) p4 = NIL; if (n[q] < 6) p5 = NIL; if (n[q] < 7) p6 = NIL;
-                        GEM_CSWAP(p0, p1); GEM_CSWAP(p2, p3); GEM_CSWAP(p4, p5); GEM_CSWAP(p6, p7);
-                        GEM_CSWAP(p0, p2); GEM_CSWAP(p1, p3); GEM_CSWAP(p4, p6); GEM_CSWAP(p5, p7);
-                        GEM_CSWAP(p1, p2); GEM_CSWAP(p5, p6); GEM_CSWAP(p0, p4); GEM_CSWAP(p3, p7);
-                        GEM_CSWAP(p1, p5); GEM_CSWAP(p2, p6);
-                        GEM_CSWAP(p1, p4); GEM_CSWAP(p3, p6);
-                        GEM_CSWAP(p2, p4); GEM_CSWAP(p3, p5);
-                        GEM_CSWAP(p3, p4);
-                        ps[q][0] = p0; ps[q][1] = p1; ps[q][2] = p2; ps[q][3] = p3; ps[q][4] = p4; ps[q][5] = p5; ps[q][6] = p6;
-                    }
-                    float hh[CPT][kRankMax], vv[CPT][kRankMax]; uint32_t sv[CPT][kRankMax];
-#pragma unroll
-                    for (int i = 0; i < kRankMax; ++i) {
-                        if (__ballot((uint32_t)i < nmax) == 0) break;    // wave-uniform
-#pragma unroll
-                        for (int q = 0; q < CPT; ++q) {
-                            const uint32_t sl = (uint32_t)i < n[q] ? ps[q][i] : 0u;       // slot 0 is always a valid address
-                            hh[q][i] = rec_h(sl); vv[q][i] = rec_v(sl);
-                            if (ATTR) sv[q][i] = rec_src(sl);
-                        }
-                    }
-                    uint32_t wlast[CPT];
-#pragma unroll
-                    for (int q = 0; q < CPT; ++q) wlast[q] = 0xffffffffu;
-#pragma unroll
-                    for (int i = 0; i < kRankMax; ++i) {
-                        if (__ballot((uint32_t)i < nmax) == 0) break;    // wave-uniform
-#pragma unroll
-                        for (int q = 0; q < CPT; ++q) {
-                            float e2 = ce[q], s2 = cs[q];
-                            const bool taken = fuse_step(e2, s2, hh[q][i], vv[q][i], a.mahal, a.var_floor);
-                            const bool live = (uint32_t)i < n[q];
-                            const bool fl = live && (!LOWEST || hh[q][i] != -1.0f);      // GPU:482 (only LOWEST passes carry such records)
-                            ce[q] = fl ? e2 : ce[q]; cs[q] = fl ? s2 : cs[q];
-                            if constexpr (LOWEST) { const float l2 = lowest_step(lw[q], hh[q][i], vv[q][i]); lw[q] = live ? l2 : lw[q]; }
-                            if (ATTR) { if (fl && taken && (sv[q][i] & 0x80000000u)) wlast[q] = sv[q][i] & 0x7fffffffu; }
-                        }
-                    }
-                    if (ATTR) {
-#pragma unroll
-                        for (int q = 0; q < CPT; ++q) if (wlast[q] != 0xffffffffu) write_attr(q, wlast[q]);
-                    }
-                } else {
-                    // ---- 3b. generic path: per-wave in-order linked lists --------------------------
-                    const uint32_t k_lo = dl_rc[0] >> 9;
-                    const uint32_t Pb = (dl_rc[m - 1] >> 9) + (dl_rc[m - 1] & 0x1ffu) - k_lo;      // records of this batch
-                    {
-                        uint4* z = reinterpret_cast<uint4*>(head);
-                        for (int c = tid; c < CELLS * NW / 8; c += NT) z[c] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-                    }
-                    __syncthreads();
-                    if (tid == 0) misc[1] = 0u;
-                    {   // wave w appends records [w * per, (w + 1) * per) of the batch, 64 consecutive records per step
-                        const uint32_t per = ((Pb + NW * 64u - 1u) / (NW * 64u)) * 64u;
-                        const uint32_t kbeg = (uint32_t)w * per, kend = min(Pb, kbeg + per);
-                        for (uint32_t kc = kbeg; kc < kend; kc += 64) {   // wave-uniform
-                            const bool on = kc + (uint32_t)lane < kend;
-                            const uint32_t sl = k_lo - slot0 + kc + (uint32_t)lane;
-                            uint32_t cell = 0u;
-                            if (on) { if constexpr (DMA) cell = stage[sl].z & 0xffffu; else cell = nxt[sl]; }
-                            const uint64_t peers = wave_peers(on, cell, 2 * TS);
-                            const uint64_t above = lane == 63 ? 0ull : (peers & (~0ull << (lane + 1)));
-                            if (on) {
-                                nxt[sl] = above ? (uint16_t)(sl + (uint32_t)(__ffsll((unsigned long long)above) - 1 - lane)) : (uint16_t)NIL;
-                                const uint32_t hi = cell * NW + (uint32_t)w;
-                                if ((peers & lt) == 0) {                  // first of its group: link behind the wave's list of this cell
-                                    if (head[hi] == NIL) head[hi] = (uint16_t)sl;
-                                    else nxt[tail[hi]] = (uint16_t)sl;
-                                }
-                                if (above == 0) tail[hi] = (uint16_t)sl;
-                            }
-                        }
-                    }
-                    __syncthreads();
-                    // walk: the CPT cells of a thread advance together (independent chains), one node per
-                    // cell and iteration, through list(wave 0), list(wave 1), ...
-                    {
-                        uint32_t cur[CPT], wwq[CPT], wl[CPT], hdp[CPT][NW];
-                        bool more = false;
-#pragma unroll
-                        for (int q = 0; q < CPT; ++q) {
-                            const int c = tid + NT * q;
-                            if constexpr (NW == 4) {
-                                const uint2 hv = *reinterpret_cast<const uint2*>(head + c * NW);
-                                hdp[q][0] = hv.x & 0xffffu; hdp[q][1] = hv.x >> 16; hdp[q][2] = hv.y & 0xffffu; hdp[q][3] = hv.y >> 16;
-                            } else {
-                                const uint4 hv = *reinterpret_cast<const uint4*>(head + c * NW);
-                                hdp[q][0] = hv.x & 0xffffu; hdp[q][1] = hv.x >> 16; hdp[q][2] = hv.y & 0xffffu; hdp[q][3] = hv.y >> 16;
-                                hdp[q][4] = hv.z & 0xffffu; hdp[q][5] = hv.z >> 16; hdp[q][6] = hv.w & 0xffffu; hdp[q][7] = hv.w >> 16;
-                            }
-                            // chain the wave lists of the cell: cur = first non-empty head, and each list's
-                            // successor is the next non-empty head (resolved when its NIL end is reached)
-                            cur[q] = NIL; wwq[q] = NW; wl[q] = 0xffffffffu;
-#pragma unroll
-                            for (int ww = NW - 1; ww >= 0; --ww) if (hdp[q][ww] != NIL) { cur[q] = hdp[q][ww]; wwq[q] = (uint32_t)ww; }
-                            if (cur[q] != NIL) { tmask |= 1u << q; more = true; }
-                        }
-                        // software-pipelined: the node after the current one is resolved from registers and its LDS
-                        // reads are issued before the current node's fusion step, so the two latencies overlap
-                        float nh[CPT], nv[CPT]; uint32_t nn[CPT], nsv[CPT];
-#pragma unroll
-                        for (int q = 0; q < CPT; ++q) {
-                            const uint32_t sl = cur[q] != NIL ? cur[q] : 0u;
-                            nh[q] = rec_h(sl); nv[q] = rec_v(sl); nn[q] = nxt[sl];
-                            if (ATTR) nsv[q] = rec_src(sl);
-                        }
-                        while (__ballot(more) != 0) {                    // wave-uniform
-                            more = false;
-#pragma unroll
-                            for (int q = 0; q < CPT; ++q) {
-                                const bool live = cur[q] != NIL;
-                                const float h = nh[q], v = nv[q];
-                                const uint32_t sv = ATTR ? nsv[q] : 0u;
-                                uint32_t nx = nn[q];
-                                if (live && nx == NIL) {                 // end of this wave's list: continue with the next non-empty one
-                                    uint32_t nw_ = NW;
-#pragma unroll
-                                    for (int ww = NW - 1; ww >= 0; --ww) if ((uint32_t)ww > wwq[q] && hdp[q][ww] != NIL) { nx = hdp[q][ww]; nw_ = (uint32_t)ww; }
-                                    wwq[q] = nw_;
-                                }
-                                nx = live ? nx : NIL;
-                                const uint32_t sl2 = nx != NIL ? nx : 0u;
-                                nh[q] = rec_h(sl2); nv[q] = rec_v(sl2); nn[q] = nxt[sl2];
-                                if (ATTR) nsv[q] = rec_src(sl2);
-                                float e2 = ce[q], s2 = cs[q];
-                                const bool taken = fuse_step(e2, s2, h, v, a.mahal, a.var_floor);
-                                const bool fl = live && (!LOWEST || h != -1.0f);          // GPU:482 (only LOWEST passes carry such records)
-                                ce[q] = fl ? e2 : ce[q]; cs[q] = fl ? s2 : cs[q];
-                                if constexpr (LOWEST) { const float l2 = lowest_step(lw[q], h, v); lw[q] = live ? l2 : lw[q]; }
-                                if (ATTR) { if (fl && taken && (sv & 0x80000000u)) wl[q] = sv & 0x7fffffffu; }
-                                cur[q] = nx;
-                                more |= cur[q] != NIL;
-                            }
-                        }
-                        if (ATTR) {
-#pragma unroll
-                            for (int q = 0; q < CPT; ++q) if (wl[q] != 0xffffffffu) write_attr(q, wl[q]);
-                        }
-                    }
-                    __syncthreads();
-                    {   // back to the fast path's invariant: every row has count 0
-                        uint4* z = reinterpret_cast<uint4*>(rowp);
-                        for (int c = tid; c < CELLS; c += NT) z[c] = make_uint4(0, 0, 0, 0);
-                    }
-                }
-                __syncthreads();
-                GEM_STAMP();                                             // 5: walked
-            }
+        }
+        if (acc_P != 0 && sweep == NS - 1) {                             // block-uniform: the last accumulated batch of the pass
+            __syncthreads();
+            const uint32_t m = acc_nd;
+            acc_nd = 0u; acc_P = 0u;
+            run_batch(m, 0u);
         }
 
         // ---- variance floor at the end of every Fuse (GPU:533-534), on every cell -----------------
