@@ -555,6 +555,37 @@ def test_dense_depth_image_default_threshold(oracle_mod):
         gpu.mapvar_update(3e-5); ref.mapvar_update(3e-5)
 
 
+# ---- accumulate mode: sweeps without variance increments between them share batches ---------------------------------------
+@pytest.mark.parametrize("dense_min", [2048, 150])
+def test_batch_without_increments_accumulates_across_sweeps(oracle_mod, monkeypatch, dense_min):
+    """Sweeps of very different sizes over the same tiles: a few points (appended), a flood (does not fit: flush, then its own
+    batches), tiles that turn dense in the middle of a collected batch, an empty sweep, a tail that is flushed at the end of
+    the pass -- and the same call with per-sweep counting on, which switches the accumulation off."""
+    import torch
+    monkeypatch.setenv("GEM_DENSE_MIN", str(dense_min))
+    L, res = 96, 0.1
+    rng = np.random.default_rng(21)
+    f0 = synth._frame_for(synth.pose_matrix(0.1, -0.2, 0.0, yaw=0.3), SensorModel.velodyne())
+    f1 = synth._frame_for(synth.pose_matrix(-0.3, 0.1, 0.05, yaw=-0.7), SensorModel.velodyne())
+    sizes = [40, 300, 25, 9000, 10, 0, 700, 60, 30_000, 15, 80, 5]
+    clouds = [synth.random_cloud(300 + k, n, 5.0, z_sigma=0.2, dup_fraction=0.3) for k, n in enumerate(sizes)]
+    clouds[6][:, :2] = clouds[6][:, :2] * 0.1 + 1.0                       # a cluster: a few cells get hundreds of records
+    frames = [f0 if k % 3 else f1 for k in range(len(sizes))]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    cat = torch.from_numpy(np.concatenate(clouds)).cuda()
+    gpu, ref = make_pair(oracle_mod, L, res)
+    gpu2 = ElevationMap(L, res)
+    gpu2.set_counting(True)
+    for rep in range(2):
+        gpu.mapvar_update(2e-5); gpu2.mapvar_update(2e-5); ref.mapvar_update(2e-5)      # queued: applied before the first record
+        gpu.add_batch(frames, cat, off, None)
+        gpu2.add_batch(frames, cat, off, None)
+        for k in range(len(sizes)):
+            ref.add(frames[k], clouds[k])
+        assert_maps_match(gpu, ref)
+        assert_maps_match(gpu2, ref)
+
+
 # ---- aggregated cloud into the big map (BASELINE config 5, reduced) -----------------------------------------------------
 def test_c5_aggregated_batch_parity(oracle_mod):
     import torch
