@@ -89,6 +89,30 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
     return base + inc - v;
 }
 
+// The same with ONE barrier: consecutive calls alternate between the two halves of `scratch` (parity), so a wave that runs
+// ahead into the next call writes the other half while a slower wave may still be reading this one; by the time a half is
+// written again every wave has passed the barrier of the call in between.  NT/64 <= 8.
+template <int NT>
+__device__ __forceinline__ uint32_t block_exclusive_scan_alt(uint32_t v, uint32_t* scratch, uint32_t parity, uint32_t* total)
+{
+    constexpr int NW = NT / 64;
+    static_assert(NW <= 8, "two halves of 8 words");
+    uint32_t* sc = scratch + (parity & 1u) * 8u;
+    const int w = (int)(threadIdx.x >> 6);
+    const uint32_t inc = wave_inclusive_scan(v);
+    if (lane_id() == 63) sc[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const uint32_t s = sc[i];
+        if (i < w) base += s;
+        tot += s;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
 // "match-any" on a 64-lane wave: the mask of valid lanes holding the same key as this lane,
 // from one ballot per key bit (no loop over distinct keys, no LDS, no divergence).
 // rank among equal keys in lane order = popc(peers & lanemask_lt); group size = popc(peers).
@@ -615,6 +639,7 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
     // Per-sweep cell counts need the sweeps apart, so counting per sweep turns it off.
     const bool acc_mode = BATCH && !var_updates && (!a.counters || a.count_per_pass);
     uint32_t acc_nd = MODE == 2 ? st.acc_nd : 0u, acc_P = MODE == 2 ? st.acc_P : 0u;   // descriptors / records collected so far (block-uniform)
+    uint32_t scan_parity = 0;                                            // see block_exclusive_scan_alt
     bool pend_done = MODE == 2 && sweep0 > 0;                            // queued Mapvar_update increments: applied once, before the first record
     for (int sweep = sweep0; sweep < NS; ++sweep) {
         if (sweep != sweep0 && (sweep & 63) == 0) { smask = sweep_mask(sweep); sweep_tables(sweep); }
@@ -923,7 +948,7 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
             }
             if (a.dbg) { asm volatile("" :: "v"(packed)); GEM_STAMP(); }                      // 2: descriptor words arrived
             uint32_t tot;
-            const uint32_t run = block_exclusive_scan<NT>(packed, scratch, &tot);
+            const uint32_t run = block_exclusive_scan_alt<NT>(packed, scratch, scan_parity++, &tot);
             const uint32_t nd = tot >> 20, P = tot & 0xfffffu;
             if (next_sweep >= 0) { evn = load_row(next_sweep, units_of(next_sweep), 0, gfn, evn_on); prefetched = next_sweep; }
             if (P == 0) continue;                                        // block-uniform
