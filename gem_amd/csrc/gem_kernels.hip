@@ -1387,7 +1387,7 @@ static size_t fuse_list_lds(int cells, int nw, int pb, int attr)
 }
 
 // (tile shift, variant) -> threads per tile and records per LDS batch
-//   16x16 tiles: 256 threads, 1024-record batches (~26 KB of LDS, 4 workgroups per CU)
+//   16x16 tiles: 256 threads, 1024-record batches (~31 KB of LDS, 4 workgroups per CU)
 //   32x32 tiles: variant 10 = 256 threads / 4096, 11 = 512 / 4096, 12 = 512 / 2048 (2 per CU, the default)
 static void fuse_list_geometry(int ts, int variant, int* nt, int* pb)
 {
