@@ -66,6 +66,7 @@ SIGNATURES = {
     "gem_map_optmove": (c_int, [c_void_p, POINTER(c_float), c_float, POINTER(c_float)]),
     "gem_map_closeloop": (c_int, [c_void_p, POINTER(c_float), c_float]),
     "gem_set_lowest_tracking": (c_int, [c_void_p, c_int]),
+    "gem_add_aos": (c_int, [c_void_p, POINTER(FrameParams), c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int]),
     "gem_raytracing": (c_int, [c_void_p]),
     "gem_set_timing": (c_int, [c_void_p, c_int]),
     "gem_set_counting": (c_int, [c_void_p, c_int]),

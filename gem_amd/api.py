@@ -308,6 +308,16 @@ class ElevationMap:
         kr, pr = _host_ptr(rgb, np.uint32, n); ko, po = _host_ptr(orig_index, np.int32, n)
         self._check(self._lib.gem_add(self._h, C.byref(p), n, a.ctypes.data_as(C.c_void_p), pr, po), "gem_add")
 
+    def add_aos(self, frame: Frame, points: np.ndarray, off_x: int = 0, off_y: int = 4, off_z: int = 8, off_intensity: int = 24,
+                off_rgb: int = 16) -> None:
+        """The cloud as an array of point structs (numpy structured array or [n, step] bytes), default offsets =
+        PointXYZRGBICT (PointXYZRGBICT.hpp:28-46); unpacked on the device (gem_add_aos)."""
+        a = np.ascontiguousarray(points)
+        n, step = a.shape[0], a.dtype.itemsize * (int(np.prod(a.shape[1:])) if a.ndim > 1 else 1)
+        p = frame.to_struct()
+        self._check(self._lib.gem_add_aos(self._h, C.byref(p), n, a.ctypes.data_as(C.c_void_p), step, off_x, off_y, off_z,
+                                          off_intensity, off_rgb), "gem_add_aos")
+
     @staticmethod
     def pack_batch(frames: Sequence[Frame], offsets, var_updates=None) -> "PackedBatch":
         """The C-ABI arrays of a batched call, built once (32 frames cost ~0.3 ms of ctypes conversion per call otherwise)."""

@@ -718,6 +718,33 @@ int gem_add(gem_handle* h, const gem_frame_params* p, int n, const float* xyzi, 
     return run_pipeline(h, in);
 }
 
+int gem_add_aos(gem_handle* h, const gem_frame_params* p, int n, const void* points, int point_step,
+                int off_x, int off_y, int off_z, int off_intensity, int off_rgb)
+{
+    if (!h || !p || n < 0 || (n > 0 && !points)) return h ? fail(h, GEM_ERR_INVALID, "gem_add_aos: bad argument") : GEM_ERR_INVALID;
+    auto field_ok = [&](int o, bool optional) { return (optional && o < 0) || (o >= 0 && (o & 3) == 0 && o + 4 <= point_step); };
+    if (point_step < 12 || (point_step & 3) || !field_ok(off_x, false) || !field_ok(off_y, false) || !field_ok(off_z, false) ||
+        !field_ok(off_intensity, true) || !field_ok(off_rgb, true))
+        return fail(h, GEM_ERR_INVALID, "gem_add_aos: fields must be 4-byte aligned inside point_step");
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    PassInput in; in.src = 0; in.n = n; in.params = p;
+    if (n > 0) {
+        const size_t raw = ((size_t)n * point_step + 15) & ~(size_t)15, S = (size_t)n * 4;
+        int rc;
+        if ((rc = ensure(h, h->stage, raw + S * 5))) return rc;
+        unsigned char* d = static_cast<unsigned char*>(h->stage.p);
+        GEM_HIP(h, hipMemcpyAsync(d, points, (size_t)n * point_step, hipMemcpyHostToDevice, h->stream));
+        float4* xyzi = reinterpret_cast<float4*>(d + raw);
+        uint32_t* rgb = off_rgb >= 0 ? reinterpret_cast<uint32_t*>(d + raw + S * 4) : nullptr;
+        GEM_HIP(h, launch_unpack_aos(h->stream, d, n, point_step, off_x, off_y, off_z, off_intensity, off_rgb, xyzi, rgb));
+        in.xyzi = xyzi; in.rgb = rgb;
+        GEM_HIP(h, hipEventRecord(h->copy_done, h->stream));
+        GEM_HIP(h, hipEventSynchronize(h->copy_done));              // the caller's buffer has been read
+    }
+    return run_pipeline(h, in);
+}
+
 int gem_add_batch_device(gem_handle* h, int n_sweeps, const gem_frame_params* params, const void* d_xyzi,
                          const long long* offsets, const float* var_updates)
 {

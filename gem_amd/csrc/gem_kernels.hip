@@ -1519,6 +1519,30 @@ __global__ __launch_bounds__(256) void k_raytracing(LayerPtrs m, int L, int star
     if (obstacle_ele - 3 * sqrtf(m.variance[i]) > restrict_ele) m.elevation[i] = kEmptyElevation;   // GPU:884-885
 }
 
+// AoS ingest (first half): the reference walks the PCL cloud on the host and copies x, y, z, r, g, b, intensity
+// into seven stack arrays (SPB.cpp:160-169).  Here the point structs go to the device as they are and this kernel pulls the
+// fields apart: byte offsets of four-byte fields inside a struct of `step` bytes (PointXYZRGBICT.hpp:28-46: x y z pad | rgb |
+// covariance | intensity | travers, 32 bytes; PCL's rgb is the bytes b, g, r, a).
+__global__ __launch_bounds__(256) void k_unpack_aos(const unsigned char* __restrict__ src, int n, int step, int ox, int oy, int oz, int oi, int orgb,
+                                                    float4* __restrict__ xyzi, uint32_t* __restrict__ rgb)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const unsigned char* p = src + (size_t)i * step;
+        float4 v;
+        v.x = *reinterpret_cast<const float*>(p + ox); v.y = *reinterpret_cast<const float*>(p + oy);
+        v.z = *reinterpret_cast<const float*>(p + oz); v.w = oi >= 0 ? *reinterpret_cast<const float*>(p + oi) : 0.0f;
+        xyzi[i] = v;
+        if (rgb) rgb[i] = *reinterpret_cast<const uint32_t*>(p + orgb) & 0x00ffffffu;      // a<<24 | r<<16 | g<<8 | b  ->  0x00RRGGBB
+    }
+}
+
+hipError_t launch_unpack_aos(hipStream_t st, const void* src, int n, int step, int ox, int oy, int oz, int oi, int orgb, float4* xyzi, uint32_t* rgb)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_unpack_aos, dim3(grid_for(n, 256)), dim3(256), 0, st, static_cast<const unsigned char*>(src), n, step, ox, oy, oz, oi, orgb, xyzi, rgb);
+    return hipGetLastError();
+}
+
 // G_Clear_maplowest (GPU:232-239)
 __global__ __launch_bounds__(256) void k_fill(float* p, int n, float v)
 {

@@ -97,6 +97,7 @@ hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr, int 
 hipError_t launch_frame(hipStream_t st, const FuseArgs& fuse_prev, const BinArgs& bin_this, LaunchEvents ev);
 size_t     fuse_lds_bytes(int ts, int variant, int attr);
 hipError_t launch_init(hipStream_t st, const LayerPtrs& m, int cells, int clear_lowest);
+hipError_t launch_unpack_aos(hipStream_t st, const void* src, int n, int step, int ox, int oy, int oz, int oi, int orgb, float4* xyzi, uint32_t* rgb);
 hipError_t launch_raytracing(hipStream_t st, const LayerPtrs& m, int L, int start0, int start1, float sensor_z, float obstacle_threshold,
                              int row0, int row1);
 hipError_t launch_clear_strip(hipStream_t st, const LayerPtrs& m, int L, int start, int count, int is_row);

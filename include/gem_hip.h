@@ -144,6 +144,15 @@ int  gem_add(gem_handle* h, const gem_frame_params* p, int n, const float* xyzi,
 int  gem_add_device(gem_handle* h, const gem_frame_params* p, int n, const void* d_xyzi,
                     const void* d_rgb, const void* d_orig_index);
 
+/* ---- AoS ingest: the cloud as an array of point structs, e.g. pcl::PointCloud<PointXYZRGBICT>::points
+ *      (PointXYZRGBICT.hpp:28-46: 32-byte structs, x y z at 0 4 8, rgb at 16 -- PCL's b g r a bytes --, intensity at 24).
+ *      Replaces the host loop that pulls the fields into seven arrays (SPB.cpp:160-169) and the packing that gem_add
+ *      expects: the structs are copied to the device as they are and unpacked there.  Offsets are byte offsets of 4-byte
+ *      fields inside a struct of point_step bytes; off_intensity / off_rgb may be -1 (intensity 0 / no colours).
+ *      Same result as gem_add on the unpacked arrays.                                                            */
+int  gem_add_aos(gem_handle* h, const gem_frame_params* p, int n, const void* points_host, int point_step,
+                 int off_x, int off_y, int off_z, int off_intensity, int off_rgb);
+
 /* ---- batched sweeps (BASELINE config 4): for s in 0..n_sweeps-1:
  *        Mapvar_update(var_updates[s]) ; add(params[s], cloud s)
  *      with the map pose fixed for the batch.  Clouds are device-resident, concatenated:

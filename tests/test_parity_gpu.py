@@ -377,6 +377,38 @@ def test_mixed_fast_and_generic_batches(oracle_mod):
         assert_maps_match(gpu, ref)
 
 
+# ---- AoS ingest: the PCL point structs as they are --------------------------------------------------------
+def test_add_aos_equals_add_on_unpacked_arrays(oracle_mod):
+    # PointXYZRGBICT (PointXYZRGBICT.hpp:28-46): x y z pad | b g r a | covariance | intensity | travers = 32 bytes
+    pt = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("pad", "<f4"), ("b", "u1"), ("g", "u1"), ("r", "u1"), ("a", "u1"),
+                   ("covariance", "<f4"), ("intensity", "<f4"), ("travers", "<f4")])
+    assert pt.itemsize == 32
+    rng = np.random.default_rng(31)
+    n = 50_000
+    c = synth.random_cloud(33, n, 5.5)
+    pts = np.zeros(n, pt)
+    pts["x"], pts["y"], pts["z"], pts["intensity"] = c[:, 0], c[:, 1], c[:, 2], c[:, 3]
+    pts["pad"], pts["covariance"], pts["travers"] = 1.0, rng.random(n), rng.random(n)          # must be ignored
+    for k in "rgb":
+        pts[k] = rng.integers(0, 3, n) * 100
+    pts["a"] = 255                                                                            # PCL sets alpha; not a colour
+    packed = (pts["r"].astype(np.uint32) << 16) | (pts["g"].astype(np.uint32) << 8) | pts["b"].astype(np.uint32)
+    f = synth._frame_for(np.eye(4), SensorModel.velodyne())
+    gpu, ref = make_pair(oracle_mod, 100, 0.1)
+    for _ in range(2):
+        gpu.add_aos(f, pts); ref.add(f, c, rgb=packed)
+        assert_maps_match(gpu, ref, layers=("elevation", "variance", "intensity", "color_r", "color_g", "color_b"))
+    assert (ref.layer("color_r") != 0).sum() > 100
+    # XYZ-only structs (no intensity, no colour), 16-byte step
+    xyz = np.zeros((n, 4), F32); xyz[:, :3] = c[:, :3]
+    gpu2, ref2 = make_pair(oracle_mod, 100, 0.1)
+    c0 = c.copy(); c0[:, 3] = 0
+    gpu2.add_aos(f, xyz, off_intensity=-1, off_rgb=-1); ref2.add(f, c0)
+    assert_maps_match(gpu2, ref2, layers=("elevation", "variance", "intensity"))
+    with pytest.raises(Exception):
+        gpu2.add_aos(f, xyz, off_x=2)                         # misaligned field
+
+
 # ---- the HIP path against the reference's own code (no oracle in between) ---------------------------------------------
 def test_hip_path_against_the_compiled_reference(ref_mod):
     """libgem_hip (through the C ABI) vs oracle/_ref/libgem_ref.so, the reference's gpu_process.cu compiled for the CPU:
