@@ -2,8 +2,9 @@
 """Regenerates the golden fixtures from the CPU oracle (oracle/gem_oracle.c).
 
 The reference ships no tests, golden vectors or fixtures and cannot be built or imported here
-(CUDA + Eigen + ROS), so these vectors are produced by our own restatement of its semantics:
-PARITY UNPINNED by the reference; the oracle itself is pinned by tests/test_oracle_kat.py.
+(CUDA + Eigen + ROS), so these vectors are produced by our own restatement of its semantics; the restatement is pinned against the
+reference's own gpu_process.cu compiled for the CPU (tests/test_reference_compiled.py), and make_ref_golden.py records
+vectors from that compiled reference directly (ref_scene.npz).
 
     python tests/golden/make_golden.py        # rewrites c1.npz, chain.npz, digests.json
 
