@@ -811,6 +811,7 @@ int gem_get_layer(gem_handle* h, int layer, int layout, void* dst_host)
     if (layout == GEM_LAYOUT_STORAGE_ROWMAJOR) {
         GEM_HIP(h, hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, h->stream));
     } else if (layout == GEM_LAYOUT_GRIDMAP_COLMAJOR_NAN) {
+        if (layer == GEM_LAYER_LOWEST) return fail(h, GEM_ERR_INVALID, "gem_get_layer: the LOWEST layer is indexed by geographic cell, it has no grid_map layout");
         if ((rc = ensure(h, h->scratch, bytes))) return rc;
         const int is_int = layer >= GEM_LAYER_COLOR_R && layer <= GEM_LAYER_COLOR_B;
         GEM_HIP(h, launch_export_gridmap(h->stream, src, h->layers.elevation, static_cast<float*>(h->scratch.p), h->L, is_int));

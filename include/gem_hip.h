@@ -49,6 +49,8 @@ enum {
     GEM_LAYER_ROUGH = 8, GEM_LAYER_SLOPE = 9,      /* outputs of gem_map_feature (visualMap_ layers "rough", "slope", EM.cpp:44) */
     GEM_LAYER_COUNT = 10
 };
+/* GEM_LAYER_LOWEST is the reference's map_lowest: indexed by the GEOGRAPHIC cell [gx * L + gy] (GPU:430, 676-679), NOT by the
+ * circular-buffer cell like the other layers, and not shifted by gem_move; the GRIDMAP layout does not apply to it. */
 /* layouts for gem_get_layer / gem_set_layer */
 enum {
     GEM_LAYOUT_STORAGE_ROWMAJOR = 0,   /* the reference's flat [storage_x * L + storage_y] arrays (EM.cpp:98-111)   */
