@@ -75,6 +75,11 @@ SIGNATURES = {
     "gem_comm_init": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "gem_allgather_layers": (c_int, [c_void_p, c_int]),
 }
+# include/gem_hip_debug.h (tuning knobs / profiling aids, not part of the drop-in surface)
+DEBUG_SIGNATURES = {
+    "gem_debug_set": (c_int, [c_void_p, c_char_p, c_longlong]),
+    "gem_debug_fuse_stamps": (c_int, [c_void_p, c_int, c_void_p, c_int]),
+}
 
 _lib = None
 
@@ -93,7 +98,7 @@ def load(rebuild_if_stale: bool = True) -> C.CDLL:
     except Exception:
         pass
     lib = C.CDLL(str(path))
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in {**SIGNATURES, **DEBUG_SIGNATURES}.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args

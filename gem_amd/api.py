@@ -218,8 +218,12 @@ class ElevationMap:
     Fuse / Mapvar_update.  This class exposes exactly those operations plus the fused add().
     """
 
+    # knobs applied to every new map through gem_debug_set (include/gem_hip_debug.h); the tests set this to drive all code paths
+    default_debug: dict = {}
+
     def __init__(self, length: int, resolution: float, mahalanobis_threshold: float = 5.0,
-                 variance_floor: float = 1e-4, strip: tuple = (0, 0), device: int = -1, obstacle_threshold: float = 0.7):
+                 variance_floor: float = 1e-4, strip: tuple = (0, 0), device: int = -1, obstacle_threshold: float = 0.7,
+                 debug: Optional[dict] = None):
         self._lib = _lib.load()
         cfg = _lib.MapConfig(int(length), float(resolution), float(mahalanobis_threshold), float(variance_floor),
                              float(obstacle_threshold), int(strip[0]), int(strip[1]), int(device))
@@ -231,6 +235,8 @@ class ElevationMap:
         self.length = int(length)
         self.resolution = float(resolution)
         _live_maps.add(self)
+        for k, v in {**type(self).default_debug, **(debug or {})}.items():
+            self.debug_set(k, v)
 
     # -- plumbing ------------------------------------------------------------------------------
     def _check(self, rc: int, what: str) -> None:
@@ -249,6 +255,10 @@ class ElevationMap:
             self.close()
         except Exception:
             pass
+
+    def debug_set(self, key: str, value: int) -> None:
+        """Tuning / test knob (gem_debug_set, include/gem_hip_debug.h): selects between code paths that produce the same map."""
+        self._check(self._lib.gem_debug_set(self._h, key.encode(), int(value)), f"gem_debug_set({key})")
 
     def set_stream(self, hip_stream: Optional[int]) -> None:
         self._check(self._lib.gem_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None), "gem_set_stream")

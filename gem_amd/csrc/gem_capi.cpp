@@ -6,6 +6,7 @@
 // Here a handle owns persistent arenas that only ever grow, everything is enqueued on one HIP
 // stream, and nothing returns to the host unless the caller asks for it.
 #include "../../include/gem_hip.h"
+#include "../../include/gem_hip_debug.h"
 #include "gem_kernels.hpp"
 
 #include <hip/hip_runtime.h>
@@ -71,6 +72,8 @@ struct gem_handle {
     struct Deferred { bool valid = false; FuseArgs fa{}; int ts = 0, attr = 0; } deferred;
     bool defer = true;
     hipStream_t bin_stream = nullptr;
+    hipEvent_t switch_done = nullptr;   // recorded on `stream` when a pass moves its binning to `bin_stream` after passes that did not
+    bool main_reads_pb = false;         // work enqueued on `stream` since the last such switch reads the pass buffers
     bool overlap = true;
     long long overlap_min_points = 1000000;
     int dbg_sweep = 0;                  // debug stamps of the dense path: which sweep (GEM_DBG_SWEEP)
@@ -189,6 +192,7 @@ int flush_deferred(gem_handle* h)
 {
     if (!h->deferred.valid) return GEM_OK;
     h->deferred.valid = false;
+    h->main_reads_pb = true;
     Timed t(h, 1);
     GEM_HIP(h, launch_fuse(h->stream, h->deferred.fa, h->deferred.ts, h->deferred.attr, h->fuse_variant, t.events()));
     return GEM_OK;
@@ -280,15 +284,21 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     // tile size of this pass: 16x16 cells (more, lighter workgroups: better balance and latency hiding)
     // unless the [sweep][tile][unit] descriptor table would get too big, then 32x32
     int ts = h->ts;
-    if (ts == 0) {
+    {
         const long long tpr4 = (h->L + 15) / 16;
-        ts = (tpr4 * tpr4 * (long long)bpad * in.n_sweeps * (long long)sizeof(uint16_t) <= (1ll << 29)) ? 4 : 5;
+        const long long table4 = tpr4 * tpr4 * (long long)bpad * in.n_sweeps * (long long)sizeof(uint16_t);
+        if (ts == 0) ts = table4 <= (1ll << 29) ? 4 : 5;
+        // the kernel variants that maintain map_lowest exist for 16x16 tiles only: the choice is made HERE, before the tile
+        // geometry (te, tiles_per_row, T, table sizes) is derived from it
+        if (h->track_lowest) {
+            if (table4 > (16ll << 30)) return fail(h, GEM_ERR_INVALID, "lowest tracking: the pass is too large for 16x16 tiles (cut it into smaller calls)");
+            ts = 4;
+        }
     }
     const int te = 1 << ts;
     const int tiles_per_row = (h->L + te - 1) / te;
     const int T = tiles_per_row * tiles_per_row;
     h->T = T;
-    if (h->track_lowest) ts = 4;
     if (fuse_lds_bytes(ts, h->fuse_variant, attr & 3) > 160 * 1024) return fail(h, GEM_ERR_INVALID, "fuse kernel geometry exceeds the LDS");
 
     // k_bin of this pass may run on its own stream, concurrently with the k_fuse of the previous pass
@@ -307,6 +317,16 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     if (!defer) { const int rcd = flush_deferred(h); if (rcd) return rcd; }
     gem_handle::PassBuffers& pb = h->pb[(overlap || defer) ? (h->pass++ & 1u) : 0u];
     hipStream_t sbin = overlap ? h->bin_stream : h->stream;
+    if (overlap && h->main_reads_pb) {
+        // Passes that ran entirely on the handle's stream (single sweeps, k_frame, a flushed deferred fuse) read either half of
+        // the double buffer without recording a per-half event.  Before k_bin on the other stream may overwrite a half, that
+        // stream waits for everything enqueued on the handle's stream so far (one event at the switch, none per frame).
+        GEM_HIP(h, hipEventRecord(h->switch_done, h->stream));
+        GEM_HIP(h, hipStreamWaitEvent(h->bin_stream, h->switch_done, 0));
+        h->main_reads_pb = false;
+        for (auto& b : h->pb) b.fuse_recorded = false;      // covered by the wait above
+    }
+    if (!overlap) h->main_reads_pb = true;
     int rc;
     if ((rc = ensure(h, pb.rec, (size_t)B * U * sizeof(uint4)))) return rc;
     if ((rc = ensure(h, pb.srt, (size_t)B * U * sizeof(uint4) + 16))) return rc;     // sorted arena + its bump pointer (last 16 bytes)
@@ -470,14 +490,13 @@ int gem_create(const gem_map_config* cfg, gem_handle** out)
         h->row0 = cfg->strip_row0; h->row1 = cfg->strip_row0 + cfg->strip_rows;
     }
     h->fuse_variant = 12;                       // k_fuse_list geometry on 32x32 tiles: 10 = 256 threads, 11 = 512, 12 = 512 with 2048-record batches (2 per CU)
-    if (const char* s = getenv("GEM_FUSE_VARIANT")) { const int v = atoi(s); if (v >= 10 && v <= 12) h->fuse_variant = v; }
     h->ts = 0;                                  // 0: chosen per pass (run_pipeline)
-    if (const char* s = getenv("GEM_TILE_SHIFT")) { const int v = atoi(s); if (v == 4 || v == 5) h->ts = v; }
 
     auto bail = [&](const char* what, hipError_t err) { int rc = fail(nullptr, GEM_ERR_HIP, what, err); gem_destroy(h); return rc; };
     if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     h->stream = h->own_stream;
     if ((e = hipEventCreateWithFlags(&h->copy_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&h->switch_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     // (the second stream, for the bin / fuse overlap of big passes, is created by the first pass that is big enough: ROCm maps
     //  streams onto four hardware queues, and streams that share one serialise -- a handle that only ever fuses single sweeps
     //  should not take a queue from its neighbours.  Measured: a batched C4 call 263 -> 345 us with a second handle alive.)
@@ -485,10 +504,6 @@ int gem_create(const gem_map_config* cfg, gem_handle** out)
         if ((e = hipEventCreateWithFlags(&b.bin_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&b.fuse_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     }
-    if (const char* s = getenv("GEM_DEFER")) h->defer = atoi(s) != 0;
-    if (const char* s = getenv("GEM_DENSE_MIN")) h->dense_min = (unsigned)atoi(s);
-    if (const char* s = getenv("GEM_DBG_SWEEP")) h->dbg_sweep = atoi(s);
-    if (const char* s = getenv("GEM_OVERLAP")) { h->overlap = atoi(s) != 0; if (atoi(s) > 1) h->overlap_min_points = 0; }
     // one allocation for the 8 layers (gpu_process.cu:954-961 uses 8 cudaMalloc)
     void* base = nullptr;
     const size_t layer_bytes = ((size_t)h->cells * 4 + 255) & ~(size_t)255;
@@ -533,6 +548,7 @@ void gem_destroy(gem_handle* h)
     }
     if (h->bin_stream) hipStreamDestroy(h->bin_stream);
     if (h->copy_done) hipEventDestroy(h->copy_done);
+    if (h->switch_done) hipEventDestroy(h->switch_done);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -843,7 +859,8 @@ int gem_layer_device_ptr(gem_handle* h, int layer, void** out_device_ptr)
     if (!h || !out_device_ptr) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
-    { const int rcd = flush_deferred(h); if (rcd) return rcd; }   // the caller is about to read or write the layer
+    // the caller is about to read or write the layer: the pending fuse AND the queued Mapvar_update increments go first
+    { const int rcd = flush_pending(h, false); if (rcd) return rcd; }
     *out_device_ptr = layer_ptr(h, layer);
     return *out_device_ptr ? GEM_OK : fail(h, GEM_ERR_INVALID, "gem_layer_device_ptr: bad layer");
 }
@@ -971,6 +988,26 @@ int gem_get_stats(gem_handle* h, gem_stats* out, int reset)
     }
     *out = h->stats;
     if (reset) { const long long pin = h->stats.points_in; h->stats = gem_stats{}; h->stats.points_in = pin; }
+    return GEM_OK;
+}
+
+// Tuning / test knobs (include/gem_hip_debug.h; not part of the drop-in surface).  They select between code paths that all
+// produce the same map: the tests use them to drive every path with small inputs.
+int gem_debug_set(gem_handle* h, const char* key, long long value)
+{
+    if (!h || !key) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
+    const std::string k(key);
+    if (k == "fuse_variant")            { if (value < 10 || value > 12) return fail(h, GEM_ERR_INVALID, "fuse_variant: 10..12"); h->fuse_variant = (int)value; }
+    else if (k == "tile_shift")         { if (value != 0 && value != 4 && value != 5) return fail(h, GEM_ERR_INVALID, "tile_shift: 0, 4 or 5"); h->ts = (int)value; }
+    else if (k == "defer")              h->defer = value != 0;
+    else if (k == "dense_min")          h->dense_min = (unsigned)value;
+    else if (k == "dbg_sweep")          h->dbg_sweep = (int)value;
+    else if (k == "overlap")            h->overlap = value != 0;
+    else if (k == "overlap_min_points") h->overlap_min_points = value;
+    else return fail(h, GEM_ERR_INVALID, "gem_debug_set: unknown key");
     return GEM_OK;
 }
 

@@ -23,6 +23,7 @@
 
 #include <hip/hip_ext.h>
 
+#include <mutex>
 #include <type_traits>
 
 namespace gem {
@@ -1335,6 +1336,8 @@ __global__ __launch_bounds__(256) void k_map_feature(const float* __restrict__ e
         else hipLaunchKernelGGL(k, grid, block, lds, st, __VA_ARGS__);                             \
     } while (0)
 
+constexpr int kMaxDevices = 64;          // per-device launch configuration caches
+
 static inline int grid_for(long long work, int block, int cap = 2048)
 {
     long long g = (work + block - 1) / block;
@@ -1405,13 +1408,20 @@ template <int TS, int NT, int PB, bool BATCH>
 static hipError_t launch_fuse_list_b(hipStream_t st, const FuseArgs& a, int attr, LaunchEvents ev)
 {
     const size_t lds = fuse_list_lds(1 << (2 * TS), NT / 64, PB, attr);
-    static size_t configured[3] = {0, 0, 0};
-    if (lds > 64 * 1024 && lds > configured[attr]) {   // more than 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel
-        const void* fn = attr == 0 ? (const void*)k_fuse_list<TS, NT, PB, 0, BATCH> : attr == 1 ? (const void*)k_fuse_list<TS, NT, PB, 1, BATCH>
-                                                                                                   : (const void*)k_fuse_list<TS, NT, PB, 2, BATCH>;
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 64 * 1024) {   // more than 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel AND device
+        static std::mutex mu;
+        static size_t configured[kMaxDevices][3] = {};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
-        configured[attr] = lds;
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= kMaxDevices || lds > configured[dev][attr]) {
+            const void* fn = attr == 0 ? (const void*)k_fuse_list<TS, NT, PB, 0, BATCH> : attr == 1 ? (const void*)k_fuse_list<TS, NT, PB, 1, BATCH>
+                                                                                                       : (const void*)k_fuse_list<TS, NT, PB, 2, BATCH>;
+            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            if (dev >= 0 && dev < kMaxDevices) configured[dev][attr] = lds;
+        }
     }
     if (attr == 0)      GEM_LAUNCH((k_fuse_list<TS, NT, PB, 0, BATCH>), dim3((a.T + 3) & ~3), dim3(NT), lds, st, ev, a);
     else if (attr == 1) GEM_LAUNCH((k_fuse_list<TS, NT, PB, 1, BATCH>), dim3((a.T + 3) & ~3), dim3(NT), lds, st, ev, a);

@@ -1,0 +1,28 @@
+/*
+ * gem_hip_debug.h -- tuning knobs and profiling aids of libgem_hip.so.  NOT part of the drop-in boundary
+ * (include/gem_hip.h): nothing the reference's callers need is declared here.  The knobs choose between code
+ * paths that all produce the same map; the parity tests use them to drive every path with small inputs.
+ */
+#ifndef GEM_HIP_DEBUG_H
+#define GEM_HIP_DEBUG_H
+
+#include "gem_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* keys: "fuse_variant" (10..12: k_fuse_list geometry on 32x32 tiles), "tile_shift" (0 = per pass, 4, 5),
+ *       "defer" (0/1: one launch per frame for streams of single sweeps), "dense_min" (records of one sweep in one
+ *       16x16 tile above which the tile is counting-sorted), "dbg_sweep", "overlap" (0/1: binning of big passes on a
+ *       second stream), "overlap_min_points".  Returns GEM_ERR_INVALID for an unknown key or a value out of range. */
+int gem_debug_set(gem_handle* h, const char* key, long long value);
+
+/* per-tile cycle stamps of the last fuse launch ([tile][16] 64-bit counters); enable != 0 turns the stamps on for the
+ * following passes; with out != NULL copies up to max_tiles rows and returns their number */
+int gem_debug_fuse_stamps(gem_handle* h, int enable, unsigned long long* out, int max_tiles);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -21,17 +21,20 @@ def lib():
     return _lib.load()
 
 
-def declared_symbols():
-    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+def declared_symbols(header=HEADER):
+    text = re.sub(r"/\*.*?\*/", "", header.read_text(), flags=re.S)
     return sorted(set(re.findall(r"\b(gem_[a-z_0-9]+)\s*\(", text)))
 
 
-def test_library_is_in_tree_and_built_for_gfx950():
+def test_library_is_in_tree_and_built_for_gfx950(tmp_path):
     from gem_amd import build
     path = build.build()
     assert path.exists() and ROOT in path.parents
     objdump = shutil.which("llvm-objdump") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
-    out = subprocess.run([objdump, "--offloading", str(path)], capture_output=True, text=True).stdout
+    # llvm-objdump --offloading unbundles the code objects NEXT TO its input: run it on a copy outside the tree
+    copy = tmp_path / path.name
+    shutil.copy(path, copy)
+    out = subprocess.run([objdump, "--offloading", str(copy)], capture_output=True, text=True, cwd=tmp_path).stdout
     assert "gfx950" in out, out[:500]
 
 
@@ -43,6 +46,16 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, n), f"{n} declared in gem_hip.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes prototype"
     assert lib.gem_abi_version() == 4
+    dbg = declared_symbols(ROOT / "include" / "gem_hip_debug.h")         # knobs / profiling aids: exported, bound, not in gem_hip.h
+    assert dbg and not set(dbg) & set(names)
+    for n in dbg:
+        assert hasattr(lib, n) and n in _lib.DEBUG_SIGNATURES, n
+
+
+def test_the_product_reads_no_environment_variables():
+    for p in list((ROOT / "gem_amd" / "csrc").glob("*")) + [ROOT / "gem_amd" / "api.py", ROOT / "gem_amd" / "_lib.py", ROOT / "gem_amd" / "tiling.py"]:
+        text = p.read_text(errors="ignore")
+        assert "getenv" not in text and "os.environ" not in text, p
 
 
 def test_struct_layouts_match_the_header(tmp_path):

@@ -348,8 +348,7 @@ def test_torch_exchange_aliases_device_layers(oracle_mod):
 # ---- kernel variants: every fuse kernel / tile size must give the same bits ---------------------------------------------
 @pytest.mark.parametrize("variant,ts", [(12, 4), (12, 5), (11, 5), (10, 5)])
 def test_fuse_kernel_variants(oracle_mod, monkeypatch, variant, ts):
-    monkeypatch.setenv("GEM_FUSE_VARIANT", str(variant))
-    monkeypatch.setenv("GEM_TILE_SHIFT", str(ts))
+    monkeypatch.setattr(ElevationMap, "default_debug", {"fuse_variant": variant, "tile_shift": ts})
     wl = synth.config_c4(n_sweeps=2)
     gpu, ref = make_pair(oracle_mod, wl.length, wl.resolution)
     for k in range(2):                                  # LiDAR: the rank-row fast path
@@ -456,7 +455,7 @@ def _walls(rng, m_list, L):
 def test_lowest_tracking_and_raytracing(oracle_mod, ref_mod, monkeypatch, L, res, dense_min):
     """gem_add with lowest tracking + gem_raytracing against the oracle AND against the reference's own code
     (Process_points + Fuse + Raytracing of the compiled gpu_process.cu); dense_min = 0 sends every tile down the dense path."""
-    monkeypatch.setenv("GEM_DENSE_MIN", str(dense_min))
+    monkeypatch.setattr(ElevationMap, "default_debug", {"dense_min": dense_min})
     gpu, ora, ref = ElevationMap(L, res), oracle_mod.OracleMap(L, res), ref_mod.RefMap(L, res)
     gpu.set_lowest_tracking(True)
     rng = np.random.default_rng(L)
@@ -529,11 +528,11 @@ def test_lowest_tracking_batched_and_off(oracle_mod):
 # ---- dense tiles (k_fuse_list hands the tile to its second copy, which counting-sorts the sweep's records by cell) ----------
 @pytest.mark.parametrize("dense_min", [0, 300])
 def test_dense_tile_path(oracle_mod, monkeypatch, dense_min):
-    """GEM_DENSE_MIN lowers the records-per-(tile, sweep) threshold of the dense path, so that ordinary clouds take it:
+    """The dense_min knob (gem_debug_set) lowers the records-per-(tile, sweep) threshold of the dense path, so that ordinary clouds take it:
     mixed dense / LiDAR tiles, several sweeps per tile with variance increments in between, colour attributes,
     the strip clipping, a single cell fed by a whole sweep."""
     import torch
-    monkeypatch.setenv("GEM_DENSE_MIN", str(dense_min))
+    monkeypatch.setattr(ElevationMap, "default_debug", {"dense_min": dense_min})
     f = synth._frame_for(np.eye(4), SensorModel.velodyne())
     # (a) collisions + attributes, twice (the second call fuses into non-empty cells)
     gpu, ref = make_pair(oracle_mod, 100, 0.1)
@@ -594,7 +593,7 @@ def test_batch_without_increments_accumulates_across_sweeps(oracle_mod, monkeypa
     batches), tiles that turn dense in the middle of a collected batch, an empty sweep, a tail that is flushed at the end of
     the pass -- and the same call with per-sweep counting on, which switches the accumulation off."""
     import torch
-    monkeypatch.setenv("GEM_DENSE_MIN", str(dense_min))
+    monkeypatch.setattr(ElevationMap, "default_debug", {"dense_min": dense_min})
     L, res = 96, 0.1
     rng = np.random.default_rng(21)
     f0 = synth._frame_for(synth.pose_matrix(0.1, -0.2, 0.0, yaw=0.3), SensorModel.velodyne())
@@ -641,7 +640,7 @@ def test_batch_tail_descriptor_crossing_a_batch_boundary(oracle_mod, monkeypatch
     # regression: a tile whose last descriptor merely extends past a multiple of the batch quantum
     # (an empty trailing batch) -- met by sweep 7 of the C4 series with 2048-record batches
     import torch
-    monkeypatch.setenv("GEM_FUSE_VARIANT", "12"); monkeypatch.setenv("GEM_TILE_SHIFT", "5")
+    monkeypatch.setattr(ElevationMap, "default_debug", {"fuse_variant": 12, "tile_shift": 5})
     wl = synth.config_c4(n_sweeps=8)
     gpu, ref = make_pair(oracle_mod, wl.length, wl.resolution)
     off = np.concatenate([[0], np.cumsum([c.shape[0] for c in wl.clouds])])

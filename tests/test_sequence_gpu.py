@@ -21,7 +21,7 @@ def test_random_call_sequence(oracle_mod, monkeypatch, seed):
     rng = np.random.default_rng(seed)
     L, res = (96, 0.1) if seed % 2 else (75, 0.2)
     if seed >= 5:
-        monkeypatch.setenv("GEM_DENSE_MIN", "40")          # most tiles of these small clouds take the dense (counting-sort) path
+        monkeypatch.setattr(ElevationMap, "default_debug", {"dense_min": 40})          # most tiles of these small clouds take the dense (counting-sort) path
     gpu, ref = ElevationMap(L, res), oracle_mod.OracleMap(L, res)
     tracking = False                                        # lowest scan points kept by the fuse kernels (for raytracing)
     frame = synth._frame_for(synth.pose_matrix(0.1, -0.2, 0.0, yaw=0.3), SensorModel.velodyne())

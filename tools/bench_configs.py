@@ -60,7 +60,10 @@ def main():
     ap.add_argument("--reps", type=int, default=50)
     ap.add_argument("--configs", default="c2,c3,c4,c5")
     ap.add_argument("--c5-points", type=int, default=10_000_000)
+    ap.add_argument("--debug", default="", help="gem_debug_set knobs applied to every map, e.g. overlap=0,dense_min=300")
     args = ap.parse_args()
+    if args.debug:
+        ElevationMap.default_debug = {k: int(v) for k, v in (kv.split("=") for kv in args.debug.split(","))}
     want = args.configs.split(",")
     dev = torch.device("cuda", 0)
 

@@ -11,8 +11,6 @@ from gem_amd import ElevationMap, synth, _lib
 wl = synth.config_c4(n_sweeps=4)
 m = ElevationMap(wl.length, wl.resolution)
 lib = _lib.load()
-lib.gem_debug_fuse_stamps.restype = C.c_int
-lib.gem_debug_fuse_stamps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
 d = [torch.from_numpy(c).cuda() for c in wl.clouds]
 for k in range(3):
     m.add(wl.frames[k], d[k])
@@ -33,7 +31,7 @@ else:
 T = 4096
 buf = np.zeros((T, 16), np.uint64)
 n = lib.gem_debug_fuse_stamps(m._h, 0, buf.ctypes.data_as(C.c_void_p), T)
-if len(sys.argv) > 1 and sys.argv[1] == "c3":          # stamps 8..13 of a tile: the dense path of sweep GEM_DBG_SWEEP
+if len(sys.argv) > 1 and sys.argv[1] == "c3":          # stamps 8..13 of a tile: the dense path of sweep `dbg_sweep` (gem_debug_set)
     d = buf[:n, 8:14].astype(np.int64)
     dn = d[d[:, 0] > 0]
     dur = dn[:, 5] - dn[:, 0]
