@@ -436,6 +436,18 @@ int gemo_add(gemo_map* m, const gemo_frame* f, int n, const float* xyzi, const u
 }
 
 
+/* the single-point pieces, for the all-core form in gem_oracle_mt.c (same code, other loop structure) */
+int gemo_process_one(const gemo_map* m, const gemo_frame* f, float x, float y, float z, int orig,
+                     int* map_index, float* var, float* xt, float* yt, float* zt)
+{
+    return process_one(m, f, x, y, z, orig, map_index, var, xt, yt, zt);
+}
+
+void gemo_fuse_one(gemo_map* m, int c, float h, float v, int r, int g, int b, float inten)
+{
+    fuse_one(m, c, h, v, r, g, b, inten);
+}
+
 /* GPU:1195-1202 (G_update_mapheight): elevation += dz on the cells that hold one */
 static void update_map_height(gemo_map* m, float dz)
 {

@@ -106,6 +106,12 @@ void gemo_mapvar_update(gemo_map* m, float var_update);
 int  gemo_add(gemo_map* m, const gemo_frame* f, int n, const float* xyzi, const unsigned* rgb,
               const int* orig_index, long long counts[2]);
 
+/* The all-core form (gem_oracle_mt.c): for every sweep, Mapvar_update(var_updates[s]) (if given) then add(frames[s],
+ * cloud s = xyzi + 4 * offsets[s]), with the CELLS partitioned into row strips, one per thread, each thread scanning the sweep's
+ * index array in input order.  Bit-identical to the sequential calls (no colours).  Returns accepted points, -1 on failure. */
+long long gemo_add_batch_mt(gemo_map* m, int n_sweeps, const gemo_frame* frames, const float* xyzi, const long long* offsets,
+                            const float* var_updates, int nthreads);
+
 /* GPU:1215-1233 / 1235-1254 with G_update_mapheight GPU:1195-1202: loop-closure re-anchoring of the map. */
 void gemo_map_optmove(gemo_map* m, const float opt_p[2], float height_update, float out_aligned[2]);
 void gemo_map_closeloop(gemo_map* m, const float update_position[2], float height_update);

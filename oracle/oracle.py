@@ -40,7 +40,7 @@ class OMotion(C.Structure):
 
 def build(force: bool = False) -> Path:
     srcs = [HERE / "gem_oracle.c", HERE / "gem_oracle_motion.c", HERE / "gem_oracle_feature.c", HERE / "gem_oracle_raytrace.c",
-            HERE / "gem_oracle.h"]
+            HERE / "gem_oracle_mt.c", HERE / "gem_oracle.h"]
     if force or not LIB.exists() or any(s.stat().st_mtime > LIB.stat().st_mtime for s in srcs):
         subprocess.run(["make", "-C", str(HERE), "-B" if force else "-s", "libgem_oracle.so"], check=True,
                        capture_output=True)
@@ -72,6 +72,8 @@ def lib() -> C.CDLL:
         l.gemo_set_obstacle_threshold.argtypes = [POINTER(OMap), c_float]
         l.gemo_add.restype = c_int
         l.gemo_add.argtypes = [POINTER(OMap), POINTER(OFrame), c_int, c_void_p, c_void_p, c_void_p, POINTER(c_longlong)]
+        l.gemo_add_batch_mt.restype = c_longlong
+        l.gemo_add_batch_mt.argtypes = [POINTER(OMap), c_int, POINTER(OFrame), c_void_p, POINTER(c_longlong), c_void_p, c_int]
         l.gemo_motion_init.argtypes = [POINTER(OMotion), c_double]
         l.gemo_motion_update.restype = c_double
         l.gemo_motion_update.argtypes = [POINTER(OMotion)] + [POINTER(c_double)] * 4
@@ -158,6 +160,21 @@ class OracleMap:
         p = frame.to_struct(OFrame)
         self._l.gemo_add(self._m, C.byref(p), a.shape[0], _vp(a), _vp(r), _vp(o), counts)
         self.last_counts = (int(counts[0]), int(counts[1]))
+
+    def add_batch_mt(self, frames, xyzi, offsets, var_updates=None, nthreads: int = 0) -> int:
+        """All-core form (gem_oracle_mt.c): for s: mapvar_update(var_updates[s]); add(frames[s], xyzi[offsets[s]:offsets[s+1]]),
+        cells partitioned into row strips over `nthreads` threads (0 = all host cores).  Same bits as the sequential calls."""
+        import os
+        ns = len(frames)
+        fr = (OFrame * ns)(*[f.to_struct(OFrame) for f in frames])
+        a = np.ascontiguousarray(xyzi, np.float32).reshape(-1, 4)
+        off = (c_longlong * (ns + 1))(*[int(v) for v in offsets])
+        vu = None if var_updates is None else np.ascontiguousarray(var_updates, np.float32)
+        nt = int(nthreads) if nthreads and nthreads > 0 else (os.cpu_count() or 1)
+        acc = self._l.gemo_add_batch_mt(self._m, ns, fr, _vp(a), off, _vp(vu), nt)
+        if acc < 0:
+            raise RuntimeError("gemo_add_batch_mt failed (threads / memory)")
+        return int(acc)
 
     def mapvar_update(self, u: float):
         self._l.gemo_mapvar_update(self._m, c_float(u))

@@ -12,8 +12,9 @@ vectors from that compiled reference directly (ref_scene.npz).
   chain.npz    a 600-point single-cell chain + collisions case: inputs and outputs
   feature.npz  a 48 x 48 terrain (slopes, a step, holes) after a Move: elevation in, rough / slope / traver out
                (the traversability stage, gemo_map_feature)
-  digests.json SHA-256 of the oracle's layers for configs C2 / C3 / C4(4 sweeps) and of the input
-               clouds (detects drift of the seeded generators)
+  digests.json SHA-256 of the oracle's layers for configs C2 / C3 / C4(4 sweeps), for the FULL-SIZE configurations that
+               bench.py times (C4: 32 sweeps batched; C2 stream of 16 sweeps; C5: 10^7 points -> 2400^2, whole map and
+               the eight row strips) and of the input clouds (detects drift of the seeded generators)
 """
 import hashlib
 import json
@@ -98,6 +99,26 @@ def main():
     for k in range(4):
         mm.mapvar_update(wl.var_updates[k]); mm.add(wl.frames[k], wl.clouds[k])
     digests["c4_4sweeps"] = {"cloud": sha(np.concatenate(wl.clouds)), "elevation": sha(mm.layer("elevation")), "variance": sha(mm.layer("variance"))}
+    # ---- the configurations bench.py TIMES, at full size (BASELINE configs[3] and [4]) ------------------------------
+    wl = synth.config_c4(n_sweeps=32)                       # one batched call: 32 sweeps, a variance increment before each
+    mm = oracle.OracleMap(wl.length, wl.resolution)
+    off = np.concatenate([[0], np.cumsum([c.shape[0] for c in wl.clouds])])
+    mm.add_batch_mt(wl.frames, np.concatenate(wl.clouds), off, wl.var_updates)
+    digests["c4_32"] = {"cloud": sha(np.concatenate(wl.clouds)), "elevation": sha(mm.layer("elevation")), "variance": sha(mm.layer("variance"))}
+    mm.add_batch_mt(wl.frames, np.concatenate(wl.clouds), off, wl.var_updates)          # the same batch again, into the populated map
+    digests["c4_32_twice"] = {"elevation": sha(mm.layer("elevation")), "variance": sha(mm.layer("variance"))}
+    wl = synth.config_c4(n_sweeps=8, seed0=100)             # the stream bench.py cycles through: 8 sweeps, two rounds, no increments
+    mm = oracle.OracleMap(wl.length, wl.resolution)
+    for k in range(16):
+        mm.add(wl.frames[k % 8], wl.clouds[k % 8])
+    digests["c2_stream16"] = {"cloud": sha(np.concatenate(wl.clouds)), "elevation": sha(mm.layer("elevation")), "variance": sha(mm.layer("variance"))}
+    wl = synth.config_c5()                                  # 10^7 points -> 2400 x 2400, 77 sweeps with their own frames, no increments
+    mm = oracle.OracleMap(wl.length, wl.resolution)
+    off = np.concatenate([[0], np.cumsum([c.shape[0] for c in wl.clouds])])
+    mm.add_batch_mt(wl.frames, np.concatenate(wl.clouds), off, None)
+    digests["c5_full"] = {"cloud": sha(np.concatenate(wl.clouds)), "elevation": sha(mm.layer("elevation")), "variance": sha(mm.layer("variance")),
+                          "strips": [{"elevation": sha(mm.layer("elevation")[r * 300:(r + 1) * 300]), "variance": sha(mm.layer("variance")[r * 300:(r + 1) * 300])}
+                                     for r in range(8)]}
     (HERE / "digests.json").write_text(json.dumps(digests, indent=1) + "\n")
     print(json.dumps(digests, indent=1))
 

@@ -307,3 +307,29 @@ def test_splitting_a_fuse_call_is_exact(oracle_mod):
         b.fuse(idx[lo:hi], h[lo:hi], v[lo:hi])
     assert np.array_equal(a.layer("elevation"), b.layer("elevation"))
     assert np.array_equal(a.layer("variance"), b.layer("variance"))
+
+
+def test_all_core_oracle_equals_the_sequential_one(oracle_mod):
+    """gemo_add_batch_mt (cells partitioned into row strips, every thread scans the index array in order) against the
+    sequential mapvar_update + add calls: every layer bit for bit, for thread counts that do and do not divide L."""
+    from gem_amd import synth
+    wl = synth.config_c4(n_sweeps=3)
+    clouds = [c[:40_000] for c in wl.clouds]
+    off = np.concatenate([[0], np.cumsum([c.shape[0] for c in clouds])])
+    seq = oracle_mod.OracleMap(wl.length, wl.resolution)
+    seq.move([0.4, -0.3, 0.0])
+    acc = 0
+    for k in range(3):
+        seq.mapvar_update(wl.var_updates[k]); seq.add(wl.frames[k], clouds[k]); acc += seq.last_counts[0]
+    for nt in (1, 7, 16):
+        mt = oracle_mod.OracleMap(wl.length, wl.resolution)
+        mt.move([0.4, -0.3, 0.0])
+        assert mt.add_batch_mt(wl.frames, np.concatenate(clouds), off, wl.var_updates, nt) == acc
+        for name in ("elevation", "variance", "lowest", "intensity"):
+            assert np.array_equal(mt.layer(name), seq.layer(name)), (nt, name)
+    mt = oracle_mod.OracleMap(wl.length, wl.resolution)          # without increments
+    seq = oracle_mod.OracleMap(wl.length, wl.resolution)
+    mt.add_batch_mt(wl.frames, np.concatenate(clouds), off, None, 5)
+    for k in range(3):
+        seq.add(wl.frames[k], clouds[k])
+    assert np.array_equal(mt.layer("variance"), seq.layer("variance")) and np.array_equal(mt.layer("elevation"), seq.layer("elevation"))
