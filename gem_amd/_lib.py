@@ -39,7 +39,8 @@ class FrameParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("points_in", c_longlong), ("points_binned", c_longlong), ("cells_touched", c_longlong),
                 ("ms_bin", c_float), ("ms_fuse", c_float), ("launches_bin", c_int), ("launches_fuse", c_int),
-                ("ms_frame", c_float), ("launches_frame", c_int)]
+                ("ms_frame", c_float), ("launches_frame", c_int),
+                ("ms_sort", c_float * 6), ("launches_sort", c_int), ("ms_walk", c_float), ("launches_walk", c_int)]
 
 
 # every symbol include/gem_hip.h declares: (restype, argtypes)

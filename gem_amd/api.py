@@ -220,6 +220,7 @@ class ElevationMap:
 
     # knobs applied to every new map through gem_debug_set (include/gem_hip_debug.h); the tests set this to drive all code paths
     default_debug: dict = {}
+    base_debug: dict = {}              # applied before default_debug (the GPU tests run every case on both pipelines through this)
 
     def __init__(self, length: int, resolution: float, mahalanobis_threshold: float = 5.0,
                  variance_floor: float = 1e-4, strip: tuple = (0, 0), device: int = -1, obstacle_threshold: float = 0.7,
@@ -235,7 +236,7 @@ class ElevationMap:
         self.length = int(length)
         self.resolution = float(resolution)
         _live_maps.add(self)
-        for k, v in {**type(self).default_debug, **(debug or {})}.items():
+        for k, v in {**type(self).base_debug, **type(self).default_debug, **(debug or {})}.items():
             self.debug_set(k, v)
 
     # -- plumbing ------------------------------------------------------------------------------
@@ -417,7 +418,7 @@ class ElevationMap:
     def stats(self, reset: bool = False) -> dict:
         s = _lib.Stats()
         self._check(self._lib.gem_get_stats(self._h, C.byref(s), int(reset)), "gem_get_stats")
-        return {k: getattr(s, k) for k, _ in _lib.Stats._fields_}
+        return {k: (list(getattr(s, k)) if k == "ms_sort" else getattr(s, k)) for k, _ in _lib.Stats._fields_}
 
     # -- multi-GPU ------------------------------------------------------------------------------------------
     @staticmethod

@@ -16,8 +16,8 @@ CSRC = ROOT / "csrc"
 LIBDIR = ROOT / "lib"
 LIB = LIBDIR / "libgem_hip.so"
 
-SOURCES = [CSRC / "gem_kernels.hip", CSRC / "gem_capi.cpp"]
-HEADERS = [CSRC / "gem_device.hpp", CSRC / "gem_kernels.hpp", ROOT.parent / "include" / "gem_hip.h"]
+SOURCES = [CSRC / "gem_kernels.hip", CSRC / "gem_sort.hip", CSRC / "gem_capi.cpp"]
+HEADERS = [CSRC / "gem_device.hpp", CSRC / "gem_kernels.hpp", CSRC / "gem_wave.hpp", ROOT.parent / "include" / "gem_hip_debug.h", ROOT.parent / "include" / "gem_hip.h"]
 
 # -ffp-contract=off: cell indices must be bit-exact with the reference arithmetic, so no product+sum
 # may be contracted into an FMA (see csrc/gem_device.hpp).  hipcc's default IEEE divide/sqrt stay on.

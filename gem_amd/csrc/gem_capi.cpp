@@ -56,6 +56,7 @@ struct gem_handle {
     // pass p runs on `stream` (binning does not depend on the map, only on the cloud and the pose).
     struct PassBuffers {
         Arena rec, srt, seg, flag, gflag;   // records, descriptor table, touched stamps per (tile, sweep) and per (sweep, tile, 32 units)
+        Arena s_hv1, s_hv2, s_key1, s_key2, s_src1, s_src2, s_cnt1, s_cnt2, s_misc;   // the sorted pipeline of big passes (gem_sort.hip)
         Arena tables;                  // batched-call tables (frames, sweep_unit0, sweep_first, var_updates)
         void* host_tables = nullptr;   // their pinned staging copy: the upload is asynchronous, `tables_done` guards its reuse
         size_t host_cap = 0;
@@ -76,6 +77,8 @@ struct gem_handle {
     bool main_reads_pb = false;         // work enqueued on `stream` since the last such switch reads the pass buffers
     bool overlap = true;
     long long overlap_min_points = 1000000;
+    bool sort_path = true;              // passes of at least sort_min_points points run the sorted pipeline (gem_sort.hip)
+    long long sort_min_points = 200000;
     int dbg_sweep = 0;                  // debug stamps of the dense path: which sweep (GEM_DBG_SWEEP)
     bool track_lowest = false;          // also maintain map_lowest in the fuse kernels (gem_set_lowest_tracking, for gem_raytracing)
     unsigned dense_min = 2048;          // records of one sweep in one 16x16 tile above which the tile is counting-sorted (k_fuse_list, dense path)
@@ -180,7 +183,9 @@ void fold_events(gem_handle* h)
         if (hipEventSynchronize(ep.b) == hipSuccess && hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
             if (ep.kind == 0)      { h->stats.ms_bin += ms; h->stats.launches_bin++; }
             else if (ep.kind == 1) { h->stats.ms_fuse += ms; h->stats.launches_fuse++; }
-            else                   { h->stats.ms_frame += ms; h->stats.launches_frame++; }
+            else if (ep.kind == 2) { h->stats.ms_frame += ms; h->stats.launches_frame++; }
+            else if (ep.kind == 9) { h->stats.ms_walk += ms; h->stats.launches_walk++; }
+            else                   { h->stats.ms_sort[ep.kind - 3] += ms; if (ep.kind == 3) h->stats.launches_sort++; }
         }
         h->pool.push_back(ep);
     }
@@ -233,8 +238,169 @@ struct PassInput {
 constexpr int       kUnit = 64;                      // points per unit (one wave of k_bin_wave)
 constexpr long long kSweepPoints = 2048ll * kUnit;   // a single cloud longer than this is processed as a batch of sweeps of this size
 
+static int ceil_log2(int v) { int b = 0; while ((1 << b) < v) ++b; return b; }
+
+// the tile geometry of the sorted pipeline for this map, and whether a pass of `n_sweeps` sweeps fits its record key
+struct SortGeometry { int tiles_per_row, T, tile_bits, sweep_shift; bool ok; };
+SortGeometry sort_geometry(const gem_handle* h, int n_sweeps)
+{
+    SortGeometry g{};
+    g.tiles_per_row = (h->L + 31) / 32;
+    g.T = g.tiles_per_row * g.tiles_per_row;
+    g.tile_bits = std::max(1, ceil_log2(g.T));
+    g.sweep_shift = 10 + g.tile_bits;
+    const long long max_sweeps = std::min<long long>(512, 1ll << (32 - g.sweep_shift));
+    g.ok = g.T <= kSortMaxTiles && n_sweeps <= max_sweeps;
+    return g;
+}
+
+// One pass through the sorted pipeline (gem_sort.hip): six sort kernels on the binning stream, k_fuse_walk on the handle's.
+int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGeometry& geo)
+{
+    const bool batched = in.n_sweeps > 1;
+    std::vector<int> chunk0(in.n_sweeps + 1, 0);
+    for (int s = 0; s < in.n_sweeps; ++s) {
+        const long long cnt = batched ? in.offsets[s + 1] - in.offsets[s] : in.n;
+        chunk0[s + 1] = chunk0[s] + (int)((cnt + kSortChunk1 - 1) / kSortChunk1);
+    }
+    const int NC1 = chunk0[in.n_sweeps];
+    const bool dense = h->n_pending > 0 || h->floor_dirty || (batched && in.var_updates != nullptr);
+    const bool with_src = (attr & 3) != 0;
+    const int T = geo.T;
+    h->T = T;
+
+    bool overlap = h->overlap && in.n >= h->overlap_min_points && h->stream == h->own_stream && !h->counting;
+    if (overlap && !h->bin_stream && hipStreamCreateWithFlags(&h->bin_stream, hipStreamNonBlocking) != hipSuccess) {
+        h->bin_stream = nullptr; overlap = false; (void)hipGetLastError();
+    }
+    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
+    gem_handle::PassBuffers& pb = h->pb[overlap ? (h->pass++ & 1u) : 0u];
+    hipStream_t sbin = overlap ? h->bin_stream : h->stream;
+    if (overlap && h->main_reads_pb) {                   // see run_pipeline
+        GEM_HIP(h, hipEventRecord(h->switch_done, h->stream));
+        GEM_HIP(h, hipStreamWaitEvent(h->bin_stream, h->switch_done, 0));
+        h->main_reads_pb = false;
+        for (auto& b : h->pb) b.fuse_recorded = false;
+    }
+    if (!overlap) h->main_reads_pb = true;
+
+    const int nt2 = sort_pass2_threads(T);
+    const long long nc2max = (in.n + (long long)nt2 * 8 - 1) / ((long long)nt2 * 8);
+    const size_t N = (size_t)in.n;
+    int rc;
+    if ((rc = ensure(h, pb.s_hv1, N * 8 + 16))) return rc;
+    if ((rc = ensure(h, pb.s_hv2, N * 8 + 16))) return rc;
+    if ((rc = ensure(h, pb.s_key1, N * 4 + 16))) return rc;
+    if ((rc = ensure(h, pb.s_key2, N * 4 + 16))) return rc;
+    if (with_src) {
+        if ((rc = ensure(h, pb.s_src1, N * 4 + 16))) return rc;
+        if ((rc = ensure(h, pb.s_src2, N * 4 + 16))) return rc;
+    }
+    if ((rc = ensure(h, pb.s_cnt1, (size_t)NC1 * 1024 * 4))) return rc;
+    if ((rc = ensure(h, pb.s_cnt2, (size_t)nc2max * T * 4 + 16))) return rc;
+    const size_t o_tot1 = 0, o_tot2 = 1024 * 4, o_total = o_tot2 + (size_t)T * 4, o_tbase = (o_total + 4 + 15) & ~(size_t)15;
+    if ((rc = ensure(h, pb.s_misc, o_tbase + ((size_t)T + 1) * 4))) return rc;
+    // the walk of pass p-2 has read these buffers (host-side wait, see run_pipeline)
+    if (overlap && pb.fuse_recorded) GEM_HIP(h, hipEventSynchronize(pb.fuse_done));
+
+    SortArgs sa{};
+    WalkArgs wa{};
+    if (batched) {
+        // tables: frames | chunk0 | first | var_updates
+        const size_t o_frames = 0;
+        const size_t o_chunk0 = o_frames + sizeof(FrameConst) * in.n_sweeps;
+        const size_t o_first = (o_chunk0 + sizeof(int) * (in.n_sweeps + 1) + 15) & ~(size_t)15;
+        const size_t o_var = o_first + sizeof(long long) * (in.n_sweeps + 1);
+        const size_t total = o_var + sizeof(float) * in.n_sweeps;
+        if ((rc = ensure(h, pb.tables, total))) return rc;
+        if (total > pb.host_cap) {
+            if (pb.tables_recorded) GEM_HIP(h, hipEventSynchronize(pb.tables_done));
+            if (pb.host_tables) GEM_HIP(h, hipHostFree(pb.host_tables));
+            pb.host_tables = nullptr; pb.host_cap = 0;
+            GEM_HIP(h, hipHostMalloc(&pb.host_tables, total * 2, hipHostMallocDefault));
+            pb.host_cap = total * 2;
+        }
+        if (!pb.tables_done) GEM_HIP(h, hipEventCreateWithFlags(&pb.tables_done, hipEventDisableTiming));
+        if (pb.tables_recorded) GEM_HIP(h, hipEventSynchronize(pb.tables_done));     // the previous upload from this buffer has been read
+        unsigned char* host = static_cast<unsigned char*>(pb.host_tables);
+        memset(host, 0, total);
+        for (int s = 0; s < in.n_sweeps; ++s) fill_frame(h, &in.params[s], reinterpret_cast<FrameConst*>(host + o_frames)[s]);
+        memcpy(host + o_chunk0, chunk0.data(), sizeof(int) * (in.n_sweeps + 1));
+        memcpy(host + o_first, in.offsets, sizeof(long long) * (in.n_sweeps + 1));
+        if (in.var_updates) memcpy(host + o_var, in.var_updates, sizeof(float) * in.n_sweeps);
+        GEM_HIP(h, hipMemcpyAsync(pb.tables.p, host, total, hipMemcpyHostToDevice, sbin));
+        GEM_HIP(h, hipEventRecord(pb.tables_done, sbin)); pb.tables_recorded = true;
+        unsigned char* d = static_cast<unsigned char*>(pb.tables.p);
+        sa.frames = reinterpret_cast<const FrameConst*>(d + o_frames);
+        sa.sweep_chunk0 = reinterpret_cast<const int*>(d + o_chunk0);
+        sa.sweep_first = reinterpret_cast<const long long*>(d + o_first);
+        sa.sweep_orig0 = nullptr;
+        wa.var_updates = in.var_updates ? reinterpret_cast<const float*>(d + o_var) : nullptr;
+    } else {
+        fill_frame(h, in.src == 0 ? in.params : nullptr, sa.frame0);
+    }
+    sa.n_sweeps = in.n_sweeps; sa.n = in.n;
+    sa.xyzi = in.xyzi; sa.rgb = in.rgb; sa.orig = in.orig;
+    sa.f_index = in.f_index; sa.f_height = in.f_height; sa.f_var = in.f_var;
+    sa.f_R = in.f_R; sa.f_G = in.f_G; sa.f_B = in.f_B; sa.f_I = in.f_I;
+    sa.keep_sentinel = h->track_lowest ? 1 : 0;
+    sa.tiles_per_row = geo.tiles_per_row; sa.T = T;
+    sa.cell_bits = 10; sa.tile_bits = geo.tile_bits; sa.sweep_shift = geo.sweep_shift; sa.tile_mask = (1u << geo.tile_bits) - 1u;
+    sa.n_chunks1 = NC1;
+    unsigned char* misc = static_cast<unsigned char*>(pb.s_misc.p);
+    sa.cnt1 = static_cast<uint32_t*>(pb.s_cnt1.p); sa.tot1 = reinterpret_cast<uint32_t*>(misc + o_tot1);
+    sa.cnt2 = static_cast<uint32_t*>(pb.s_cnt2.p); sa.tot2 = reinterpret_cast<uint32_t*>(misc + o_tot2);
+    sa.total = reinterpret_cast<uint32_t*>(misc + o_total); sa.tile_base = reinterpret_cast<uint32_t*>(misc + o_tbase);
+    sa.hv1 = static_cast<uint2*>(pb.s_hv1.p); sa.hv2 = static_cast<uint2*>(pb.s_hv2.p);
+    sa.key1 = static_cast<uint32_t*>(pb.s_key1.p); sa.key2 = static_cast<uint32_t*>(pb.s_key2.p);
+    sa.src1 = with_src ? static_cast<uint32_t*>(pb.s_src1.p) : nullptr; sa.src2 = with_src ? static_cast<uint32_t*>(pb.s_src2.p) : nullptr;
+    sa.counters = h->counting ? h->d_counters : nullptr;
+
+    wa.hv = sa.hv2; wa.key = sa.key2; wa.src = sa.src2; wa.tile_base = sa.tile_base;
+    wa.T = T; wa.tiles_per_row = geo.tiles_per_row; wa.L = h->L; wa.row0 = h->row0; wa.row1 = h->row1;
+    wa.sweep_shift = geo.sweep_shift; wa.n_sweeps = in.n_sweeps;
+    wa.mahal = h->cfg.mahalanobis_threshold; wa.var_floor = h->cfg.variance_floor;
+    wa.dense = dense ? 1 : 0;
+    wa.n_pending = h->n_pending;
+    for (int i = 0; i < kMaxPending; ++i) wa.pending[i] = h->pending[i];
+    wa.elevation = h->layers.elevation; wa.variance = h->layers.variance; wa.lowest = h->layers.lowest;
+    wa.start0 = h->start[0]; wa.start1 = h->start[1];
+    wa.intensity = h->layers.intensity; wa.colorR = h->layers.colorR; wa.colorG = h->layers.colorG; wa.colorB = h->layers.colorB;
+    wa.xyzi = in.xyzi; wa.rgb = in.rgb; wa.f_R = in.f_R; wa.f_G = in.f_G; wa.f_B = in.f_B; wa.f_I = in.f_I;
+    wa.counters = sa.counters;
+    wa.count_per_pass = batched ? 0 : 1;
+
+    if (h->counting) GEM_HIP(h, hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
+    {
+        Timed t0(h, 3), t1(h, 4), t2(h, 5), t3(h, 6), t4(h, 7), t5(h, 8);
+        const LaunchEvents ev[6] = {t0.events(), t1.events(), t2.events(), t3.events(), t4.events(), t5.events()};
+        GEM_HIP(h, launch_sort(sbin, sa, in.src, with_src, ev));
+    }
+    if (overlap) {
+        GEM_HIP(h, hipEventRecord(pb.bin_done, sbin));
+        GEM_HIP(h, hipStreamWaitEvent(h->stream, pb.bin_done, 0));
+    }
+    { Timed t(h, 9); GEM_HIP(h, launch_walk(h->stream, wa, attr, t.events())); }
+    if (overlap) { GEM_HIP(h, hipEventRecord(pb.fuse_done, h->stream)); pb.fuse_recorded = true; }
+    h->n_pending = 0;
+    h->floor_dirty = false;
+    h->stats.points_in = in.n;
+    return GEM_OK;
+}
+
 int run_pipeline(gem_handle* h, const PassInput& in0)
 {
+    // Big passes (batches of sweeps, aggregated clouds, depth images) go through the sorted pipeline: a global two-digit counting
+    // sort of the in-map points by (tile, cell), then one walk per cell (gem_sort.hip).  Small ones -- a single LiDAR sweep -- keep
+    // the tile pipeline below, whose one or two launches cost less than the sort's seven.
+    if (h->sort_path && in0.n >= h->sort_min_points && in0.n < (1ll << 31)) {
+        int attr = 0;
+        if (in0.src == 0 && in0.rgb) attr = 1;
+        if (in0.src == 1 && in0.f_R && in0.f_G && in0.f_B && in0.f_I) attr = 2;
+        if (h->track_lowest) attr |= 4;
+        const SortGeometry geo = sort_geometry(h, in0.n_sweeps);
+        if (geo.ok) return run_sort_pipeline(h, in0, attr, geo);
+    }
     // A big single cloud becomes a batch of sweeps with one frame: every tile then only reads the descriptor
     // rows of the sweeps that reach it (flag[tile][sweep]) instead of one row over all units.  The
     // recurrence is unchanged: the per-sweep variance floor is idempotent with the floor at the start of every
@@ -540,7 +706,8 @@ void gem_destroy(gem_handle* h)
     if (h->d_counters) hipFree(h->d_counters);
     for (Arena* a : {&h->stage, &h->scratch, &h->dbg}) if (a->p) hipFree(a->p);
     for (auto& b : h->pb) {
-        for (Arena* a : {&b.rec, &b.srt, &b.seg, &b.flag, &b.gflag, &b.tables}) if (a->p) hipFree(a->p);
+        for (Arena* a : {&b.rec, &b.srt, &b.seg, &b.flag, &b.gflag, &b.tables, &b.s_hv1, &b.s_hv2, &b.s_key1, &b.s_key2, &b.s_src1, &b.s_src2,
+                         &b.s_cnt1, &b.s_cnt2, &b.s_misc}) if (a->p) hipFree(a->p);
         if (b.host_tables) hipHostFree(b.host_tables);
         if (b.tables_done) hipEventDestroy(b.tables_done);
         if (b.bin_done) hipEventDestroy(b.bin_done);
@@ -1007,6 +1174,8 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "dbg_sweep")          h->dbg_sweep = (int)value;
     else if (k == "overlap")            h->overlap = value != 0;
     else if (k == "overlap_min_points") h->overlap_min_points = value;
+    else if (k == "sort_path")          h->sort_path = value != 0;
+    else if (k == "sort_min_points")    h->sort_min_points = value;
     else return fail(h, GEM_ERR_INVALID, "gem_debug_set: unknown key");
     return GEM_OK;
 }

@@ -88,9 +88,57 @@ struct FuseArgs {
     unsigned long long* dbg;           // optional: [T][16] cycle-counter stamps of thread 0 (profiling aid)
 };
 
+// ---- the sorted pipeline of big passes (gem_sort.hip) ------------------------------------------------------------------------
+// Record key, 32 bits:  cell in tile (cell_bits = 10) | tile (tile_bits) << cell_bits | sweep << (cell_bits + tile_bits).
+struct SortArgs {
+    FrameConst frame0;                 // single-sweep call: the frame, by value
+    const FrameConst* frames;          // [n_sweeps]    (batched call)
+    const int*        sweep_chunk0;    // [n_sweeps+1]  first pass-1 chunk of each sweep (chunks never span sweeps)
+    const long long*  sweep_first;     // [n_sweeps+1]  first point of each sweep in the concatenated cloud
+    const int*        sweep_orig0;     // [n_sweeps]    original index of the sweep's first point (a big cloud cut into sweeps), or NULL
+    int               n_sweeps;
+    long long         n;               // total points
+    const float4*   xyzi; const uint32_t* rgb; const int* orig;                       // SRC 0
+    const int* f_index; const float* f_height; const float* f_var;                    // SRC 1: Fuse()'s arrays (GPU:1154)
+    const int* f_R; const int* f_G; const int* f_B; const float* f_I;
+    int keep_sentinel;                 // keep records with h == -1 (GPU:482) for the LOWEST walk
+    int tiles_per_row, T;              // 32x32-cell tiles
+    int cell_bits, tile_bits, sweep_shift; uint32_t tile_mask;
+    int n_chunks1;                     // chunks of pass 1 (8192 points each)
+    uint32_t *cnt1, *tot1;             // [n_chunks1][1024] per-chunk counts -> prefixes over the chunks; [1024] column totals
+    uint32_t *cnt2, *tot2;             // [chunks of pass 2][T]; [T]
+    uint32_t *total;                   // [0] records kept by pass 1 (in the map, in the strip, accepted)
+    uint32_t *tile_base;               // [T+1] first record of every tile in the final order
+    uint2 *hv1, *hv2;                  // {h, var} after pass 1 / pass 2
+    uint32_t *key1, *key2, *src1, *src2;      // keys; source point | colour flag << 31 (only when colours are fused)
+    unsigned long long* counters;      // optional: [0] += records
+};
+
+struct WalkArgs {
+    const uint2* hv; const uint32_t* key; const uint32_t* src; const uint32_t* tile_base;
+    int   T, tiles_per_row, L, row0, row1, sweep_shift, n_sweeps;
+    float mahal, var_floor;
+    int   dense;                       // 1: visit every tile (pending variance increments / floor not yet established)
+    int   n_pending; float pending[kMaxPending];
+    const float* var_updates;          // [n_sweeps] applied before each sweep, or NULL
+    float *elevation, *variance, *lowest;
+    int   start0, start1;
+    float* intensity; int *colorR, *colorG, *colorB;
+    const float4* xyzi; const uint32_t* rgb;
+    const int* f_R; const int* f_G; const int* f_B; const float* f_I;
+    unsigned long long* counters;      // optional: [1] += distinct touched cells (per sweep unless count_per_pass)
+    int   count_per_pass;
+};
+
+struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };   // optional dispatch time-stamps
+hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, const LaunchEvents ev[6]);   // count1, scan1, scatter1, count2, scan2, scatter2
+hipError_t launch_walk(hipStream_t st, const WalkArgs& a, int flags, LaunchEvents ev);
+int        sort_pass2_threads(int T);
+constexpr int kSortChunk1 = 8192;      // points per pass-1 chunk
+constexpr int kSortMaxTiles = 8000;    // tiles per map the sorted pipeline handles (LDS of k_sort_scatter2)
+
 hipError_t launch_project(hipStream_t st, const FrameConst& fc, int n, float* x, float* y, float* z, const int* orig,
                           int write_back, int* map_idx, float* var, float* xt, float* yt, float* zt);
-struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };   // optional dispatch time-stamps
 
 hipError_t launch_bin(hipStream_t st, const BinArgs& a, int src, int ts, LaunchEvents ev);
 hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr, int variant, LaunchEvents ev);

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GEM_ABI_VERSION 4
+#define GEM_ABI_VERSION 5
 
 typedef enum gem_status {
     GEM_OK = 0,
@@ -104,6 +104,10 @@ typedef struct gem_stats {
     int       launches_bin, launches_fuse;
     float     ms_frame;            /* ... and of k_frame (fuse of the previous sweep + bin of the new one)     */
     int       launches_frame;
+    float     ms_sort[6];          /* the sorted pipeline of big passes: count1, scan1, scatter1, count2, scan2, scatter2 */
+    int       launches_sort;       /* passes through it                                                        */
+    float     ms_walk;             /* ... and its k_fuse_walk                                                  */
+    int       launches_walk;
 } gem_stats;
 
 /* ---- lifecycle: replaces Init_GPU_elevationmap (GPU:940-994, called EMg.cpp:199) --------------- */

@@ -53,3 +53,20 @@ def ref_mod():
     if ref.lib() is None:
         pytest.skip("no /root/reference to build from and no prebuilt oracle/_ref/libgem_ref.so")
     return ref
+
+
+def pytest_generate_tests(metafunc):
+    # every GPU test runs on both pipelines (see the `pipeline` fixture)
+    if metafunc.definition.get_closest_marker("gpu") is not None:
+        metafunc.fixturenames.append("pipeline")
+        metafunc.parametrize("pipeline", ["default", "sorted"], indirect=True)
+
+
+@pytest.fixture
+def pipeline(request, monkeypatch):
+    """GPU tests run twice: with the library's own choice between the tile pipeline (k_frame / k_bin_wave + k_fuse_list) and
+    the sorted pipeline (gem_sort.hip), and with the sorted pipeline forced for every pass, however small."""
+    from gem_amd import ElevationMap
+    which = getattr(request, "param", "default")
+    monkeypatch.setattr(ElevationMap, "base_debug", {"sort_min_points": 1} if which == "sorted" else {})
+    return which

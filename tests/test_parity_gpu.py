@@ -685,7 +685,8 @@ def test_device_sweep_stream(oracle_mod):
         if k in (1, 4):
             assert_maps_match(gpu, ref)                  # observing the map flushes the pending fuse
     assert_maps_match(gpu, ref)
-    assert gpu.stats()["launches_frame"] >= 3            # the merged kernel is what ran
+    if not ElevationMap.base_debug:
+        assert gpu.stats()["launches_frame"] >= 3        # the merged kernel is what ran
     # dense clusters through the device path: more than 7 records per cell and batch
     gpu, ref = make_pair(oracle_mod, 40, 0.1)
     c = synth.random_cloud(23, 90_000, 2.2, z_sigma=0.05)
