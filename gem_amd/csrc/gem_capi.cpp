@@ -79,6 +79,7 @@ struct gem_handle {
     long long overlap_min_points = 1000000;
     bool sort_path = true;              // passes of at least sort_min_points points run the sorted pipeline (gem_sort.hip)
     long long sort_min_points = 200000;
+    bool walk_permute = true;           // k_fuse_walk: blocks mapped to cell groups through a stride permutation
     int dbg_sweep = 0;                  // debug stamps of the dense path: which sweep (GEM_DBG_SWEEP)
     bool track_lowest = false;          // also maintain map_lowest in the fuse kernels (gem_set_lowest_tracking, for gem_raytracing)
     unsigned dense_min = 2048;          // records of one sweep in one 16x16 tile above which the tile is counting-sorted (k_fuse_list, dense path)
@@ -240,17 +241,19 @@ constexpr long long kSweepPoints = 2048ll * kUnit;   // a single cloud longer th
 
 static int ceil_log2(int v) { int b = 0; while ((1 << b) < v) ++b; return b; }
 
-// the tile geometry of the sorted pipeline for this map, and whether a pass of `n_sweeps` sweeps fits its record key
-struct SortGeometry { int tiles_per_row, T, tile_bits, sweep_shift; bool ok; };
+// the key geometry of the sorted pipeline for this map, and whether a pass of `n_sweeps` sweeps fits the 32-bit record key
+struct SortGeometry { int tiles_per_row, T, id_bits, d0_bits, bins0, bins1; bool ok; };
 SortGeometry sort_geometry(const gem_handle* h, int n_sweeps)
 {
     SortGeometry g{};
     g.tiles_per_row = (h->L + 31) / 32;
     g.T = g.tiles_per_row * g.tiles_per_row;
-    g.tile_bits = std::max(1, ceil_log2(g.T));
-    g.sweep_shift = 10 + g.tile_bits;
-    const long long max_sweeps = std::min<long long>(512, 1ll << (32 - g.sweep_shift));
-    g.ok = g.T <= kSortMaxTiles && n_sweeps <= max_sweeps;
+    g.id_bits = 10 + std::max(1, ceil_log2(g.T));                 // id = tile << 10 | cell in tile
+    g.d0_bits = std::max(6, g.id_bits / 2);                       // two digits of about equal width; a wave's 64 cells never straddle a bin
+    g.bins0 = 1 << g.d0_bits;
+    g.bins1 = (int)(((((long long)g.T) << 10) - 1) >> g.d0_bits) + 1;
+    const long long max_sweeps = std::min<long long>(512, (1ll << (32 - g.id_bits)) - 1);     // the sweep field is never all ones
+    g.ok = g.id_bits <= 26 && g.bins0 <= kSortMaxBins && g.bins1 <= kSortMaxBins && n_sweeps <= max_sweeps;
     return g;
 }
 
@@ -258,14 +261,15 @@ SortGeometry sort_geometry(const gem_handle* h, int n_sweeps)
 int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGeometry& geo)
 {
     const bool batched = in.n_sweeps > 1;
+    const bool with_src = (attr & 3) != 0;
+    const SortShape sh1 = sort_shape(geo.bins0, with_src);
     std::vector<int> chunk0(in.n_sweeps + 1, 0);
     for (int s = 0; s < in.n_sweeps; ++s) {
         const long long cnt = batched ? in.offsets[s + 1] - in.offsets[s] : in.n;
-        chunk0[s + 1] = chunk0[s] + (int)((cnt + kSortChunk1 - 1) / kSortChunk1);
+        chunk0[s + 1] = chunk0[s] + (int)((cnt + sh1.chunk - 1) / sh1.chunk);
     }
     const int NC1 = chunk0[in.n_sweeps];
     const bool dense = h->n_pending > 0 || h->floor_dirty || (batched && in.var_updates != nullptr);
-    const bool with_src = (attr & 3) != 0;
     const int T = geo.T;
     h->T = T;
 
@@ -284,22 +288,23 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     }
     if (!overlap) h->main_reads_pb = true;
 
-    const int nt2 = sort_pass2_threads(T);
-    const long long nc2max = (in.n + (long long)nt2 * 8 - 1) / ((long long)nt2 * 8);
+    const long long nc2max = (in.n + sh1.chunk - 1) / sh1.chunk;
     const size_t N = (size_t)in.n;
     int rc;
-    if ((rc = ensure(h, pb.s_hv1, N * 8 + 16))) return rc;
-    if ((rc = ensure(h, pb.s_hv2, N * 8 + 16))) return rc;
-    if ((rc = ensure(h, pb.s_key1, N * 4 + 16))) return rc;
-    if ((rc = ensure(h, pb.s_key2, N * 4 + 16))) return rc;
+    // (+64 bytes: k_fuse_walk fetches whole groups of four records; a cell's last group may reach past the last record)
+    if ((rc = ensure(h, pb.s_hv1, N * 8 + 64))) return rc;
+    if ((rc = ensure(h, pb.s_hv2, N * 8 + 64))) return rc;
+    if ((rc = ensure(h, pb.s_key1, N * 4 + 64))) return rc;
+    if ((rc = ensure(h, pb.s_key2, N * 4 + 64))) return rc;
     if (with_src) {
-        if ((rc = ensure(h, pb.s_src1, N * 4 + 16))) return rc;
-        if ((rc = ensure(h, pb.s_src2, N * 4 + 16))) return rc;
+        if ((rc = ensure(h, pb.s_src1, N * 4 + 64))) return rc;
+        if ((rc = ensure(h, pb.s_src2, N * 4 + 64))) return rc;
     }
-    if ((rc = ensure(h, pb.s_cnt1, (size_t)NC1 * 1024 * 4))) return rc;
-    if ((rc = ensure(h, pb.s_cnt2, (size_t)nc2max * T * 4 + 16))) return rc;
-    const size_t o_tot1 = 0, o_tot2 = 1024 * 4, o_total = o_tot2 + (size_t)T * 4, o_tbase = (o_total + 4 + 15) & ~(size_t)15;
-    if ((rc = ensure(h, pb.s_misc, o_tbase + ((size_t)T + 1) * 4))) return rc;
+    if ((rc = ensure(h, pb.s_cnt1, (size_t)NC1 * geo.bins0 * 4))) return rc;
+    if ((rc = ensure(h, pb.s_cnt2, (size_t)nc2max * geo.bins1 * 4 + 16))) return rc;
+    // segment sums of pass 1 [4][bins0] | of pass 2 [4][bins1] | record count | bin bases [bins1 + 1]
+    const size_t o_tot1 = 0, o_tot2 = (size_t)geo.bins0 * 16, o_total = o_tot2 + (size_t)geo.bins1 * 16, o_base = (o_total + 4 + 15) & ~(size_t)15;
+    if ((rc = ensure(h, pb.s_misc, o_base + ((size_t)geo.bins1 + 1) * 4))) return rc;
     // the walk of pass p-2 has read these buffers (host-side wait, see run_pipeline)
     if (overlap && pb.fuse_recorded) GEM_HIP(h, hipEventSynchronize(pb.fuse_done));
 
@@ -345,20 +350,26 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     sa.f_R = in.f_R; sa.f_G = in.f_G; sa.f_B = in.f_B; sa.f_I = in.f_I;
     sa.keep_sentinel = h->track_lowest ? 1 : 0;
     sa.tiles_per_row = geo.tiles_per_row; sa.T = T;
-    sa.cell_bits = 10; sa.tile_bits = geo.tile_bits; sa.sweep_shift = geo.sweep_shift; sa.tile_mask = (1u << geo.tile_bits) - 1u;
+    sa.id_bits = geo.id_bits; sa.d0_bits = geo.d0_bits; sa.bins0 = geo.bins0; sa.bins1 = geo.bins1;
     sa.n_chunks1 = NC1;
     unsigned char* misc = static_cast<unsigned char*>(pb.s_misc.p);
     sa.cnt1 = static_cast<uint32_t*>(pb.s_cnt1.p); sa.tot1 = reinterpret_cast<uint32_t*>(misc + o_tot1);
     sa.cnt2 = static_cast<uint32_t*>(pb.s_cnt2.p); sa.tot2 = reinterpret_cast<uint32_t*>(misc + o_tot2);
-    sa.total = reinterpret_cast<uint32_t*>(misc + o_total); sa.tile_base = reinterpret_cast<uint32_t*>(misc + o_tbase);
-    sa.hv1 = static_cast<uint2*>(pb.s_hv1.p); sa.hv2 = static_cast<uint2*>(pb.s_hv2.p);
-    sa.key1 = static_cast<uint32_t*>(pb.s_key1.p); sa.key2 = static_cast<uint32_t*>(pb.s_key2.p);
-    sa.src1 = with_src ? static_cast<uint32_t*>(pb.s_src1.p) : nullptr; sa.src2 = with_src ? static_cast<uint32_t*>(pb.s_src2.p) : nullptr;
+    sa.total = reinterpret_cast<uint32_t*>(misc + o_total); sa.bin_base = reinterpret_cast<uint32_t*>(misc + o_base);
+    // arrays a: the projected records in input order, later the final order; arrays b: the order after pass 1
+    sa.hv_a = static_cast<uint2*>(pb.s_hv2.p); sa.hv_b = static_cast<uint2*>(pb.s_hv1.p);
+    sa.key_a = static_cast<uint32_t*>(pb.s_key2.p); sa.key_b = static_cast<uint32_t*>(pb.s_key1.p);
+    sa.src_a = with_src ? static_cast<uint32_t*>(pb.s_src2.p) : nullptr; sa.src_b = with_src ? static_cast<uint32_t*>(pb.s_src1.p) : nullptr;
     sa.counters = h->counting ? h->d_counters : nullptr;
 
-    wa.hv = sa.hv2; wa.key = sa.key2; wa.src = sa.src2; wa.tile_base = sa.tile_base;
+    wa.hv = sa.hv_a; wa.key = sa.key_a; wa.src = sa.src_a; wa.bin_base = sa.bin_base;
+    {   // block -> cell-group permutation of k_fuse_walk: a prime stride coprime with the number of groups
+        static const int primes[] = {1021, 1031, 2053, 4099, 509};
+        wa.walk_stride = 1;
+        if (h->walk_permute) for (int pr : primes) if ((16ll * T) % pr != 0) { wa.walk_stride = pr; break; }
+    }
     wa.T = T; wa.tiles_per_row = geo.tiles_per_row; wa.L = h->L; wa.row0 = h->row0; wa.row1 = h->row1;
-    wa.sweep_shift = geo.sweep_shift; wa.n_sweeps = in.n_sweeps;
+    wa.id_bits = geo.id_bits; wa.bin_shift = geo.d0_bits; wa.n_sweeps = in.n_sweeps;
     wa.mahal = h->cfg.mahalanobis_threshold; wa.var_floor = h->cfg.variance_floor;
     wa.dense = dense ? 1 : 0;
     wa.n_pending = h->n_pending;
@@ -374,7 +385,15 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     {
         Timed t0(h, 3), t1(h, 4), t2(h, 5), t3(h, 6), t4(h, 7), t5(h, 8);
         const LaunchEvents ev[6] = {t0.events(), t1.events(), t2.events(), t3.events(), t4.events(), t5.events()};
-        GEM_HIP(h, launch_sort(sbin, sa, in.src, with_src, ev));
+        // clouds whose frames all use the laser model (the reference's only GPU model, GPU:403-408) take the instantiation without
+        // the camera models' double-precision code
+        int src = in.src;
+        if (src == 0) {
+            bool laser = true;
+            for (int s = 0; s < in.n_sweeps && laser; ++s) laser = in.params[s].sensor_model == GEM_MODEL_LASER;
+            if (laser) src = 2;
+        }
+        GEM_HIP(h, launch_sort(sbin, sa, src, with_src, ev));
     }
     if (overlap) {
         GEM_HIP(h, hipEventRecord(pb.bin_done, sbin));
@@ -1176,6 +1195,7 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "overlap_min_points") h->overlap_min_points = value;
     else if (k == "sort_path")          h->sort_path = value != 0;
     else if (k == "sort_min_points")    h->sort_min_points = value;
+    else if (k == "walk_permute")       h->walk_permute = value != 0;
     else return fail(h, GEM_ERR_INVALID, "gem_debug_set: unknown key");
     return GEM_OK;
 }

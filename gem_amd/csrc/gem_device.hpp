@@ -91,10 +91,13 @@ __device__ __forceinline__ int map_index(const FrameConst& f, float px, float py
     return map_row_col(f, px, py, row, col) ? row * f.L + col : -1;
 }
 
+// MODEL >= 0: the sensor model is known at compile time (the laser-only instantiations of the big-pass kernels do not carry the
+// double-precision pow / sqrt code of the camera models); MODEL < 0: taken from the frame
+template <int MODEL = -1>
 __device__ __forceinline__ void sensor_variances(const FrameConst& f, float x, float y, float z, int orig,
                                                  float& vn, float& vl)
 {
-    switch (f.model) {
+    switch (MODEL >= 0 ? MODEL : f.model) {
     default:
     case 0: {   // laser, GPU:404-408
         const float d = sqrtf(dot3(x, x, y, y, z, z));
@@ -129,10 +132,11 @@ __device__ __forceinline__ void sensor_variances(const FrameConst& f, float x, f
 }
 
 // GPU:403-425
+template <int MODEL = -1>
 __device__ __forceinline__ float height_variance(const FrameConst& f, float x, float y, float z, int orig)
 {
     float vn, vl;
-    sensor_variances(f, x, y, z, orig, vn, vl);
+    sensor_variances<MODEL>(f, x, y, z, orig, vn, vl);
     const float q0 = dot3(f.C[0], x, f.C[1], y, f.C[2], z);
     const float q1 = dot3(f.C[3], x, f.C[4], y, f.C[5], z);
     const float q2 = dot3(f.C[6], x, f.C[7], y, f.C[8], z);
@@ -154,6 +158,7 @@ __device__ __forceinline__ float height_variance(const FrameConst& f, float x, f
 }
 
 // one point of G_pointsprocess (GPU:384-455), without the racy map_lowest side effect
+template <int MODEL = -1>
 __device__ __forceinline__ Projected project_point(const FrameConst& f, float x, float y, float z, int orig)
 {
     Projected r;
@@ -165,7 +170,7 @@ __device__ __forceinline__ Projected project_point(const FrameConst& f, float x,
         r.xt = f.T[0] * x + f.T[1] * y + f.T[2] * z + f.T[3];                      // GPU:399
         r.yt = f.T[4] * x + f.T[5] * y + f.T[6] * z + f.T[7];                      // GPU:400
         r.h = h;
-        r.var = height_variance(f, x, y, z, orig);
+        r.var = height_variance<MODEL>(f, x, y, z, orig);
         r.cell = map_row_col(f, r.xt, r.yt, r.row, r.col) ? r.row * f.L + r.col : -1;   // GPU:431
         r.accepted = true;
     } else {                                                                       // GPU:441-451

@@ -89,13 +89,14 @@ struct FuseArgs {
 };
 
 // ---- the sorted pipeline of big passes (gem_sort.hip) ------------------------------------------------------------------------
-// Record key, 32 bits:  cell in tile (cell_bits = 10) | tile (tile_bits) << cell_bits | sweep << (cell_bits + tile_bits).
+// Record key, 32 bits:  id | sweep << id_bits,  id = tile << 10 | cell in its 32x32 tile  (id_bits = 10 + bits of the tile index).
+// The id is sorted in two stable counting-sort passes: low digit = id & (bins0 - 1), high digit = id >> d0_bits (bins1 values).
 struct SortArgs {
     FrameConst frame0;                 // single-sweep call: the frame, by value
     const FrameConst* frames;          // [n_sweeps]    (batched call)
-    const int*        sweep_chunk0;    // [n_sweeps+1]  first pass-1 chunk of each sweep (chunks never span sweeps)
+    const int*        sweep_chunk0;    // [n_sweeps+1]  first pass-1 chunk of each sweep (chunks never span sweeps); NULL = one sweep
     const long long*  sweep_first;     // [n_sweeps+1]  first point of each sweep in the concatenated cloud
-    const int*        sweep_orig0;     // [n_sweeps]    original index of the sweep's first point (a big cloud cut into sweeps), or NULL
+    const int*        sweep_orig0;     // [n_sweeps]    original index of the sweep's first point, or NULL
     int               n_sweeps;
     long long         n;               // total points
     const float4*   xyzi; const uint32_t* rgb; const int* orig;                       // SRC 0
@@ -103,22 +104,36 @@ struct SortArgs {
     const int* f_R; const int* f_G; const int* f_B; const float* f_I;
     int keep_sentinel;                 // keep records with h == -1 (GPU:482) for the LOWEST walk
     int tiles_per_row, T;              // 32x32-cell tiles
-    int cell_bits, tile_bits, sweep_shift; uint32_t tile_mask;
-    int n_chunks1;                     // chunks of pass 1 (8192 points each)
-    uint32_t *cnt1, *tot1;             // [n_chunks1][1024] per-chunk counts -> prefixes over the chunks; [1024] column totals
-    uint32_t *cnt2, *tot2;             // [chunks of pass 2][T]; [T]
+    int id_bits, d0_bits, bins0, bins1;
+    int n_chunks1;                     // chunks of pass 1
+    uint32_t *cnt1, *tot1;             // [n_chunks1][bins0] per-chunk counts -> prefixes over the chunks of a segment; [4][bins0] segment sums
+    uint32_t *cnt2, *tot2;             // [chunks of pass 2][bins1]; [4][bins1]
     uint32_t *total;                   // [0] records kept by pass 1 (in the map, in the strip, accepted)
-    uint32_t *tile_base;               // [T+1] first record of every tile in the final order
-    uint2 *hv1, *hv2;                  // {h, var} after pass 1 / pass 2
-    uint32_t *key1, *key2, *src1, *src2;      // keys; source point | colour flag << 31 (only when colours are fused)
+    uint32_t *bin_base;                // [bins1 + 1] first record of every high-digit bin in the final order (what k_fuse_walk searches in)
+    uint2 *hv_a, *hv_b;                // {h, var}: a = input order, then the final order; b = after pass 1
+    uint32_t *key_a, *key_b, *src_a, *src_b;      // keys; source point | colour flag << 31 (src only when colours are fused)
     unsigned long long* counters;      // optional: [0] += records
 };
 
+// one counting-sort pass over a digit of the key
+struct PassArgs {
+    const uint2* hv_in; const uint32_t* key_in; const uint32_t* src_in;
+    uint2* hv_out; uint32_t* key_out; uint32_t* src_out;
+    uint32_t* cnt; const uint32_t* segtot;       // [chunks][bins] counts -> prefixes over the chunks of a segment; [4][bins] segment sums (k_sort_scan)
+    int n_chunks;                                // pass 1: chunks of the pass (pass 2 derives them from *n_dev)
+    int bins, shift, digit_bits; uint32_t mask;
+    const uint32_t* n_dev; long long n_host;     // number of items: on the device (pass 2) or known to the host (pass 1)
+    const int* sweep_chunk0; const long long* sweep_first; int n_sweeps;   // pass 1 of a batched call: sweep-aligned chunks
+    uint32_t* bin_base;                          // last pass: [bins + 1] published by workgroup 0
+    unsigned long long* counters;
+};
+
 struct WalkArgs {
-    const uint2* hv; const uint32_t* key; const uint32_t* src; const uint32_t* tile_base;
-    int   T, tiles_per_row, L, row0, row1, sweep_shift, n_sweeps;
+    const uint2* hv; const uint32_t* key; const uint32_t* src; const uint32_t* bin_base;
+    int   T, tiles_per_row, L, row0, row1, id_bits, bin_shift, n_sweeps;
+    int   walk_stride;                 // block -> cell-group permutation: a prime that does not divide 16 T
     float mahal, var_floor;
-    int   dense;                       // 1: visit every tile (pending variance increments / floor not yet established)
+    int   dense;                       // 1: visit every cell (pending variance increments / floor not yet established)
     int   n_pending; float pending[kMaxPending];
     const float* var_updates;          // [n_sweeps] applied before each sweep, or NULL
     float *elevation, *variance, *lowest;
@@ -131,11 +146,11 @@ struct WalkArgs {
 };
 
 struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };   // optional dispatch time-stamps
-hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, const LaunchEvents ev[6]);   // count1, scan1, scatter1, count2, scan2, scatter2
+struct SortShape { int nt, chunk; size_t lds; };
+SortShape  sort_shape(int bins, bool attr);   // workgroup shape of a pass with that many bins
+hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, const LaunchEvents ev[6]);   // project, scan1, scatter1, count2, scan2, scatter2
 hipError_t launch_walk(hipStream_t st, const WalkArgs& a, int flags, LaunchEvents ev);
-int        sort_pass2_threads(int T);
-constexpr int kSortChunk1 = 8192;      // points per pass-1 chunk
-constexpr int kSortMaxTiles = 8000;    // tiles per map the sorted pipeline handles (LDS of k_sort_scatter2)
+constexpr int kSortMaxBins = 8000;     // bins per pass the sorted pipeline handles (LDS of k_sort_scatter)
 
 hipError_t launch_project(hipStream_t st, const FrameConst& fc, int n, float* x, float* y, float* z, const int* orig,
                           int write_back, int* map_idx, float* var, float* xt, float* yt, float* zt);

@@ -8,19 +8,23 @@
 // chip instead: a stable two-digit LSD counting sort of the in-map points by (tile, cell-in-tile), every pass split into
 // equal chunks, and then every cell walks its own contiguous run:
 //
-//   k_sort_count1    chunk of 8192 points: project + bin (G_pointsprocess, GPU:384-455), histogram over the LOW digit
-//                    (cell inside its 32x32 tile, 1024 bins) in LDS                      -> cnt1[chunk][1024]
-//   k_sort_scan      column-wise exclusive prefix over the chunks, column totals          -> cnt1 (in place), tot1[1024], M
-//   k_sort_scatter1  the same chunk again: project, STABLE rank inside the chunk (wave w owns the w-th contiguous share,
-//                    64 consecutive points per step, equal bins matched by ballots, a per-wave cursor per bin in LDS),
-//                    record {h, var} + key {cell | tile | sweep} written to its final place of pass 1
-//   k_sort_count2 / k_sort_scan / k_sort_scatter2   the same over the HIGH digit (tile) on the records of pass 1
-//   k_fuse_walk      one workgroup per tile, one thread per cell: cell boundaries of the tile's run from one look at the keys,
-//                    then every thread streams its own run through the reference's recurrence (GPU:480-531), the variance
-//                    increments of the sweeps in between (GPU:540-547) and the floors (GPU:533-534) replayed per cell.
+//   k_sort_project  chunk of 8192 points: project + bin (G_pointsprocess, GPU:384-455) ONCE; {h, var} and the key
+//                   {cell | tile | sweep} of every point stored in input order (rejected points: key = ~0), histogram over
+//                   the LOW digit of the key in LDS                                         -> cntA[chunk][bins0]
+//   k_sort_scan     column-wise exclusive prefix over the chunks, column totals             -> cntA (in place), totA, M
+//   k_sort_scatter  the same chunk again, records only: STABLE rank inside the chunk (wave w owns the w-th contiguous
+//                   share, 64 consecutive records per step, equal bins matched by ballots, a per-wave cursor per bin
+//                   in LDS), every record written to its final place of the pass
+//   k_sort_count / k_sort_scan / k_sort_scatter   the same over the HIGH digit on the records of pass 1
+//   k_fuse_walk     one WAVE per 64 consecutive cells (two rows of a 32x32 tile): a 32-ary search finds the wave's share of
+//                   the sorted records, one look at its keys gives the cell boundaries, then every lane streams its own
+//                   cell's run through the reference's recurrence (GPU:480-531), the variance increments of the sweeps in
+//                   between (GPU:540-547) and the floors (GPU:533-534) replayed per cell.
+// The key's cell id (tile << 10 | cell in tile) is split into two digits of about equal width, so that both passes have a few
+// hundred to a few thousand bins whatever the map size (600^2: 512 x 722; 2400^2: 2048 x 2813).
 //
 // Stability of both passes keeps ascending input order inside every cell; no float atomics, no LDS batches, no fast / generic /
-// dense cases: the tile takes the time of its LONGEST cell chain, which is the floor of any exact implementation.
+// dense cases: a wave takes the time of its LONGEST cell chain, and the waves of the tile under the sensor spread over the chip.
 // Algorithmic bytes: 16 B per point (read) + 16 B per distinct touched cell (+ 8 L^2 per dense variance pass).  What the
 // sort moves on top of that is stated in DESIGN.md section 4.
 //
@@ -30,26 +34,28 @@
 
 #include <hip/hip_ext.h>
 
+#include <algorithm>
 #include <mutex>
 
 namespace gem {
 
-constexpr int kSortK = 8;                       // items per thread and chunk
+constexpr int kSortChunk = 4096;                 // records per chunk of every pass (its sorted copy is staged in LDS)
+constexpr uint32_t kKeyInvalid = 0xffffffffu;   // key of a rejected / outside point in the input-ordered record arrays
 
 // ------------------------------------------------------------------------------------------
 // one point of the pass: projection + binning, the same decisions as bin_wave_body (gem_kernels.hip)
 // ------------------------------------------------------------------------------------------
-struct Binned { bool valid; uint32_t cell, tile; float h, v; bool colour_ok; };
+struct Binned { bool valid; uint32_t id; float h, v; bool colour_ok; };
 
-template <int SRC, int TS>
-__device__ __forceinline__ Binned bin_one(const SortArgs& a, const FrameConst& fc, bool live, const float4& p, long long i, int orig_fallback)
+// SRC: 0 = XYZI cloud, sensor model taken from the frame; 2 = XYZI cloud, every frame uses the laser model; 1 = Fuse()'s arrays
+template <int SRC>
+__device__ __forceinline__ Binned bin_one(const SortArgs& a, const FrameConst& fc, const float4& p, long long i, int orig_fallback)
 {
-    constexpr int TE = 1 << TS;
-    Binned b; b.valid = false; b.cell = 0; b.tile = 0; b.h = 0.0f; b.v = 0.0f; b.colour_ok = false;
-    if (!live) return b;
+    Binned b; b.valid = false; b.id = 0; b.h = 0.0f; b.v = 0.0f; b.colour_ok = false;
     int row, col; float h, v; bool colour_ok = false;
-    if (SRC == 0) {
-        const Projected r = project_point(fc, p.x, p.y, p.z, a.orig ? a.orig[i] : orig_fallback);
+    if (SRC != 1) {
+        const Projected r = SRC == 2 ? project_point<0>(fc, p.x, p.y, p.z, 0)
+                                     : project_point<-1>(fc, p.x, p.y, p.z, a.orig ? a.orig[i] : orig_fallback);
         row = r.row; col = r.col; h = r.h; v = r.var;
         if (a.rgb) {
             const uint32_t c = a.rgb[i];
@@ -65,123 +71,149 @@ __device__ __forceinline__ Binned bin_one(const SortArgs& a, const FrameConst& f
     // points are tracked: GPU:430-439 sees the point, the LOWEST walk skips its fusion)
     if (row >= fc.row0 && row < fc.row1 && (h != -1.0f || a.keep_sentinel)) {
         b.valid = true;
-        b.tile = (uint32_t)((row >> TS) * a.tiles_per_row + (col >> TS));
-        b.cell = (uint32_t)(((row & (TE - 1)) << TS) | (col & (TE - 1)));
+        const uint32_t tile = (uint32_t)((row >> 5) * a.tiles_per_row + (col >> 5));
+        b.id = (tile << 10) | (uint32_t)(((row & 31) << 5) | (col & 31));
         b.h = h; b.v = v; b.colour_ok = colour_ok;
     }
     return b;
 }
 
-// chunk -> (sweep, first point of the chunk, end of the sweep): chunks never span sweeps (the frame constants differ)
+// chunk -> (sweep, first item of the chunk, end of the sweep): pass-1 chunks never span sweeps (the frame constants differ)
 struct ChunkRange { int sweep; long long first, end; int orig0; };
 
-template <bool BATCH, int CH>
-__device__ __forceinline__ ChunkRange chunk_range(const SortArgs& a, int chunk)
+template <int CH>
+__device__ __forceinline__ ChunkRange chunk_range(const int* __restrict__ sweep_chunk0, const long long* __restrict__ sweep_first,
+                                                  const int* __restrict__ sweep_orig0, int n_sweeps, long long n, int chunk)
 {
-    ChunkRange r; r.sweep = 0; r.first = (long long)chunk * CH; r.end = a.n; r.orig0 = 0;
-    if (BATCH) {
-        int lo = 0, hi = a.n_sweeps;                                   // block-uniform: scalar loads
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.sweep_chunk0[mid] <= chunk) lo = mid; else hi = mid; }
+    ChunkRange r; r.sweep = 0; r.first = (long long)chunk * CH; r.end = n; r.orig0 = 0;
+    if (sweep_chunk0) {                                                // batched call; block-uniform: scalar loads
+        int lo = 0, hi = n_sweeps;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sweep_chunk0[mid] <= chunk) lo = mid; else hi = mid; }
         r.sweep = lo;
-        const long long sb = a.sweep_first[lo];
-        r.first = sb + (long long)(chunk - a.sweep_chunk0[lo]) * CH;
-        r.end = a.sweep_first[lo + 1];
-        r.orig0 = (a.sweep_orig0 ? a.sweep_orig0[lo] : 0) - (int)sb;   // original index of point i = i + orig0
+        const long long sb = sweep_first[lo];
+        r.first = sb + (long long)(chunk - sweep_chunk0[lo]) * CH;
+        r.end = sweep_first[lo + 1];
+        r.orig0 = (sweep_orig0 ? sweep_orig0[lo] : 0) - (int)sb;       // original index of point i = i + orig0
     }
     return r;
 }
 
 // ------------------------------------------------------------------------------------------
-// pass 1, count
+// pass 1, project + count: the only kernel that touches the cloud
 // ------------------------------------------------------------------------------------------
-template <int SRC, int TS, bool BATCH>
-__global__ __launch_bounds__(1024) void k_sort_count1(SortArgs a)
+// (256-thread workgroups whatever the chunk size: the projection needs ~100 VGPRs, and five light workgroups per CU hide its
+//  load latency better than one of 1024 threads)
+template <int SRC>
+__global__ __launch_bounds__(256) void k_sort_project(SortArgs a)
 {
-    constexpr int NT = 1024, K = kSortK, CH = NT * K, D0 = 1 << (2 * TS);
-    __shared__ uint32_t hist[D0];
+    constexpr int NT = 256, CH = kSortChunk, K = CH / NT;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_sort[];
+    uint32_t* hist = lds_sort;                                         // [bins0]
     const int tid = (int)threadIdx.x, chunk = (int)blockIdx.x;
-    for (int i = tid; i < D0; i += NT) hist[i] = 0u;
+    for (int i = tid; i < a.bins0; i += NT) hist[i] = 0u;
     if (chunk == 0 && tid == 0) *a.total = 0u;                         // k_sort_scan of this pass adds the column totals up
-    const ChunkRange cr = chunk_range<BATCH, CH>(a, chunk);
-    const FrameConst& fc = BATCH ? a.frames[cr.sweep] : a.frame0;
+    const ChunkRange cr = chunk_range<CH>(a.sweep_chunk0, a.sweep_first, a.sweep_orig0, a.n_sweeps, a.n, chunk);
+    // BY VALUE: the stores below may alias the frame table as far as the compiler knows, and a reference would make it reload
+    // every constant after every store (measured: 105 us instead of 25 for the 32 sweeps of C4)
+    const FrameConst fc = a.sweep_chunk0 ? a.frames[cr.sweep] : a.frame0;
     const long long base = cr.first + (long long)(tid >> 6) * (K * 64) + (tid & 63);
-    float4 p[K]; bool live[K];
-    if (SRC == 0) {
+    const uint32_t sweep_bits = (uint32_t)cr.sweep << a.id_bits;
+    const uint32_t d0mask = (uint32_t)a.bins0 - 1u;
+    __syncthreads();
+    // blocks of eight points: the loads of a block are in flight together, then each point is projected, stored and counted
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        float4 p[8];
+        if (SRC != 1) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) {                                  // all loads in flight before the first projection
-            const long long i = base + k * 64;
-            live[k] = i < cr.end;
-            p[k] = a.xyzi[live[k] ? i : cr.first];
+            for (int k = 0; k < 8; ++k) { const long long i = base + (k0 + k) * 64; p[k] = a.xyzi[i < cr.end ? i : cr.first]; }
         }
-    } else {
 #pragma unroll
-        for (int k = 0; k < K; ++k) { live[k] = base + k * 64 < cr.end; p[k] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        for (int k = 0; k < 8; ++k) {
+            const long long i = base + (k0 + k) * 64;
+            if (i < cr.end) {
+                const Binned b = bin_one<SRC>(a, fc, SRC != 1 ? p[k] : make_float4(0.f, 0.f, 0.f, 0.f), i, (int)i + cr.orig0);
+                a.key_a[i] = b.valid ? (b.id | sweep_bits) : kKeyInvalid;
+                a.hv_a[i] = make_uint2(__float_as_uint(b.h), __float_as_uint(b.v));
+                if (a.src_a) a.src_a[i] = (uint32_t)i | (b.colour_ok ? 0x80000000u : 0u);   // source point; bit 31: R, G, B, intensity all non-zero
+                if (b.valid) atomicAdd(&hist[b.id & d0mask], 1u);
+            }
+        }
     }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const long long i = base + k * 64;
-        const Binned b = bin_one<SRC, TS>(a, fc, live[k], p[k], i, (int)i + cr.orig0);
-        if (b.valid) atomicAdd(&hist[b.cell], 1u);
-    }
-    __syncthreads();
-    for (int i = tid; i < D0; i += NT) a.cnt1[(size_t)chunk * D0 + i] = hist[i];
+    for (int i = tid; i < a.bins0; i += NT) a.cnt1[(size_t)chunk * a.bins0 + i] = hist[i];
 }
 
 // ------------------------------------------------------------------------------------------
-// column scan over the chunks (both passes): cnt[c][b] -> sum over c' < c of cnt[c'][b], in place; tot[b] = column sum.
-// One workgroup per 64 bins; wave w owns the w-th contiguous share of the chunks (lane = bin: 256-byte coalesced rows).
+// column scan over the chunks (both passes), in kScanSegs SEGMENTS of the chunk range so that enough workgroups take part:
+// workgroup (x, seg) owns 64 bins x the seg-th quarter of the chunks, wave w the w-th contiguous share of those (lane = bin:
+// 256-byte coalesced rows).  cnt[c][b] -> records of bin b in the earlier chunks OF THE SAME SEGMENT, in place;
+// segtot[seg][b] = the segment's column sum; *total_out += everything.  The consumers add the (at most three) earlier
+// segments' sums themselves.
+// (Tried and dropped: one workgroup per 64 bins over all chunks -- 8 workgroups for 512 bins, 15 us once the per-wave share
+//  spilled registers; a "last workgroup scans the totals" epilogue -- its device-scope fences write the L2s back on this
+//  multi-XCD part and tripled the kernel's time.)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_sort_scan(uint32_t* __restrict__ cnt, uint32_t* __restrict__ tot, int bins, int n_chunks,
-                                                    const uint32_t* __restrict__ records, int chunk_records, uint32_t* __restrict__ total_out)
+constexpr int kScanSegs = 4;
+
+__device__ __forceinline__ int scan_seg_chunks(int nc) { return (nc + kScanSegs - 1) / kScanSegs; }     // chunks per segment
+
+__global__ __launch_bounds__(1024) void k_sort_scan(uint32_t* __restrict__ cnt, uint32_t* __restrict__ segtot, int bins, int n_chunks,
+                                                    const uint32_t* __restrict__ records, uint32_t* __restrict__ total_out)
 {
     __shared__ uint32_t part[16][64];
-    const int lane = lane_id(), w = (int)(threadIdx.x >> 6);
+    const int lane = lane_id(), w = (int)(threadIdx.x >> 6), seg = (int)blockIdx.y;
     const int b = (int)blockIdx.x * 64 + lane;
     // pass 2: the number of chunks depends on how many records pass 1 kept (known on the device only)
-    const int nc = records ? (int)(((unsigned long long)*records + (unsigned)chunk_records - 1u) / (unsigned)chunk_records) : n_chunks;
-    const int S = (nc + 15) >> 4;
-    const int c_lo = min(nc, w * S), c_hi = min(nc, c_lo + S);
+    const int nc = records ? (int)(((unsigned long long)*records + (unsigned)kSortChunk - 1u) / (unsigned)kSortChunk) : n_chunks;
+    const int Q = scan_seg_chunks(nc);
+    const int s_lo = min(nc, seg * Q), s_hi = min(nc, s_lo + Q);
+    const int S = (Q + 15) >> 4;
+    const int c_lo = min(s_hi, s_lo + w * S), c_hi = min(s_hi, c_lo + S);
+    const bool on = b < bins;
+    uint32_t* col = cnt + (on ? b : 0);
+    const int c_last = c_hi > c_lo ? c_hi - 1 : 0;
     uint32_t sum = 0;
-    if (b < bins) {
-        int c = c_lo;
-        for (; c + 4 <= c_hi; c += 4) {                                // four independent loads in flight
-            const uint32_t v0 = cnt[(size_t)c * bins + b], v1 = cnt[(size_t)(c + 1) * bins + b];
-            const uint32_t v2 = cnt[(size_t)(c + 2) * bins + b], v3 = cnt[(size_t)(c + 3) * bins + b];
-            sum += (v0 + v1) + (v2 + v3);
+    uint32_t keep[16];
+    if (S <= 16) {                                                     // block-uniform: the share stays in registers
+#pragma unroll
+        for (int j = 0; j < 16; ++j) keep[j] = col[(size_t)min(c_lo + j, c_last) * bins];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { keep[j] = c_lo + j < c_hi ? keep[j] : 0u; sum += keep[j]; }
+    } else {
+        for (int c0 = c_lo; c0 < c_hi; c0 += 16) {                     // sixteen independent loads in flight (clamped rows)
+            uint32_t v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = col[(size_t)min(c0 + j, c_last) * bins];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) sum += c0 + j < c_hi ? v[j] : 0u;
         }
-        for (; c < c_hi; ++c) sum += cnt[(size_t)c * bins + b];
     }
-    part[w][lane] = sum;
+    part[w][lane] = on ? sum : 0u;
     __syncthreads();
     uint32_t run = 0, all = 0;
 #pragma unroll
     for (int ww = 0; ww < 16; ++ww) { const uint32_t v = part[ww][lane]; run += ww < w ? v : 0u; all += v; }
-    if (b < bins) {
-        for (int c = c_lo; c < c_hi; ++c) {
-            const uint32_t v = cnt[(size_t)c * bins + b];
-            cnt[(size_t)c * bins + b] = run;
-            run += v;
+    if (S <= 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (on && c_lo + j < c_hi) { col[(size_t)(c_lo + j) * bins] = run; run += keep[j]; }
         }
-        if (w == 0) tot[b] = all;
+    } else {
+        for (int c0 = c_lo; c0 < c_hi; c0 += 16) {
+            uint32_t v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = col[(size_t)min(c0 + j, c_last) * bins];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (on && c0 + j < c_hi) { col[(size_t)(c0 + j) * bins] = run; run += v[j]; }
+            }
+        }
     }
+    if (on && w == 0) segtot[(size_t)seg * bins + b] = all;
     if (total_out && w == 0) {
-        const uint32_t s = wave_inclusive_scan(b < bins ? all : 0u);
+        const uint32_t s = wave_inclusive_scan(all);
         if (lane == 63 && s) atomicAdd(total_out, s);
     }
-}
-
-// exclusive scan of src[0 .. n) (global) into dst[0 .. n) (LDS) by an NT-thread block; *total = the sum
-template <int NT>
-__device__ __forceinline__ void block_scan_array(const uint32_t* __restrict__ src, uint32_t* dst, int n, uint32_t* scratch, uint32_t* total)
-{
-    const int tid = (int)threadIdx.x;
-    const int per = (n + NT - 1) / NT;
-    const int b0 = tid * per;
-    uint32_t sum = 0;
-    for (int j = 0; j < per; ++j) if (b0 + j < n) sum += src[b0 + j];
-    uint32_t ex = block_exclusive_scan<NT>(sum, scratch, total);
-    for (int j = 0; j < per; ++j) if (b0 + j < n) { const uint32_t v = src[b0 + j]; dst[b0 + j] = ex; ex += v; }
 }
 
 // Stable rank of this lane's item among the items of the same bin that precede it in the wave's share of the chunk:
@@ -198,187 +230,202 @@ __device__ __forceinline__ uint32_t wave_rank_step(bool valid, uint32_t bin, int
 }
 
 // ------------------------------------------------------------------------------------------
-// pass 1, scatter: the chunk's records go to  base1[bin] + (records of the bin in earlier chunks) + (stable rank in the chunk)
-// ------------------------------------------------------------------------------------------
-template <int SRC, int TS, bool ATTR, bool BATCH>
-__global__ __launch_bounds__(1024) void k_sort_scatter1(SortArgs a)
-{
-    constexpr int NT = 1024, NW = NT / 64, K = kSortK, CH = NT * K, D0 = 1 << (2 * TS);
-    static_assert(D0 == NT, "one low-digit bin per thread");
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_sort[];
-    uint32_t* wcnt = lds_sort;                                         // [NW][D0]
-    uint32_t* scratch = wcnt + NW * D0;                                // [16]
-    const int tid = (int)threadIdx.x, lane = lane_id(), w = tid >> 6, chunk = (int)blockIdx.x;
-    const uint64_t lt = lanemask_lt();
-    for (int i = tid; i < NW * D0; i += NT) wcnt[i] = 0u;
-    const ChunkRange cr = chunk_range<BATCH, CH>(a, chunk);
-    const FrameConst& fc = BATCH ? a.frames[cr.sweep] : a.frame0;
-    const long long base = cr.first + (long long)w * (K * 64) + lane;
-    float4 p[K]; bool live[K];
-    if (SRC == 0) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const long long i = base + k * 64;
-            live[k] = i < cr.end;
-            p[k] = a.xyzi[live[k] ? i : cr.first];
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < K; ++k) { live[k] = base + k * 64 < cr.end; p[k] = make_float4(0.f, 0.f, 0.f, 0.f); }
-    }
-    const uint32_t colpre = a.cnt1[(size_t)chunk * D0 + tid];          // records of bin `tid` in earlier chunks (k_sort_scan)
-    const uint32_t tot = a.tot1[tid];
-    __syncthreads();
-    // ---- 1. stable rank inside the wave's share, per-wave counts
-    uint32_t key[K], rk[K]; float hh[K], vv[K]; bool ok[K], cok[K];
-    uint32_t* wcur = wcnt + w * D0;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const long long i = base + k * 64;
-        const Binned b = bin_one<SRC, TS>(a, fc, live[k], p[k], i, (int)i + cr.orig0);
-        ok[k] = b.valid; hh[k] = b.h; vv[k] = b.v; cok[k] = b.colour_ok;
-        key[k] = b.cell | (b.tile << (2 * TS)) | ((uint32_t)cr.sweep << a.sweep_shift);
-        rk[k] = wave_rank_step(b.valid, b.cell, 2 * TS, wcur, lt);
-    }
-    __syncthreads();
-    // ---- 2. bin `tid`: global base + earlier chunks, then the waves of this chunk in order
-    {
-        uint32_t all;
-        uint32_t g = block_exclusive_scan<NT>(tot, scratch, &all) + colpre;
-#pragma unroll
-        for (int ww = 0; ww < NW; ++ww) { const uint32_t c = wcnt[ww * D0 + tid]; wcnt[ww * D0 + tid] = g; g += c; }
-    }
-    __syncthreads();
-    // ---- 3. records to their places
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        if (ok[k]) {
-            const uint32_t cell = key[k] & (uint32_t)(D0 - 1);
-            const uint32_t pos = wcur[cell] + rk[k];
-            a.hv1[pos] = make_uint2(__float_as_uint(hh[k]), __float_as_uint(vv[k]));
-            a.key1[pos] = key[k];
-            if (ATTR) a.src1[pos] = (uint32_t)(base + k * 64) | (cok[k] ? 0x80000000u : 0u);   // source point; bit 31: all of R, G, B, intensity non-zero
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// pass 2 (high digit = tile) over the records of pass 1
+// count + scatter of one digit (both passes), chunks of kSortChunk records.  Pass 1 reads the input-ordered records of
+// k_sort_project (sweep-aligned chunks, rejected points carry an invalid key); pass 2 reads the output of pass 1.
 // ------------------------------------------------------------------------------------------
 template <int NT>
-__global__ __launch_bounds__(NT) void k_sort_count2(SortArgs a)
+__global__ __launch_bounds__(NT) void k_sort_count(PassArgs a)
 {
-    constexpr int K = kSortK, CH = NT * K;
+    constexpr int CH = kSortChunk, K = CH / NT;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_sort[];
-    uint32_t* hist = lds_sort;                                         // [T]
+    uint32_t* hist = lds_sort;                                         // [bins]
     const int tid = (int)threadIdx.x, chunk = (int)blockIdx.x;
-    const uint32_t M = *a.total;
+    const uint32_t M = *a.n_dev;
     if ((unsigned long long)chunk * CH >= M) return;                   // k_sort_scan only reads the rows of live chunks
-    for (int i = tid; i < a.T; i += NT) hist[i] = 0u;
+    for (int i = tid; i < a.bins; i += NT) hist[i] = 0u;
     const uint32_t base = (uint32_t)chunk * CH + (uint32_t)(tid >> 6) * (K * 64) + (uint32_t)(tid & 63);
     uint32_t key[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) { const uint32_t i = base + k * 64; key[k] = a.key1[i < M ? i : M - 1u]; }
+    for (int k = 0; k < K; ++k) { const uint32_t i = base + k * 64; key[k] = a.key_in[i < M ? i : M - 1u]; }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < K; ++k) if (base + k * 64 < M) atomicAdd(&hist[(key[k] >> a.cell_bits) & a.tile_mask], 1u);
+    for (int k = 0; k < K; ++k) if (base + k * 64 < M) atomicAdd(&hist[(key[k] >> a.shift) & a.mask], 1u);
     __syncthreads();
-    for (int i = tid; i < a.T; i += NT) a.cnt2[(size_t)chunk * a.T + i] = hist[i];
+    for (int i = tid; i < a.bins; i += NT) a.cnt[(size_t)chunk * a.bins + i] = hist[i];
 }
 
+// The chunk's records are ranked (stable), put into LDS in their sorted order and written out from there: consecutive threads
+// then write consecutive records of a bin -- runs of several records, 64-byte segments -- instead of 64 lanes writing 64
+// scattered 8-byte pieces (which cost 55 us for the 2.9 M records of C4 against 24 from LDS).
 template <int NT, bool ATTR>
-__global__ __launch_bounds__(NT) void k_sort_scatter2(SortArgs a)
+__global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void k_sort_scatter(PassArgs a)
 {
-    constexpr int NW = NT / 64, K = kSortK, CH = NT * K;
+    constexpr int NW = NT / 64, CH = kSortChunk, K = CH / NT;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_sort[];
-    const int T = a.T;
-    uint32_t* gbase = lds_sort;                                        // [T]     first record of every tile
-    uint32_t* wcnt = gbase + T;                                        // [NW][T]
-    uint32_t* scratch = wcnt + NW * T;                                 // [16]
+    const int bins = a.bins;
+    uint32_t* lbase = lds_sort;                                        // [bins] first LOCAL (chunk-sorted) position of every bin
+    uint32_t* delta = lbase + bins;                                    // [bins] global position - local position
+    uint32_t* scratch = delta + bins;                                  // [16]
+    uint32_t* region = scratch + 16;                                   // per-wave cursors, then (aliased) the staged records
+    uint32_t* wcnt = region;                                           // [NW][bins]
+    uint2* st_hv = reinterpret_cast<uint2*>(region);                   // [CH]
+    uint32_t* st_key = region + 2 * CH;                                // [CH]
+    uint32_t* st_src = region + 3 * CH;                                // [CH] (ATTR)
     const int tid = (int)threadIdx.x, lane = lane_id(), w = tid >> 6, chunk = (int)blockIdx.x;
     const uint64_t lt = lanemask_lt();
-    const uint32_t M = *a.total;
-    const bool live_chunk = (unsigned long long)chunk * CH < M;
-    if (!live_chunk && chunk != 0) return;                             // workgroup 0 always publishes the tile bases
-    for (int i = tid; i < NW * T; i += NT) wcnt[i] = 0u;
-    const uint32_t base = (uint32_t)chunk * CH + (uint32_t)w * (K * 64) + (uint32_t)lane;
+    long long first, end;
+    if (a.n_dev) { first = (long long)chunk * CH; end = (long long)*a.n_dev; }
+    else { const ChunkRange cr = chunk_range<CH>(a.sweep_chunk0, a.sweep_first, nullptr, a.n_sweeps, a.n_host, chunk); first = cr.first; end = cr.end; }
+    if (first >= end && !(a.bin_base && chunk == 0)) return;           // workgroup 0 of the last pass always publishes the bin bases
+    for (int i = tid; i < NW * bins; i += NT) wcnt[i] = 0u;
+    const long long base = first + (long long)w * (K * 64) + lane;
     uint2 hv[K]; uint32_t key[K], src[K], rk[K];
-    if (live_chunk) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const uint32_t i = base + k * 64, ic = i < M ? i : M - 1u;
-            key[k] = a.key1[ic]; hv[k] = a.hv1[ic];
-            if (ATTR) src[k] = a.src1[ic];
-        }
+    for (int k = 0; k < K; ++k) {
+        const long long i = base + k * 64, ic = i < end ? i : first;
+        key[k] = a.key_in[ic]; hv[k] = a.hv_in[ic];
+        if (ATTR) src[k] = a.src_in[ic];
+        if (i >= end) key[k] = kKeyInvalid;
     }
     __syncthreads();
-    if (live_chunk) {
-        uint32_t* wcur = wcnt + w * T;
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-            rk[k] = wave_rank_step(base + k * 64 < M, (key[k] >> a.cell_bits) & a.tile_mask, a.tile_bits, wcur, lt);
-    }
-    __syncthreads();
+    // ---- 1. stable rank inside the wave's share, per-wave counts
     {
-        uint32_t all;
-        block_scan_array<NT>(a.tot2, gbase, T, scratch, &all);
-        __syncthreads();
-        if (chunk == 0) {
-            for (int i = tid; i < T; i += NT) a.tile_base[i] = gbase[i];
-            if (tid == 0) { a.tile_base[T] = all; if (a.counters) atomicAdd(&a.counters[0], (unsigned long long)all); }
-        }
-        if (live_chunk) {
-            for (int b = tid; b < T; b += NT) {
-                uint32_t g = gbase[b] + a.cnt2[(size_t)chunk * T + b];
+        uint32_t* wcur = wcnt + w * bins;
 #pragma unroll
-                for (int ww = 0; ww < NW; ++ww) { const uint32_t c = wcnt[ww * T + b]; wcnt[ww * T + b] = g; g += c; }
+        for (int k = 0; k < K; ++k) rk[k] = wave_rank_step(key[k] != kKeyInvalid, (key[k] >> a.shift) & a.mask, a.digit_bits, wcur, lt);
+    }
+    __syncthreads();
+    // ---- 2. per bin: the waves in order (exclusive prefix), the chunk's local base, the way from local to global positions
+    {
+        const int per = (bins + NT - 1) / NT, b0 = tid * per;
+        uint32_t sum = 0;
+        for (int j = 0; j < per; ++j) {
+            const int b = b0 + j;
+            if (b < bins) {
+                uint32_t run = 0;
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww) { const uint32_t c = wcnt[ww * bins + b]; wcnt[ww * bins + b] = run; run += c; }
+                lbase[b] = run;                                        // the bin's records in this chunk, for now
+                sum += run;
             }
+        }
+        uint32_t chunk_records, all;
+        uint32_t ex = block_exclusive_scan<NT>(sum, scratch, &chunk_records);
+        // the bin's records in the whole pass / in the chunk segments before this chunk's (k_sort_scan)
+        const int nc = a.n_dev ? (int)((end + CH - 1) / CH) : a.n_chunks;
+        const int seg = chunk / scan_seg_chunks(nc);
+        auto bin_sums = [&](int b, uint32_t& before) -> uint32_t {
+            uint32_t t = 0; before = 0;
+#pragma unroll
+            for (int sg = 0; sg < kScanSegs; ++sg) { const uint32_t v = a.segtot[(size_t)sg * bins + b]; before += sg < seg ? v : 0u; t += v; }
+            return t;
+        };
+        uint32_t gsum = 0;
+        for (int j = 0; j < per; ++j) if (b0 + j < bins) { uint32_t bf; gsum += bin_sums(b0 + j, bf); }
+        uint32_t gex = block_exclusive_scan<NT>(gsum, scratch, &all);  // first record of the bin in the pass's output
+        for (int j = 0; j < per; ++j) {
+            const int b = b0 + j;
+            if (b < bins) {
+                const uint32_t c = lbase[b];
+                uint32_t before; const uint32_t tb = bin_sums(b, before);
+                lbase[b] = ex;
+                delta[b] = gex + before + a.cnt[(size_t)chunk * bins + b] - ex;   // bin base + earlier segments + earlier chunks - local position
+                if (a.bin_base && chunk == 0) a.bin_base[b] = gex;
+                ex += c; gex += tb;
+            }
+        }
+        if (tid == 0) {
+            scratch[15] = chunk_records;
+            if (a.bin_base && chunk == 0) { a.bin_base[bins] = all; if (a.counters) atomicAdd(&a.counters[0], (unsigned long long)all); }
         }
     }
     __syncthreads();
-    if (live_chunk) {
-        const uint32_t* wcur = wcnt + w * T;
+    // ---- 3. local position of every record (the cursors are read for the last time)
+    {
+        const uint32_t* wcur = wcnt + w * bins;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            if (base + k * 64 < M) {
-                const uint32_t pos = wcur[(key[k] >> a.cell_bits) & a.tile_mask] + rk[k];
-                a.hv2[pos] = hv[k];
-                a.key2[pos] = key[k];
-                if (ATTR) a.src2[pos] = src[k];
-            }
+            const uint32_t bin = (key[k] >> a.shift) & a.mask;
+            rk[k] = key[k] != kKeyInvalid ? lbase[bin] + wcur[bin] + rk[k] : 0xffffffffu;
+        }
+    }
+    const uint32_t chunk_records = scratch[15];
+    __syncthreads();
+    // ---- 4. the records in chunk-sorted order in LDS (over the cursors)
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (rk[k] != 0xffffffffu) {
+            st_hv[rk[k]] = hv[k]; st_key[rk[k]] = key[k];
+            if (ATTR) st_src[rk[k]] = src[k];
+        }
+    }
+    __syncthreads();
+    // ---- 5. out, consecutive threads = consecutive records of a bin
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t j = (uint32_t)(tid + k * NT);
+        if (j < chunk_records) {
+            const uint32_t kk = st_key[j];
+            const uint32_t pos = j + delta[(kk >> a.shift) & a.mask];
+            a.hv_out[pos] = st_hv[j];
+            a.key_out[pos] = kk;
+            if (ATTR) a.src_out[pos] = st_src[j];
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// k_fuse_walk : one workgroup per 32x32 tile, one thread per cell
+// k_fuse_walk : one wave per 64 consecutive cells (two rows of a 32x32 tile), one lane per cell
 // ------------------------------------------------------------------------------------------
 // FLAGS: bits 0-1 = ATTR (0 none, 1 colours from the cloud, 2 colours from gem_fuse's arrays), bit 2 = LOWEST (also maintain
 // map_lowest, GPU:432-439).  MODE: bit 0 = variance increments between the sweeps (batched call with var_updates), bit 1 =
 // count the touched cells per sweep (statistics).
 constexpr int kWalkMaxSweeps = 512;
 
-template <int TS, int FLAGS, int MODE>
-__global__ __launch_bounds__(1024) void k_fuse_walk(WalkArgs a)
+template <int FLAGS, int MODE>
+__global__ __launch_bounds__(64) void k_fuse_walk(WalkArgs a)
 {
     constexpr int ATTR = FLAGS & 3;
     constexpr bool LOWEST = (FLAGS & 4) != 0;
     constexpr bool HAS_VU = (MODE & 1) != 0, COUNT_SWEEPS = (MODE & 2) != 0, KEYED = HAS_VU || COUNT_SWEEPS;
-    constexpr int TE = 1 << TS, CELLS = TE * TE, NT = 1024;
-    static_assert(CELLS == NT, "one cell per thread");
-    __shared__ uint32_t cstart[CELLS], cend[CELLS];
+    __shared__ uint32_t cstart[64], cend[64];
     __shared__ float vu[HAS_VU ? kWalkMaxSweeps : 1];
-    __shared__ uint32_t n_touched;
-    const int tid = (int)threadIdx.x, lane = lane_id(), w = tid >> 6;
-    const int tile = (int)blockIdx.x;
-    const uint32_t rb = a.tile_base[tile], re = a.tile_base[tile + 1];
-    if (rb == re && !a.dense) return;                                  // nothing reaches this tile and nothing is pending
+    const int lane = (int)threadIdx.x;
+    // Block -> group of 64 cells through a stride permutation (walk_stride is coprime with the number of groups): the groups
+    // under the sensor carry chains a hundred times longer than the rim's, and neighbours in index would land on neighbouring
+    // SIMDs, which then issue two or three long chains each while the rest of the chip idles (measured: 89 -> 4x us on C4).
+    const uint32_t grp = (uint32_t)(((unsigned long long)blockIdx.x * (unsigned)a.walk_stride) % (unsigned)gridDim.x);
+    const int tile = (int)(grp >> 4), q = (int)(grp & 15);
+    const uint32_t idmask = (1u << a.id_bits) - 1u;
+    const uint32_t id0 = ((uint32_t)tile << 10) | ((uint32_t)q << 6);  // the cell ids of this wave: id0 .. id0 + 63
+    // the records of these cells lie inside the run of the pass-2 bin that holds id0 (64 divides the bin width)
+    const uint32_t bin = id0 >> a.bin_shift;
+    const uint32_t run_lo = a.bin_base[bin], run_hi = a.bin_base[bin + 1];
+    if (run_lo == run_hi && !a.dense) return;
+    // ---- 32-ary search, both ends at once: lanes 0-31 look for the first record with id >= id0, lanes 32-63 for id >= id0 + 64
+    uint32_t lo = run_lo, hi = run_hi;                                 // ids below `lo` are < target, ids from `hi` on are >= target
+    {
+        const uint32_t target = id0 + (uint32_t)(lane >> 5) * 64u, l5 = (uint32_t)lane & 31u;
+        while (__ballot(lo < hi) != 0) {                               // wave-uniform
+            const uint32_t n = hi - lo, s = (n + 32u) / 33u;           // probes lo + j s + s - 1, j = 0..31
+            const uint32_t pos = lo + l5 * s + s - 1u;
+            const bool probe = lo < hi && pos < hi;
+            const uint32_t id = probe ? (a.key[pos] & idmask) : 0xffffffffu;
+            const uint64_t bl = __ballot(probe && id < target);
+            const uint32_t k = (uint32_t)__popc((uint32_t)(bl >> (lane & 32)));   // a prefix of the probes: the ids are sorted
+            // probes 0 .. k-1 are below the target, probe k (if there is one: k < 32 and inside the range) is not
+            if (lo < hi) { const uint32_t nl = lo + k * s; if (k < 32u) hi = min(hi, nl + s - 1u); lo = nl; }
+        }
+    }
+    const uint32_t rb = (uint32_t)__shfl((int)lo, 0, 64), re = (uint32_t)__shfl((int)lo, 32, 64);
+    if (rb == re && !a.dense) return;                                  // nothing reaches these cells and nothing is pending
+
     const int tr = tile / a.tiles_per_row, tc = tile - tr * a.tiles_per_row;
-    const int row = (tr << TS) + (tid >> TS), col = (tc << TS) + (tid & (TE - 1));
+    const int row = (tr << 5) + (q << 1) + (lane >> 5), col = (tc << 5) + (lane & 31);
     const int L = a.L;
     const bool owned = row >= a.row0 && row < a.row1 && col < L;
     const size_t g = owned ? (size_t)row * L + col : 0;
-    const float e0 = a.elevation[g], s0 = a.variance[g];               // in flight behind the boundary search
+    const float e0 = a.elevation[g], s0 = a.variance[g];               // in flight behind the boundary scan
     size_t lgeo = 0; float lw = 0.0f, lw0 = 0.0f;
     if constexpr (LOWEST) {                                            // map_lowest is indexed by the GEOGRAPHIC cell (GPU:430)
         int gr = row - a.start0, gc = col - a.start1;
@@ -386,23 +433,34 @@ __global__ __launch_bounds__(1024) void k_fuse_walk(WalkArgs a)
         lgeo = owned ? (size_t)gr * L + gc : 0;
         lw0 = lw = a.lowest[lgeo];
     }
-    cstart[tid] = 0u; cend[tid] = 0u;
-    if (tid == 0) n_touched = 0u;
-    if constexpr (HAS_VU) for (int i = tid; i < a.n_sweeps; i += NT) vu[i] = a.var_updates[i];
+    cstart[lane] = 0u; cend[lane] = 0u;
+    if constexpr (HAS_VU) for (int i = lane; i < a.n_sweeps; i += 64) vu[i] = a.var_updates[i];
     __syncthreads();
-    // ---- cell boundaries of the tile's run: the keys are sorted by cell, so a cell starts where the key's cell changes
-    for (uint32_t p0 = rb + (uint32_t)w * 64u; p0 < re; p0 += NT) {    // wave-uniform
-        const uint32_t p = p0 + (uint32_t)lane;
-        const bool live = p < re;
-        const uint32_t cell = live ? (a.key[p] & (uint32_t)(CELLS - 1)) : 0xfffffffeu;
-        uint32_t prev = (uint32_t)__shfl_up((int)cell, 1, 64), next = (uint32_t)__shfl_down((int)cell, 1, 64);
-        if (lane == 0)  prev = p > rb ? (a.key[p - 1] & (uint32_t)(CELLS - 1)) : 0xffffffffu;
-        if (lane == 63) next = p + 1u < re ? (a.key[p + 1] & (uint32_t)(CELLS - 1)) : 0xffffffffu;
-        if (live && cell != prev) cstart[cell] = p;
-        if (live && cell != next) cend[cell] = p + 1u;
+    // ---- cell boundaries of the wave's run: the records are sorted by cell, so a cell starts -- and the one before it ends --
+    //      where the key's cell changes.  Eight loads in flight per round: the run of a wave under the sensor is thousands of
+    //      records long, and one load per round made this loop a chain of memory latencies (half of the kernel's time).
+    {
+        constexpr int U = 8;
+        uint32_t carry = 0xffffffffu;                                  // cell of the record before the round's first (wave-uniform)
+        for (uint32_t p0 = rb; p0 < re; p0 += 64u * U) {               // wave-uniform
+            uint32_t c[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const uint32_t p = p0 + 64u * u + (uint32_t)lane; c[u] = a.key[min(p, re - 1u)] & 63u; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t p = p0 + 64u * u + (uint32_t)lane;
+                const bool live = p < re;
+                const uint32_t cell = live ? c[u] : 0xfffffffeu;
+                uint32_t prev = (uint32_t)__shfl_up((int)cell, 1, 64);
+                if (lane == 0) prev = carry;
+                carry = (uint32_t)__builtin_amdgcn_readlane((int)cell, 63);
+                if (live && cell != prev) { cstart[cell] = p; if (prev < 64u) cend[prev] = p; }
+                if (p + 1u == re) cend[cell] = re;
+            }
+        }
     }
     __syncthreads();
-    const uint32_t first = cstart[tid], n = cend[tid] - first;
+    const uint32_t first = cstart[lane], n = cend[lane] - first;
 
     float ce = e0, cs = s0;
     // Mapvar_update increments queued before this pass, then the one of sweep 0 (GPU:540-547)
@@ -418,52 +476,64 @@ __global__ __launch_bounds__(1024) void k_fuse_walk(WalkArgs a)
         }
     };
     uint32_t wlast = 0xffffffffu, sweeps_seen = 0, last_sweep = 0xffffffffu;
-    {   // the cell's own run, the records D steps ahead in flight (clamped address: never a branch round a load)
-        constexpr int D = 4;
-        const uint32_t nm1 = n ? n - 1u : 0u;
+    {   // The cell's own run.  The 64 lanes read 64 different streams, and a wave load whose lanes fall into 64 different cache
+        // lines occupies the CU's vector L1 for 64 cycles whatever its width: with one 8-byte and one 4-byte load per step the
+        // waves of a CU queue up at the L1 (125 us for the 32 sweeps of C4).  So the records come in GROUPS of four steps, as
+        // 16-byte loads -- two {h, var} pairs, four keys per request: 0.75 requests per step instead of 2 -- and three groups
+        // are in flight (the address is clamped to the lane's last group: never a branch round a load; the arrays are padded).
+        struct __attribute__((packed, aligned(4))) Quad { uint32_t x, y, z, w; };
+        struct Group { Quad h01, h23, k4, s4; };
+        const uint32_t nmax = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_max(n), 63);    // the wave's longest run: no loads beyond it
+        const uint32_t glast = n ? (n - 1u) >> 2 : 0u;
         const uint2* hp = a.hv + (n ? first : 0u);
         const uint32_t* kp = a.key + (n ? first : 0u);
         const uint32_t* sp = a.src + (n ? first : 0u);
-        uint2 pre_hv[D]; uint32_t pre_k[D], pre_s[D];
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-            const uint32_t j = min((uint32_t)k, nm1);
-            pre_hv[k] = hp[j];
-            if (KEYED) pre_k[k] = kp[j];
-            if (ATTR) pre_s[k] = sp[j];
-        }
-        for (uint32_t i = 0; __ballot(i < n) != 0; i += D) {           // wave-uniform
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-                const uint2 cur_hv = pre_hv[k];
-                const uint32_t cur_k = KEYED ? pre_k[k] : 0u, cur_s = ATTR ? pre_s[k] : 0u;
-                const uint32_t idx = i + (uint32_t)k;
-                const uint32_t j = min(idx + D, nm1);
-                pre_hv[k] = hp[j];
-                if (KEYED) pre_k[k] = kp[j];
-                if (ATTR) pre_s[k] = sp[j];
-                const bool live = idx < n;
-                const float h = __uint_as_float(cur_hv.x), v = __uint_as_float(cur_hv.y);
-                if constexpr (KEYED) {
-                    const uint32_t sw = cur_k >> a.sweep_shift;
-                    if constexpr (HAS_VU) { if (live) advance(sw); }
-                    if constexpr (COUNT_SWEEPS) { if (live && sw != last_sweep) { ++sweeps_seen; last_sweep = sw; } }
-                }
-                float e2 = ce, s2 = cs;
-                const bool taken = fuse_step(e2, s2, h, v, a.mahal, a.var_floor);
-                const bool fl = live && (!LOWEST || h != -1.0f);       // GPU:482 (only LOWEST passes carry such records)
-                ce = fl ? e2 : ce; cs = fl ? s2 : cs;
-                if constexpr (LOWEST) { const float l2 = lowest_step(lw, h, v); lw = live ? l2 : lw; }
-                if constexpr (ATTR != 0) { if (fl && taken && (cur_s & 0x80000000u)) wlast = cur_s & 0x7fffffffu; }
+        auto load_group = [&](uint32_t g, Group& G) {
+            if (4u * g < nmax) {                                       // wave-uniform
+                const uint32_t r = 4u * min(g, glast);
+                G.h01 = *reinterpret_cast<const Quad*>(hp + r);
+                G.h23 = *reinterpret_cast<const Quad*>(hp + r + 2u);
+                if (KEYED) G.k4 = *reinterpret_cast<const Quad*>(kp + r);
+                if (ATTR) G.s4 = *reinterpret_cast<const Quad*>(sp + r);
             }
+        };
+        auto step = [&](uint32_t idx, uint32_t hb, uint32_t vb, uint32_t cur_k, uint32_t cur_s) {
+            const bool live = idx < n;
+            const float h = __uint_as_float(hb), v = __uint_as_float(vb);
+            if constexpr (KEYED) {
+                const uint32_t sw = cur_k >> a.id_bits;
+                if constexpr (HAS_VU) { if (live) advance(sw); }
+                if constexpr (COUNT_SWEEPS) { if (live && sw != last_sweep) { ++sweeps_seen; last_sweep = sw; } }
+            }
+            float e2 = ce, s2 = cs;
+            const bool taken = fuse_step(e2, s2, h, v, a.mahal, a.var_floor);
+            const bool fl = live && (!LOWEST || h != -1.0f);           // GPU:482 (only LOWEST passes carry such records)
+            ce = fl ? e2 : ce; cs = fl ? s2 : cs;
+            if constexpr (LOWEST) { const float l2 = lowest_step(lw, h, v); lw = live ? l2 : lw; }
+            if constexpr (ATTR != 0) { if (fl && taken && (cur_s & 0x80000000u)) wlast = cur_s & 0x7fffffffu; }
+        };
+        auto run_group = [&](uint32_t i0, const Group& G) {
+            step(i0, G.h01.x, G.h01.y, G.k4.x, G.s4.x);
+            step(i0 + 1u, G.h01.z, G.h01.w, G.k4.y, G.s4.y);
+            step(i0 + 2u, G.h23.x, G.h23.y, G.k4.z, G.s4.z);
+            step(i0 + 3u, G.h23.z, G.h23.w, G.k4.w, G.s4.w);
+        };
+        Group A{}, B{}, C{};
+        load_group(0u, A); load_group(1u, B); load_group(2u, C);
+        for (uint32_t g = 0; 4u * g < nmax; g += 3u) {                 // wave-uniform
+            run_group(4u * g, A);       load_group(g + 3u, A);
+            if (4u * g + 4u >= nmax) break;
+            run_group(4u * g + 4u, B);  load_group(g + 4u, B);
+            if (4u * g + 8u >= nmax) break;
+            run_group(4u * g + 8u, C);  load_group(g + 5u, C);
         }
     }
     if constexpr (HAS_VU) advance((uint32_t)a.n_sweeps - 1u);
     if (cs < a.var_floor) cs = a.var_floor;                            // GPU:533-534, on every cell
 
     if (owned) {
-        // only what changed goes back (a sweep touches a fraction of a tile's cells; whole-tile write-backs were most of the
-        // write traffic of the tile kernels)
+        // only what changed goes back (a pass touches a fraction of the cells; whole-tile write-backs were most of the write
+        // traffic of the tile kernels)
         if (__float_as_uint(ce) != __float_as_uint(e0)) a.elevation[g] = ce;
         if (__float_as_uint(cs) != __float_as_uint(s0)) a.variance[g] = cs;
         if constexpr (LOWEST) { if (__float_as_uint(lw) != __float_as_uint(lw0)) a.lowest[lgeo] = lw; }
@@ -483,9 +553,7 @@ __global__ __launch_bounds__(1024) void k_fuse_walk(WalkArgs a)
     if (a.counters) {                                                  // distinct touched cells: per pass, or summed over the sweeps
         const uint32_t mine = COUNT_SWEEPS ? sweeps_seen : (n ? 1u : 0u);
         const uint32_t s = wave_inclusive_scan(mine);
-        if (lane == 63 && s) atomicAdd(&n_touched, s);
-        __syncthreads();
-        if (tid == 0 && n_touched) atomicAdd(&a.counters[1], (unsigned long long)n_touched);
+        if (lane == 63 && s) atomicAdd(&a.counters[1], (unsigned long long)s);
     }
 }
 
@@ -498,90 +566,106 @@ __global__ __launch_bounds__(1024) void k_fuse_walk(WalkArgs a)
         else hipLaunchKernelGGL(k, grid, block, lds, st, __VA_ARGS__);                             \
     } while (0)
 
-int sort_pass2_threads(int T)
+// Threads of the count / scatter workgroups of a pass with `bins` bins.  LDS of k_sort_scatter: 2 bins + 16 words + the larger of
+// the per-wave cursors (threads / 64 * bins) and the staged chunk (3 or 4 words per record).
+SortShape sort_shape(int bins, bool attr)
 {
-    // LDS of k_sort_scatter2 = (T + T * NT / 64 + 16) words: 1024 threads while two workgroups fit a CU, fewer waves for big maps
-    if (T <= 900) return 1024;
-    if (T <= 1800) return 512;
-    return 256;
+    SortShape s;
+    const size_t stage = (size_t)(attr ? 4 : 3) * kSortChunk;
+    s.nt = (size_t)8 * bins <= stage + 2048 ? 512 : 256;              // eight waves while their cursors fit under the stage
+    s.chunk = kSortChunk;
+    s.lds = ((size_t)2 * bins + 16 + std::max((size_t)(s.nt / 64) * bins, stage)) * 4;
+    return s;
 }
 
-static size_t scatter2_lds(int T, int nt) { return ((size_t)T * (1 + nt / 64) + 16) * 4; }
-
 // more than 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel and device
-static hipError_t lds_opt_in(const void* fn, size_t lds, int slot)
+static hipError_t lds_opt_in(const void* fn, size_t lds)
 {
     if (lds <= 64 * 1024) return hipSuccess;
-    constexpr int kMaxDev = 64, kSlots = 8;
+    constexpr int kMaxDev = 64, kSlots = 32;
     static std::mutex mu;
+    static const void* fns[kSlots] = {};
     static size_t configured[kMaxDev][kSlots] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lk(mu);
-    if (dev < 0 || dev >= kMaxDev || lds > configured[dev][slot]) {
+    int slot = -1;
+    for (int i = 0; i < kSlots; ++i) { if (fns[i] == fn) { slot = i; break; } if (!fns[i]) { fns[i] = fn; slot = i; break; } }
+    if (dev < 0 || dev >= kMaxDev || slot < 0 || lds > configured[dev][slot]) {
         e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < kMaxDev) configured[dev][slot] = lds;
+        if (dev >= 0 && dev < kMaxDev && slot >= 0) configured[dev][slot] = lds;
     }
     return hipSuccess;
 }
 
-template <int SRC, bool ATTR, bool BATCH>
-static hipError_t launch_sort_pass1(hipStream_t st, const SortArgs& a, LaunchEvents ev_count, LaunchEvents ev_scan, LaunchEvents ev_scatter)
+static hipError_t launch_project(hipStream_t st, const SortArgs& a, int src, LaunchEvents ev)
 {
-    constexpr int TS = 5, D0 = 1 << (2 * TS);
-    GEM_LAUNCH((k_sort_count1<SRC, TS, BATCH>), dim3(a.n_chunks1), dim3(1024), 0, st, ev_count, a);
-    GEM_LAUNCH(k_sort_scan, dim3(D0 / 64), dim3(1024), 0, st, ev_scan, a.cnt1, a.tot1, D0, a.n_chunks1, (const uint32_t*)nullptr, 0, a.total);
-    const size_t lds = ((size_t)16 * D0 + 16) * 4;
-    hipError_t e = lds_opt_in((const void*)k_sort_scatter1<SRC, TS, ATTR, BATCH>, lds, (SRC ? 1 : 0) | (ATTR ? 2 : 0) | (BATCH ? 4 : 0));
-    if (e != hipSuccess) return e;
-    GEM_LAUNCH((k_sort_scatter1<SRC, TS, ATTR, BATCH>), dim3(a.n_chunks1), dim3(1024), lds, st, ev_scatter, a);
+    const size_t lds = (size_t)a.bins0 * 4;
+    if (src == 0)      GEM_LAUNCH((k_sort_project<0>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
+    else if (src == 2) GEM_LAUNCH((k_sort_project<2>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
+    else               GEM_LAUNCH((k_sort_project<1>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
     return hipGetLastError();
 }
 
-template <int NT, bool ATTR>
-static hipError_t launch_sort_pass2(hipStream_t st, const SortArgs& a, LaunchEvents ev_count, LaunchEvents ev_scan, LaunchEvents ev_scatter)
+template <int NT>
+static hipError_t launch_pass_nt(hipStream_t st, const PassArgs& p, bool attr, int grid, bool count, size_t lds, LaunchEvents ev)
 {
-    constexpr int CH = NT * kSortK;
-    const int grid = (int)((a.n + CH - 1) / CH);                       // upper bound: the live chunks are known on the device only
-    hipError_t e = lds_opt_in((const void*)k_sort_count2<NT>, (size_t)a.T * 4, 0);
-    if (e != hipSuccess) return e;
-    GEM_LAUNCH((k_sort_count2<NT>), dim3(grid), dim3(NT), (size_t)a.T * 4, st, ev_count, a);
-    GEM_LAUNCH(k_sort_scan, dim3((a.T + 63) / 64), dim3(1024), 0, st, ev_scan, a.cnt2, a.tot2, a.T, 0, (const uint32_t*)a.total, CH, (uint32_t*)nullptr);
-    const size_t lds = scatter2_lds(a.T, NT);
-    e = lds_opt_in((const void*)k_sort_scatter2<NT, ATTR>, lds, ATTR ? 1 : 0);
-    if (e != hipSuccess) return e;
-    GEM_LAUNCH((k_sort_scatter2<NT, ATTR>), dim3(grid > 0 ? grid : 1), dim3(NT), lds, st, ev_scatter, a);
+    hipError_t e;
+    if (count) {
+        GEM_LAUNCH((k_sort_count<NT>), dim3(grid), dim3(NT), (size_t)p.bins * 4, st, ev, p);
+        return hipGetLastError();
+    }
+    const void* fn = attr ? (const void*)k_sort_scatter<NT, true> : (const void*)k_sort_scatter<NT, false>;
+    if ((e = lds_opt_in(fn, lds)) != hipSuccess) return e;
+    if (attr) GEM_LAUNCH((k_sort_scatter<NT, true>), dim3(grid), dim3(NT), lds, st, ev, p);
+    else      GEM_LAUNCH((k_sort_scatter<NT, false>), dim3(grid), dim3(NT), lds, st, ev, p);
     return hipGetLastError();
+}
+
+static hipError_t launch_pass(hipStream_t st, const SortShape& sh, const PassArgs& p, bool attr, int grid, bool count, LaunchEvents ev)
+{
+    if (sh.nt == 512) return launch_pass_nt<512>(st, p, attr, grid, count, sh.lds, ev);
+    return launch_pass_nt<256>(st, p, attr, grid, count, sh.lds, ev);
 }
 
 hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, const LaunchEvents ev[6])
 {
     if (a.n <= 0 || a.n_chunks1 <= 0) return hipErrorInvalidValue;
-    const bool batch = a.n_sweeps > 1;
+    const SortShape s1 = sort_shape(a.bins0, attr), s2 = sort_shape(a.bins1, attr);
+    if (s1.lds > 160 * 1024 || s2.lds > 160 * 1024) return hipErrorInvalidValue;
     hipError_t e;
-#define GEM_P1(S, A, B) launch_sort_pass1<S, A, B>(st, a, ev[0], ev[1], ev[2])
-    if (src == 0) e = attr ? (batch ? GEM_P1(0, true, true) : GEM_P1(0, true, false)) : (batch ? GEM_P1(0, false, true) : GEM_P1(0, false, false));
-    else          e = attr ? (batch ? GEM_P1(1, true, true) : GEM_P1(1, true, false)) : (batch ? GEM_P1(1, false, true) : GEM_P1(1, false, false));
-#undef GEM_P1
-    if (e != hipSuccess) return e;
-    const int nt = sort_pass2_threads(a.T);
-    if (scatter2_lds(a.T, nt) > 160 * 1024) return hipErrorInvalidValue;
-    if (nt == 1024) return attr ? launch_sort_pass2<1024, true>(st, a, ev[3], ev[4], ev[5]) : launch_sort_pass2<1024, false>(st, a, ev[3], ev[4], ev[5]);
-    if (nt == 512)  return attr ? launch_sort_pass2<512, true>(st, a, ev[3], ev[4], ev[5]) : launch_sort_pass2<512, false>(st, a, ev[3], ev[4], ev[5]);
-    return attr ? launch_sort_pass2<256, true>(st, a, ev[3], ev[4], ev[5]) : launch_sort_pass2<256, false>(st, a, ev[3], ev[4], ev[5]);
+    // ---- pass 1: project + count, scan, scatter by the low digit (input order -> arrays b)
+    if ((e = launch_project(st, a, src, ev[0])) != hipSuccess) return e;
+    GEM_LAUNCH(k_sort_scan, dim3((a.bins0 + 63) / 64, kScanSegs), dim3(1024), 0, st, ev[1], a.cnt1, a.tot1, a.bins0, a.n_chunks1, (const uint32_t*)nullptr, a.total);
+    PassArgs p{};
+    p.hv_in = a.hv_a; p.key_in = a.key_a; p.src_in = a.src_a; p.hv_out = a.hv_b; p.key_out = a.key_b; p.src_out = a.src_b;
+    p.cnt = a.cnt1; p.segtot = a.tot1; p.n_chunks = a.n_chunks1; p.bins = a.bins0; p.shift = 0; p.digit_bits = a.d0_bits; p.mask = (uint32_t)a.bins0 - 1u;
+    p.n_dev = nullptr; p.n_host = a.n; p.sweep_chunk0 = a.sweep_chunk0; p.sweep_first = a.sweep_first; p.n_sweeps = a.n_sweeps;
+    p.bin_base = nullptr; p.counters = nullptr;
+    if ((e = launch_pass(st, s1, p, attr, a.n_chunks1, false, ev[2])) != hipSuccess) return e;
+    // ---- pass 2: count, scan, scatter by the high digit (arrays b -> arrays a); the live chunks are known on the device only
+    const int grid2 = (int)((a.n + kSortChunk - 1) / kSortChunk);
+    p.hv_in = a.hv_b; p.key_in = a.key_b; p.src_in = a.src_b; p.hv_out = a.hv_a; p.key_out = a.key_a; p.src_out = a.src_a;
+    p.cnt = a.cnt2; p.segtot = a.tot2; p.n_chunks = 0; p.bins = a.bins1; p.shift = a.d0_bits; p.digit_bits = a.id_bits - a.d0_bits;
+    p.mask = (1u << (a.id_bits - a.d0_bits)) - 1u;
+    p.n_dev = a.total; p.n_host = 0; p.sweep_chunk0 = nullptr; p.sweep_first = nullptr; p.n_sweeps = 1;
+    p.bin_base = a.bin_base; p.counters = a.counters;
+    if ((e = launch_pass(st, s2, p, attr, grid2, true, ev[3])) != hipSuccess) return e;
+    GEM_LAUNCH(k_sort_scan, dim3((a.bins1 + 63) / 64, kScanSegs), dim3(1024), 0, st, ev[4], a.cnt2, a.tot2, a.bins1, 0, (const uint32_t*)a.total, (uint32_t*)nullptr);
+    return launch_pass(st, s2, p, attr, grid2 > 0 ? grid2 : 1, false, ev[5]);
 }
 
 template <int FLAGS>
 static hipError_t launch_walk_f(hipStream_t st, const WalkArgs& a, int mode, LaunchEvents ev)
 {
-    const dim3 grid(a.T), block(1024);
+    const dim3 grid(a.T * 16), block(64);
     switch (mode) {
-    case 0:  GEM_LAUNCH((k_fuse_walk<5, FLAGS, 0>), grid, block, 0, st, ev, a); break;
-    case 1:  GEM_LAUNCH((k_fuse_walk<5, FLAGS, 1>), grid, block, 0, st, ev, a); break;
-    case 2:  GEM_LAUNCH((k_fuse_walk<5, FLAGS, 2>), grid, block, 0, st, ev, a); break;
-    default: GEM_LAUNCH((k_fuse_walk<5, FLAGS, 3>), grid, block, 0, st, ev, a); break;
+    case 0:  GEM_LAUNCH((k_fuse_walk<FLAGS, 0>), grid, block, 0, st, ev, a); break;
+    case 1:  GEM_LAUNCH((k_fuse_walk<FLAGS, 1>), grid, block, 0, st, ev, a); break;
+    case 2:  GEM_LAUNCH((k_fuse_walk<FLAGS, 2>), grid, block, 0, st, ev, a); break;
+    default: GEM_LAUNCH((k_fuse_walk<FLAGS, 3>), grid, block, 0, st, ev, a); break;
     }
     return hipGetLastError();
 }
