@@ -36,6 +36,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 
 namespace gem {
 
@@ -418,7 +419,8 @@ __global__ __launch_bounds__(64) void k_fuse_walk(WalkArgs a)
         }
     }
     const uint32_t rb = (uint32_t)__shfl((int)lo, 0, 64), re = (uint32_t)__shfl((int)lo, 32, 64);
-    if (rb == re && !a.dense) return;                                  // nothing reaches these cells and nothing is pending
+    if (rb == re && !a.dense) return;
+                                  // nothing reaches these cells and nothing is pending
 
     const int tr = tile / a.tiles_per_row, tc = tile - tr * a.tiles_per_row;
     const int row = (tr << 5) + (q << 1) + (lane >> 5), col = (tc << 5) + (lane & 31);
@@ -437,27 +439,33 @@ __global__ __launch_bounds__(64) void k_fuse_walk(WalkArgs a)
     if constexpr (HAS_VU) for (int i = lane; i < a.n_sweeps; i += 64) vu[i] = a.var_updates[i];
     __syncthreads();
     // ---- cell boundaries of the wave's run: the records are sorted by cell, so a cell starts -- and the one before it ends --
-    //      where the key's cell changes.  Eight loads in flight per round: the run of a wave under the sensor is thousands of
+    //      where the key's cell changes.  Sixteen loads in flight per round: the run of a wave under the sensor is thousands of
     //      records long, and one load per round made this loop a chain of memory latencies (half of the kernel's time).
     {
-        constexpr int U = 8;
         uint32_t carry = 0xffffffffu;                                  // cell of the record before the round's first (wave-uniform)
-        for (uint32_t p0 = rb; p0 < re; p0 += 64u * U) {               // wave-uniform
-            uint32_t c[U];
+        auto scan_rounds = [&](auto Uc, uint32_t p_begin, uint32_t p_end) {
+            constexpr int U = decltype(Uc)::value;
+            for (uint32_t p0 = p_begin; p0 < p_end; p0 += 64u * U) {   // wave-uniform
+                uint32_t c[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) { const uint32_t p = p0 + 64u * u + (uint32_t)lane; c[u] = a.key[min(p, re - 1u)] & 63u; }
+                for (int u = 0; u < U; ++u) { const uint32_t p = p0 + 64u * u + (uint32_t)lane; c[u] = a.key[min(p, re - 1u)] & 63u; }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t p = p0 + 64u * u + (uint32_t)lane;
-                const bool live = p < re;
-                const uint32_t cell = live ? c[u] : 0xfffffffeu;
-                uint32_t prev = (uint32_t)__shfl_up((int)cell, 1, 64);
-                if (lane == 0) prev = carry;
-                carry = (uint32_t)__builtin_amdgcn_readlane((int)cell, 63);
-                if (live && cell != prev) { cstart[cell] = p; if (prev < 64u) cend[prev] = p; }
-                if (p + 1u == re) cend[cell] = re;
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t p = p0 + 64u * u + (uint32_t)lane;
+                    const bool live = p < re;
+                    const uint32_t cell = live ? c[u] : 0xfffffffeu;
+                    uint32_t prev = (uint32_t)__shfl_up((int)cell, 1, 64);
+                    if (lane == 0) prev = carry;
+                    carry = (uint32_t)__builtin_amdgcn_readlane((int)cell, 63);
+                    if (live && cell != prev) { cstart[cell] = p; if (prev < 64u) cend[prev] = p; }
+                    if (p + 1u == re) cend[cell] = re;
+                }
             }
-        }
+        };
+        // long runs (the waves under the sensor, a depth camera's near field) in rounds of 16 loads, the rest in rounds of 2
+        const uint32_t long_part = re - rb >= 2048u ? ((re - rb) / 1024u) * 1024u : 0u;
+        if (long_part) scan_rounds(std::integral_constant<int, 16>{}, rb, rb + long_part);
+        scan_rounds(std::integral_constant<int, 2>{}, rb + long_part, re);
     }
     __syncthreads();
     const uint32_t first = cstart[lane], n = cend[lane] - first;
@@ -467,12 +475,20 @@ __global__ __launch_bounds__(64) void k_fuse_walk(WalkArgs a)
     for (int k = 0; k < a.n_pending; ++k) if (cs != kInitVariance) cs += a.pending[k];
     uint32_t cur = 0;                                                  // "inside sweep cur, its increment applied"
     if constexpr (HAS_VU) { if (cs != kInitVariance) cs += vu[0]; }
-    // from sweep `cur` to sweep `to`: the floor that ends every Fuse (GPU:533-534), then the next sweep's increment
+    // From sweep `cur` to sweep `to`: the floor that ends every Fuse (GPU:533-534), then the next sweep's increment.  The lanes of
+    // a wave stand at unrelated sweeps, so this loop runs as long as the lane with the widest gap needs; the increment of the
+    // lane's NEXT sweep is kept in a register (fetched behind the previous use), so that the common one-sweep gap costs no LDS
+    // round trip.  (Tried: the first two sweeps of a gap as straight-line predicated code -- every record then pays for them,
+    // 69 -> 144 us on C4.)
+    const uint32_t last_sw = (uint32_t)(a.n_sweeps > 0 ? a.n_sweeps - 1 : 0);
+    float u1 = 0.0f;
+    if constexpr (HAS_VU) u1 = vu[min(1u, last_sw)];
     auto advance = [&](uint32_t to) {
         while (cur < to) {
             if (cs < a.var_floor) cs = a.var_floor;
             ++cur;
-            if (cs != kInitVariance) cs += vu[cur];
+            if (cs != kInitVariance) cs += u1;
+            u1 = vu[min(cur + 1u, last_sw)];
         }
     };
     uint32_t wlast = 0xffffffffu, sweeps_seen = 0, last_sweep = 0xffffffffu;
@@ -528,7 +544,7 @@ __global__ __launch_bounds__(64) void k_fuse_walk(WalkArgs a)
             run_group(4u * g + 8u, C);  load_group(g + 5u, C);
         }
     }
-    if constexpr (HAS_VU) advance((uint32_t)a.n_sweeps - 1u);
+    if constexpr (HAS_VU) advance(last_sw);
     if (cs < a.var_floor) cs = a.var_floor;                            // GPU:533-534, on every cell
 
     if (owned) {
