@@ -80,6 +80,7 @@ struct gem_handle {
     bool sort_path = true;              // passes of at least sort_min_points points run the sorted pipeline (gem_sort.hip)
     long long sort_min_points = 200000;
     bool walk_permute = true;           // k_fuse_walk: blocks mapped to cell groups through a stride permutation
+    int  sort_passes = 0;               // 0 = by map size (two digits up to 2^20 cells, else three); 2 / 3 force it
     int dbg_sweep = 0;                  // debug stamps of the dense path: which sweep (GEM_DBG_SWEEP)
     bool track_lowest = false;          // also maintain map_lowest in the fuse kernels (gem_set_lowest_tracking, for gem_raytracing)
     unsigned dense_min = 2048;          // records of one sweep in one 16x16 tile above which the tile is counting-sorted (k_fuse_list, dense path)
@@ -166,7 +167,7 @@ hipEvent_t get_event(gem_handle* h)
 struct Timed {
     gem_handle* h; EventPair ep{};
     bool on;
-    Timed(gem_handle* hh, int kind) : h(hh), on(hh->timing)
+    Timed(gem_handle* hh, int kind) : h(hh), on(hh->timing && kind >= 0)
     {
         if (!on) return;
         if (!h->pool.empty()) { ep = h->pool.back(); h->pool.pop_back(); }
@@ -242,18 +243,30 @@ constexpr long long kSweepPoints = 2048ll * kUnit;   // a single cloud longer th
 static int ceil_log2(int v) { int b = 0; while ((1 << b) < v) ++b; return b; }
 
 // the key geometry of the sorted pipeline for this map, and whether a pass of `n_sweeps` sweeps fits the 32-bit record key
-struct SortGeometry { int tiles_per_row, T, id_bits, d0_bits, bins0, bins1; bool ok; };
+struct SortGeometry { int tiles_per_row, T, id_bits, n_passes, dshift[3], dbits[3], dbins[3]; bool ok; };
 SortGeometry sort_geometry(const gem_handle* h, int n_sweeps)
 {
     SortGeometry g{};
     g.tiles_per_row = (h->L + 31) / 32;
     g.T = g.tiles_per_row * g.tiles_per_row;
     g.id_bits = 10 + std::max(1, ceil_log2(g.T));                 // id = tile << 10 | cell in tile
-    g.d0_bits = std::max(6, g.id_bits / 2);                       // two digits of about equal width; a wave's 64 cells never straddle a bin
-    g.bins0 = 1 << g.d0_bits;
-    g.bins1 = (int)(((((long long)g.T) << 10) - 1) >> g.d0_bits) + 1;
+    // Digits of about equal width, at most ten bits: the records of a (chunk, bin) leave k_sort_scatter as one run, and with
+    // thousands of bins a 4096-record chunk has one or two records per run -- no coalescing left (the 2400^2 map in two passes of
+    // 2048 / 2813 bins: 206 + 158 us; in three passes of 256 / 256 / 88 bins: see DESIGN.md).
+    g.n_passes = h->sort_passes ? h->sort_passes : (g.id_bits <= 20 ? 2 : 3);
+    int shift = 0;
+    for (int i = 0; i < g.n_passes; ++i) {
+        const int left = g.n_passes - i;
+        int bits = (g.id_bits - shift + left - 1) / left;
+        if (i == 0) bits = std::max(bits, 6);                     // a wave's 64 cells never straddle a bin of the last pass
+        if (i == g.n_passes - 1) bits = g.id_bits - shift;
+        g.dshift[i] = shift; g.dbits[i] = bits;
+        g.dbins[i] = i == g.n_passes - 1 ? (int)(((((long long)g.T) << 10) - 1) >> shift) + 1 : 1 << bits;
+        shift += bits;
+    }
     const long long max_sweeps = std::min<long long>(512, (1ll << (32 - g.id_bits)) - 1);     // the sweep field is never all ones
-    g.ok = g.id_bits <= 26 && g.bins0 <= kSortMaxBins && g.bins1 <= kSortMaxBins && n_sweeps <= max_sweeps;
+    g.ok = g.id_bits <= 26 && n_sweeps <= max_sweeps && g.dshift[g.n_passes - 1] >= 6;
+    for (int i = 0; i < g.n_passes; ++i) g.ok = g.ok && g.dbins[i] <= kSortMaxBins && g.dbits[i] >= 1;
     return g;
 }
 
@@ -262,7 +275,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
 {
     const bool batched = in.n_sweeps > 1;
     const bool with_src = (attr & 3) != 0;
-    const SortShape sh1 = sort_shape(geo.bins0, with_src);
+    const SortShape sh1 = sort_shape(geo.dbins[0], with_src);
     std::vector<int> chunk0(in.n_sweeps + 1, 0);
     for (int s = 0; s < in.n_sweeps; ++s) {
         const long long cnt = batched ? in.offsets[s + 1] - in.offsets[s] : in.n;
@@ -300,11 +313,15 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
         if ((rc = ensure(h, pb.s_src1, N * 4 + 64))) return rc;
         if ((rc = ensure(h, pb.s_src2, N * 4 + 64))) return rc;
     }
-    if ((rc = ensure(h, pb.s_cnt1, (size_t)NC1 * geo.bins0 * 4))) return rc;
-    if ((rc = ensure(h, pb.s_cnt2, (size_t)nc2max * geo.bins1 * 4 + 16))) return rc;
-    // segment sums of pass 1 [4][bins0] | of pass 2 [4][bins1] | record count | bin bases [bins1 + 1]
-    const size_t o_tot1 = 0, o_tot2 = (size_t)geo.bins0 * 16, o_total = o_tot2 + (size_t)geo.bins1 * 16, o_base = (o_total + 4 + 15) & ~(size_t)15;
-    if ((rc = ensure(h, pb.s_misc, o_base + ((size_t)geo.bins1 + 1) * 4))) return rc;
+    int bins_hi = 1;                                                  // the later passes share one count table
+    for (int i = 1; i < geo.n_passes; ++i) bins_hi = std::max(bins_hi, geo.dbins[i]);
+    if ((rc = ensure(h, pb.s_cnt1, (size_t)NC1 * geo.dbins[0] * 4))) return rc;
+    if ((rc = ensure(h, pb.s_cnt2, (size_t)nc2max * bins_hi * 4 + 16))) return rc;
+    // segment sums [pass][4][bins] | record count | bin bases of the last pass [bins + 1]
+    size_t o_seg[3] = {0, 0, 0}, o_next = 0;
+    for (int i = 0; i < geo.n_passes; ++i) { o_seg[i] = o_next; o_next += (size_t)geo.dbins[i] * 16; }
+    const size_t o_total = o_next, o_base = (o_total + 4 + 15) & ~(size_t)15;
+    if ((rc = ensure(h, pb.s_misc, o_base + ((size_t)geo.dbins[geo.n_passes - 1] + 1) * 4))) return rc;
     // the walk of pass p-2 has read these buffers (host-side wait, see run_pipeline)
     if (overlap && pb.fuse_recorded) GEM_HIP(h, hipEventSynchronize(pb.fuse_done));
 
@@ -350,11 +367,14 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     sa.f_R = in.f_R; sa.f_G = in.f_G; sa.f_B = in.f_B; sa.f_I = in.f_I;
     sa.keep_sentinel = h->track_lowest ? 1 : 0;
     sa.tiles_per_row = geo.tiles_per_row; sa.T = T;
-    sa.id_bits = geo.id_bits; sa.d0_bits = geo.d0_bits; sa.bins0 = geo.bins0; sa.bins1 = geo.bins1;
+    sa.id_bits = geo.id_bits; sa.n_passes = geo.n_passes;
+    for (int i = 0; i < 3; ++i) { sa.dshift[i] = geo.dshift[i]; sa.dbits[i] = geo.dbits[i]; sa.dbins[i] = geo.dbins[i]; }
     sa.n_chunks1 = NC1;
     unsigned char* misc = static_cast<unsigned char*>(pb.s_misc.p);
-    sa.cnt1 = static_cast<uint32_t*>(pb.s_cnt1.p); sa.tot1 = reinterpret_cast<uint32_t*>(misc + o_tot1);
-    sa.cnt2 = static_cast<uint32_t*>(pb.s_cnt2.p); sa.tot2 = reinterpret_cast<uint32_t*>(misc + o_tot2);
+    for (int i = 0; i < geo.n_passes; ++i) {
+        sa.cnt[i] = static_cast<uint32_t*>(i == 0 ? pb.s_cnt1.p : pb.s_cnt2.p);
+        sa.segtot[i] = reinterpret_cast<uint32_t*>(misc + o_seg[i]);
+    }
     sa.total = reinterpret_cast<uint32_t*>(misc + o_total); sa.bin_base = reinterpret_cast<uint32_t*>(misc + o_base);
     // arrays a: the projected records in input order, later the final order; arrays b: the order after pass 1
     sa.hv_a = static_cast<uint2*>(pb.s_hv2.p); sa.hv_b = static_cast<uint2*>(pb.s_hv1.p);
@@ -362,14 +382,15 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     sa.src_a = with_src ? static_cast<uint32_t*>(pb.s_src2.p) : nullptr; sa.src_b = with_src ? static_cast<uint32_t*>(pb.s_src1.p) : nullptr;
     sa.counters = h->counting ? h->d_counters : nullptr;
 
-    wa.hv = sa.hv_a; wa.key = sa.key_a; wa.src = sa.src_a; wa.bin_base = sa.bin_base;
+    const bool final_b = (geo.n_passes & 1) != 0;                     // the passes ping-pong between the arrays: a -> b -> a (-> b)
+    wa.hv = final_b ? sa.hv_b : sa.hv_a; wa.key = final_b ? sa.key_b : sa.key_a; wa.src = final_b ? sa.src_b : sa.src_a; wa.bin_base = sa.bin_base;
     {   // block -> cell-group permutation of k_fuse_walk: a prime stride coprime with the number of groups
         static const int primes[] = {1021, 1031, 2053, 4099, 509};
         wa.walk_stride = 1;
         if (h->walk_permute) for (int pr : primes) if ((16ll * T) % pr != 0) { wa.walk_stride = pr; break; }
     }
     wa.T = T; wa.tiles_per_row = geo.tiles_per_row; wa.L = h->L; wa.row0 = h->row0; wa.row1 = h->row1;
-    wa.id_bits = geo.id_bits; wa.bin_shift = geo.d0_bits; wa.n_sweeps = in.n_sweeps;
+    wa.id_bits = geo.id_bits; wa.bin_shift = geo.dshift[geo.n_passes - 1]; wa.n_sweeps = in.n_sweeps;
     wa.mahal = h->cfg.mahalanobis_threshold; wa.var_floor = h->cfg.variance_floor;
     wa.dense = dense ? 1 : 0;
     wa.n_pending = h->n_pending;
@@ -383,8 +404,10 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
 
     if (h->counting) GEM_HIP(h, hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
     {
-        Timed t0(h, 3), t1(h, 4), t2(h, 5), t3(h, 6), t4(h, 7), t5(h, 8);
-        const LaunchEvents ev[6] = {t0.events(), t1.events(), t2.events(), t3.events(), t4.events(), t5.events()};
+        // (a third pass is accounted with the second: count / scan / scatter of the higher digits)
+        const bool three = geo.n_passes == 3;
+        Timed t0(h, 3), t1(h, 4), t2(h, 5), t3(h, 6), t4(h, 7), t5(h, 8), t6(h, three ? 6 : -1), t7(h, three ? 7 : -1), t8(h, three ? 8 : -1);
+        const LaunchEvents ev[9] = {t0.events(), t1.events(), t2.events(), t3.events(), t4.events(), t5.events(), t6.events(), t7.events(), t8.events()};
         // clouds whose frames all use the laser model (the reference's only GPU model, GPU:403-408) take the instantiation without
         // the camera models' double-precision code
         int src = in.src;
@@ -1196,6 +1219,7 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "sort_path")          h->sort_path = value != 0;
     else if (k == "sort_min_points")    h->sort_min_points = value;
     else if (k == "walk_permute")       h->walk_permute = value != 0;
+    else if (k == "sort_passes")        { if (value != 0 && value != 2 && value != 3) return fail(h, GEM_ERR_INVALID, "sort_passes: 0, 2 or 3"); h->sort_passes = (int)value; }
     else return fail(h, GEM_ERR_INVALID, "gem_debug_set: unknown key");
     return GEM_OK;
 }

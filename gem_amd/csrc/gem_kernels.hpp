@@ -90,7 +90,7 @@ struct FuseArgs {
 
 // ---- the sorted pipeline of big passes (gem_sort.hip) ------------------------------------------------------------------------
 // Record key, 32 bits:  id | sweep << id_bits,  id = tile << 10 | cell in its 32x32 tile  (id_bits = 10 + bits of the tile index).
-// The id is sorted in two stable counting-sort passes: low digit = id & (bins0 - 1), high digit = id >> d0_bits (bins1 values).
+// The id is sorted by two or three stable counting-sort passes over digits of about equal width, lowest digit first.
 struct SortArgs {
     FrameConst frame0;                 // single-sweep call: the frame, by value
     const FrameConst* frames;          // [n_sweeps]    (batched call)
@@ -104,13 +104,14 @@ struct SortArgs {
     const int* f_R; const int* f_G; const int* f_B; const float* f_I;
     int keep_sentinel;                 // keep records with h == -1 (GPU:482) for the LOWEST walk
     int tiles_per_row, T;              // 32x32-cell tiles
-    int id_bits, d0_bits, bins0, bins1;
+    int id_bits;
+    int n_passes;                      // counting-sort passes over the id: two digits, three for maps with more than 2^20 cells
+    int dshift[3], dbits[3], dbins[3]; // digit i = (id >> dshift[i]) & ((1 << dbits[i]) - 1), dbins[i] values
     int n_chunks1;                     // chunks of pass 1
-    uint32_t *cnt1, *tot1;             // [n_chunks1][bins0] per-chunk counts -> prefixes over the chunks of a segment; [4][bins0] segment sums
-    uint32_t *cnt2, *tot2;             // [chunks of pass 2][bins1]; [4][bins1]
+    uint32_t *cnt[3], *segtot[3];      // per pass: [chunks][bins] per-chunk counts -> prefixes over the chunks of a segment; [4][bins] segment sums
     uint32_t *total;                   // [0] records kept by pass 1 (in the map, in the strip, accepted)
-    uint32_t *bin_base;                // [bins1 + 1] first record of every high-digit bin in the final order (what k_fuse_walk searches in)
-    uint2 *hv_a, *hv_b;                // {h, var}: a = input order, then the final order; b = after pass 1
+    uint32_t *bin_base;                // [bins of the last pass + 1] first record of every highest-digit bin in the final order (what k_fuse_walk searches in)
+    uint2 *hv_a, *hv_b;                // {h, var}: a = input order, then after the even passes; b = after the odd passes (the passes ping-pong)
     uint32_t *key_a, *key_b, *src_a, *src_b;      // keys; source point | colour flag << 31 (src only when colours are fused)
     unsigned long long* counters;      // optional: [0] += records
 };
@@ -148,7 +149,7 @@ struct WalkArgs {
 struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };   // optional dispatch time-stamps
 struct SortShape { int nt, chunk; size_t lds; };
 SortShape  sort_shape(int bins, bool attr);   // workgroup shape of a pass with that many bins
-hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, const LaunchEvents ev[6]);   // project, scan1, scatter1, count2, scan2, scatter2
+hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, const LaunchEvents ev[9]);   // project, scan, scatter | count, scan, scatter | (count, scan, scatter)
 hipError_t launch_walk(hipStream_t st, const WalkArgs& a, int flags, LaunchEvents ev);
 constexpr int kSortMaxBins = 8000;     // bins per pass the sorted pipeline handles (LDS of k_sort_scatter)
 

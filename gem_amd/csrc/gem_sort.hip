@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_sort_project(SortArgs a)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_sort[];
     uint32_t* hist = lds_sort;                                         // [bins0]
     const int tid = (int)threadIdx.x, chunk = (int)blockIdx.x;
-    for (int i = tid; i < a.bins0; i += NT) hist[i] = 0u;
+    for (int i = tid; i < a.dbins[0]; i += NT) hist[i] = 0u;
     if (chunk == 0 && tid == 0) *a.total = 0u;                         // k_sort_scan of this pass adds the column totals up
     const ChunkRange cr = chunk_range<CH>(a.sweep_chunk0, a.sweep_first, a.sweep_orig0, a.n_sweeps, a.n, chunk);
     // BY VALUE: the stores below may alias the frame table as far as the compiler knows, and a reference would make it reload
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_sort_project(SortArgs a)
     const FrameConst fc = a.sweep_chunk0 ? a.frames[cr.sweep] : a.frame0;
     const long long base = cr.first + (long long)(tid >> 6) * (K * 64) + (tid & 63);
     const uint32_t sweep_bits = (uint32_t)cr.sweep << a.id_bits;
-    const uint32_t d0mask = (uint32_t)a.bins0 - 1u;
+    const uint32_t d0mask = (1u << a.dbits[0]) - 1u;
     __syncthreads();
     // blocks of eight points: the loads of a block are in flight together, then each point is projected, stored and counted
     for (int k0 = 0; k0 < K; k0 += 8) {
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_sort_project(SortArgs a)
         }
     }
     __syncthreads();
-    for (int i = tid; i < a.bins0; i += NT) a.cnt1[(size_t)chunk * a.bins0 + i] = hist[i];
+    for (int i = tid; i < a.dbins[0]; i += NT) a.cnt[0][(size_t)chunk * a.dbins[0] + i] = hist[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -618,7 +618,7 @@ static hipError_t lds_opt_in(const void* fn, size_t lds)
 
 static hipError_t launch_project(hipStream_t st, const SortArgs& a, int src, LaunchEvents ev)
 {
-    const size_t lds = (size_t)a.bins0 * 4;
+    const size_t lds = (size_t)a.dbins[0] * 4;
     if (src == 0)      GEM_LAUNCH((k_sort_project<0>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
     else if (src == 2) GEM_LAUNCH((k_sort_project<2>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
     else               GEM_LAUNCH((k_sort_project<1>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
@@ -646,31 +646,41 @@ static hipError_t launch_pass(hipStream_t st, const SortShape& sh, const PassArg
     return launch_pass_nt<256>(st, p, attr, grid, count, sh.lds, ev);
 }
 
-hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, const LaunchEvents ev[6])
+hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, const LaunchEvents ev[9])
 {
-    if (a.n <= 0 || a.n_chunks1 <= 0) return hipErrorInvalidValue;
-    const SortShape s1 = sort_shape(a.bins0, attr), s2 = sort_shape(a.bins1, attr);
-    if (s1.lds > 160 * 1024 || s2.lds > 160 * 1024) return hipErrorInvalidValue;
+    if (a.n <= 0 || a.n_chunks1 <= 0 || a.n_passes < 1 || a.n_passes > 3) return hipErrorInvalidValue;
+    SortShape sh[3];
+    for (int i = 0; i < a.n_passes; ++i) { sh[i] = sort_shape(a.dbins[i], attr); if (sh[i].lds > 160 * 1024) return hipErrorInvalidValue; }
     hipError_t e;
-    // ---- pass 1: project + count, scan, scatter by the low digit (input order -> arrays b)
+    // ---- pass 1: project + count, scan, scatter by the lowest digit (input order in arrays a -> arrays b)
     if ((e = launch_project(st, a, src, ev[0])) != hipSuccess) return e;
-    GEM_LAUNCH(k_sort_scan, dim3((a.bins0 + 63) / 64, kScanSegs), dim3(1024), 0, st, ev[1], a.cnt1, a.tot1, a.bins0, a.n_chunks1, (const uint32_t*)nullptr, a.total);
+    GEM_LAUNCH(k_sort_scan, dim3((a.dbins[0] + 63) / 64, kScanSegs), dim3(1024), 0, st, ev[1], a.cnt[0], a.segtot[0], a.dbins[0], a.n_chunks1,
+               (const uint32_t*)nullptr, a.total);
     PassArgs p{};
     p.hv_in = a.hv_a; p.key_in = a.key_a; p.src_in = a.src_a; p.hv_out = a.hv_b; p.key_out = a.key_b; p.src_out = a.src_b;
-    p.cnt = a.cnt1; p.segtot = a.tot1; p.n_chunks = a.n_chunks1; p.bins = a.bins0; p.shift = 0; p.digit_bits = a.d0_bits; p.mask = (uint32_t)a.bins0 - 1u;
+    p.cnt = a.cnt[0]; p.segtot = a.segtot[0]; p.n_chunks = a.n_chunks1; p.bins = a.dbins[0]; p.shift = a.dshift[0]; p.digit_bits = a.dbits[0];
+    p.mask = (1u << a.dbits[0]) - 1u;
     p.n_dev = nullptr; p.n_host = a.n; p.sweep_chunk0 = a.sweep_chunk0; p.sweep_first = a.sweep_first; p.n_sweeps = a.n_sweeps;
-    p.bin_base = nullptr; p.counters = nullptr;
-    if ((e = launch_pass(st, s1, p, attr, a.n_chunks1, false, ev[2])) != hipSuccess) return e;
-    // ---- pass 2: count, scan, scatter by the high digit (arrays b -> arrays a); the live chunks are known on the device only
-    const int grid2 = (int)((a.n + kSortChunk - 1) / kSortChunk);
-    p.hv_in = a.hv_b; p.key_in = a.key_b; p.src_in = a.src_b; p.hv_out = a.hv_a; p.key_out = a.key_a; p.src_out = a.src_a;
-    p.cnt = a.cnt2; p.segtot = a.tot2; p.n_chunks = 0; p.bins = a.bins1; p.shift = a.d0_bits; p.digit_bits = a.id_bits - a.d0_bits;
-    p.mask = (1u << (a.id_bits - a.d0_bits)) - 1u;
-    p.n_dev = a.total; p.n_host = 0; p.sweep_chunk0 = nullptr; p.sweep_first = nullptr; p.n_sweeps = 1;
-    p.bin_base = a.bin_base; p.counters = a.counters;
-    if ((e = launch_pass(st, s2, p, attr, grid2, true, ev[3])) != hipSuccess) return e;
-    GEM_LAUNCH(k_sort_scan, dim3((a.bins1 + 63) / 64, kScanSegs), dim3(1024), 0, st, ev[4], a.cnt2, a.tot2, a.bins1, 0, (const uint32_t*)a.total, (uint32_t*)nullptr);
-    return launch_pass(st, s2, p, attr, grid2 > 0 ? grid2 : 1, false, ev[5]);
+    const bool last0 = a.n_passes == 1;
+    p.bin_base = last0 ? a.bin_base : nullptr; p.counters = last0 ? a.counters : nullptr;
+    if ((e = launch_pass(st, sh[0], p, attr, a.n_chunks1, false, ev[2])) != hipSuccess) return e;
+    // ---- the higher digits: count, scan, scatter on the records of the pass before (ping-pong between the arrays); the
+    //      live chunks are known on the device only
+    const int grid = std::max(1, (int)((a.n + kSortChunk - 1) / kSortChunk));
+    for (int i = 1; i < a.n_passes; ++i) {
+        const bool from_b = (i & 1) != 0, last = i == a.n_passes - 1;
+        p.hv_in = from_b ? a.hv_b : a.hv_a; p.key_in = from_b ? a.key_b : a.key_a; p.src_in = from_b ? a.src_b : a.src_a;
+        p.hv_out = from_b ? a.hv_a : a.hv_b; p.key_out = from_b ? a.key_a : a.key_b; p.src_out = from_b ? a.src_a : a.src_b;
+        p.cnt = a.cnt[i]; p.segtot = a.segtot[i]; p.n_chunks = 0; p.bins = a.dbins[i]; p.shift = a.dshift[i]; p.digit_bits = a.dbits[i];
+        p.mask = (1u << a.dbits[i]) - 1u;
+        p.n_dev = a.total; p.n_host = 0; p.sweep_chunk0 = nullptr; p.sweep_first = nullptr; p.n_sweeps = 1;
+        p.bin_base = last ? a.bin_base : nullptr; p.counters = last ? a.counters : nullptr;
+        if ((e = launch_pass(st, sh[i], p, attr, grid, true, ev[3 * i])) != hipSuccess) return e;
+        GEM_LAUNCH(k_sort_scan, dim3((a.dbins[i] + 63) / 64, kScanSegs), dim3(1024), 0, st, ev[3 * i + 1], a.cnt[i], a.segtot[i], a.dbins[i], 0,
+                   (const uint32_t*)a.total, (uint32_t*)nullptr);
+        if ((e = launch_pass(st, sh[i], p, attr, grid, false, ev[3 * i + 2])) != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 template <int FLAGS>

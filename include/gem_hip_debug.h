@@ -15,7 +15,8 @@ extern "C" {
 /* keys: "fuse_variant" (10..12: k_fuse_list geometry on 32x32 tiles), "tile_shift" (0 = per pass, 4, 5),
  *       "defer" (0/1: one launch per frame for streams of single sweeps), "dense_min" (records of one sweep in one
  *       16x16 tile above which the tile is counting-sorted), "dbg_sweep", "overlap" (0/1: binning of big passes on a
- *       second stream), "overlap_min_points", "sort_path" (0/1: the sorted pipeline for big passes), "sort_min_points".  Returns GEM_ERR_INVALID for an unknown key or a value out of range. */
+ *       second stream), "overlap_min_points", "sort_path" (0/1: the sorted pipeline for big passes), "sort_min_points",
+ *       "sort_passes" (0 = by map size, 2, 3: counting-sort passes over the cell id), "walk_permute" (0/1).  Returns GEM_ERR_INVALID for an unknown key or a value out of range. */
 int gem_debug_set(gem_handle* h, const char* key, long long value);
 
 /* per-tile cycle stamps of the last fuse launch ([tile][16] 64-bit counters); enable != 0 turns the stamps on for the

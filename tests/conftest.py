@@ -59,14 +59,16 @@ def pytest_generate_tests(metafunc):
     # every GPU test runs on both pipelines (see the `pipeline` fixture)
     if metafunc.definition.get_closest_marker("gpu") is not None:
         metafunc.fixturenames.append("pipeline")
-        metafunc.parametrize("pipeline", ["default", "sorted"], indirect=True)
+        metafunc.parametrize("pipeline", ["default", "sorted", "sorted3"], indirect=True)
 
 
 @pytest.fixture
 def pipeline(request, monkeypatch):
-    """GPU tests run twice: with the library's own choice between the tile pipeline (k_frame / k_bin_wave + k_fuse_list) and
-    the sorted pipeline (gem_sort.hip), and with the sorted pipeline forced for every pass, however small."""
+    """GPU tests run three times: with the library's own choice between the tile pipeline (k_frame / k_bin_wave + k_fuse_list)
+    and the sorted pipeline (gem_sort.hip), and with the sorted pipeline forced for every pass, however small -- once with the
+    pass count the map size calls for, once with three counting-sort passes (what only maps beyond 2^20 cells would take)."""
     from gem_amd import ElevationMap
     which = getattr(request, "param", "default")
-    monkeypatch.setattr(ElevationMap, "base_debug", {"sort_min_points": 1} if which == "sorted" else {})
+    knobs = {"default": {}, "sorted": {"sort_min_points": 1}, "sorted3": {"sort_min_points": 1, "sort_passes": 3}}[which]
+    monkeypatch.setattr(ElevationMap, "base_debug", knobs)
     return which
