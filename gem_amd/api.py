@@ -436,6 +436,66 @@ class ElevationMap:
     def allgather_layers(self, with_attributes: bool = False) -> None:
         self._check(self._lib.gem_allgather_layers(self._h, int(with_attributes)), "gem_allgather_layers")
 
+    def comm_init_tiles(self, unique_id: bytes, nranks: int, rank: int) -> None:
+        """Like comm_init, with strips made of whole rows of 32 x 32-cell tiles (what the sharded path needs)."""
+        buf = C.create_string_buffer(unique_id, 128)
+        self._check(self._lib.gem_comm_init_tiles(self._h, buf, int(nranks), int(rank)), "gem_comm_init_tiles")
+
+    def strip(self):
+        r0, r1 = C.c_int(), C.c_int()
+        self._check(self._lib.gem_get_strip(self._h, C.byref(r0), C.byref(r1)), "gem_get_strip")
+        return int(r0.value), int(r1.value)
+
+    # -- multi-GPU with the points sharded (SURVEY 8e stage B) --------------------------------------------------------------
+    def add_sharded(self, pb: "PackedBatch", xyzi_device, first_global_sweep: int, n_global_sweeps: int, var_updates_global=None) -> None:
+        """This rank's contiguous share of a batch (local sweeps of `pb`, numbered first_global_sweep.. globally): sort, RCCL
+        exchange of the sorted records to the strip owners, walk in rank order (gem_add_sharded_device)."""
+        vu = None if var_updates_global is None else (C.c_float * n_global_sweeps)(*[float(v) for v in var_updates_global])
+        ptr = C.c_void_p(xyzi_device.data_ptr()) if pb.n else None
+        self._check(self._lib.gem_add_sharded_device(self._h, pb.n, pb.frames, ptr, pb.offsets, int(first_global_sweep),
+                                                     int(n_global_sweeps), vu), "gem_add_sharded_device")
+
+    def shard_sort(self, pb: "PackedBatch", xyzi_device, first_global_sweep: int, n_global_sweeps: int, strip_rows):
+        """First half: returns (bounds [nstrips + 1], device pointer of the sorted {h, var} records, of their keys)."""
+        ns = len(strip_rows) - 1
+        rows = (C.c_int * (ns + 1))(*[int(v) for v in strip_rows])
+        bounds = (C.c_uint32 * (ns + 1))()
+        phv, pkey = C.c_void_p(), C.c_void_p()
+        ptr = C.c_void_p(xyzi_device.data_ptr()) if pb.n else None
+        self._check(self._lib.gem_shard_sort_device(self._h, pb.n, pb.frames, ptr, pb.offsets, int(first_global_sweep), int(n_global_sweeps),
+                                                    ns, rows, bounds, C.byref(phv), C.byref(pkey)), "gem_shard_sort_device")
+        return np.array(bounds[:], np.int64), phv.value or 0, pkey.value or 0
+
+    def shard_sort_tensors(self, pb, xyzi_device, first_global_sweep, n_global_sweeps, strip_rows):
+        """shard_sort with the sorted records as torch tensors aliasing the handle's arenas ([M, 2] int32 {h, var} bits, [M] int32
+        keys); they stay valid until the next pass of this handle."""
+        import torch
+        from .tiling import _DeviceArray
+        bounds, phv, pkey = self.shard_sort(pb, xyzi_device, first_global_sweep, n_global_sweeps, strip_rows)
+        m = int(bounds[-1])
+        if m == 0:
+            dev = xyzi_device.device
+            return bounds, torch.empty((0, 2), dtype=torch.int32, device=dev), torch.empty((0,), dtype=torch.int32, device=dev)
+        hv = torch.as_tensor(_DeviceArray(phv, (m, 2), "<i4"), device="cuda")
+        key = torch.as_tensor(_DeviceArray(pkey, (m,), "<i4"), device="cuda")
+        return bounds, hv, key
+
+    def shard_fuse_tensors(self, hv_list, key_list, n_global_sweeps, var_updates_global=None) -> None:
+        import torch
+        torch.cuda.synchronize()                     # the exchange ran on torch's stream, the walk runs on the handle's
+        self._keep = (hv_list, key_list)             # until the walk has read them
+        self.shard_fuse([t.data_ptr() if t.numel() else 0 for t in hv_list], [t.data_ptr() if t.numel() else 0 for t in key_list],
+                        [int(t.shape[0]) for t in key_list], n_global_sweeps, var_updates_global)
+
+    def shard_fuse(self, hv_ptrs, key_ptrs, counts, n_global_sweeps: int, var_updates_global=None) -> None:
+        """Second half: walk this handle's strip through the sources (device pointers + record counts) in the order given."""
+        n = len(counts)
+        a_hv = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in hv_ptrs])
+        a_key = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in key_ptrs])
+        a_cnt = (C.c_uint32 * n)(*[int(c) for c in counts])
+        vu = None if var_updates_global is None else (C.c_float * n_global_sweeps)(*[float(v) for v in var_updates_global])
+        self._check(self._lib.gem_shard_fuse_device(self._h, n, a_hv, a_key, a_cnt, int(n_global_sweeps), vu), "gem_shard_fuse_device")
+
 
 class RobotMotionMapUpdater:
     """RobotMotionMapUpdater (RobotMotionMapUpdater.cpp:42-145): pose covariance -> scalar variance

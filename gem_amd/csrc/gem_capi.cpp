@@ -99,6 +99,17 @@ struct gem_handle {
 
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
+    int strip_row[kMaxRanks + 1] = {0};  // storage rows [strip_row[k], strip_row[k+1]) belong to rank k (gem_comm_init / gem_comm_init_tiles)
+    bool tile_strips = false;           // strips are whole rows of 32x32 tiles (needed by the sharded path)
+    // multi-GPU, points sharded (gem_shard_sort_device / gem_shard_fuse_device / gem_add_sharded_device)
+    struct Shard {
+        bool valid = false;
+        const uint2* hv = nullptr; const uint32_t* key = nullptr;     // this device's sorted records
+        uint32_t bounds[kMaxRanks + 1] = {0};                          // first record of every strip in them
+        int nstrips = 0, n_global_sweeps = 0;
+    } shard;
+    Arena sh_dev, sh_recv_hv, sh_recv_key;  // ids / bounds / gathered bounds / variance increments; records received from the other ranks
+    void* sh_host = nullptr;            // pinned staging of the small tables (kShardHostBytes)
 
     Arena dbg;          // optional k_fuse phase stamps
     bool  dbg_on = false;
@@ -271,7 +282,10 @@ SortGeometry sort_geometry(const gem_handle* h, int n_sweeps)
 }
 
 // One pass through the sorted pipeline (gem_sort.hip): six sort kernels on the binning stream, k_fuse_walk on the handle's.
-int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGeometry& geo)
+constexpr size_t kShardHostBytes = 8192;
+struct ShardOpts { int sweep_id0; int nstrips; const int* strip_rows; };      // sort only: the walk happens on the strip owners
+
+int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGeometry& geo, const ShardOpts* shard = nullptr)
 {
     const bool batched = in.n_sweeps > 1;
     const bool with_src = (attr & 3) != 0;
@@ -286,11 +300,15 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     const int T = geo.T;
     h->T = T;
 
-    bool overlap = h->overlap && in.n >= h->overlap_min_points && h->stream == h->own_stream && !h->counting;
+    bool overlap = h->overlap && in.n >= h->overlap_min_points && h->stream == h->own_stream && !h->counting && !shard;
     if (overlap && !h->bin_stream && hipStreamCreateWithFlags(&h->bin_stream, hipStreamNonBlocking) != hipSuccess) {
         h->bin_stream = nullptr; overlap = false; (void)hipGetLastError();
     }
     { const int rcd = flush_deferred(h); if (rcd) return rcd; }
+    // a shard bins into the WHOLE map (its records go to the strip owners); the frames carry the strip
+    const int keep_row0 = h->row0, keep_row1 = h->row1;
+    struct RestoreRows { gem_handle* h; int r0, r1; ~RestoreRows() { h->row0 = r0; h->row1 = r1; } } restore{h, keep_row0, keep_row1};
+    if (shard) { h->row0 = 0; h->row1 = h->L; }
     gem_handle::PassBuffers& pb = h->pb[overlap ? (h->pass++ & 1u) : 0u];
     hipStream_t sbin = overlap ? h->bin_stream : h->stream;
     if (overlap && h->main_reads_pb) {                   // see run_pipeline
@@ -361,7 +379,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     } else {
         fill_frame(h, in.src == 0 ? in.params : nullptr, sa.frame0);
     }
-    sa.n_sweeps = in.n_sweeps; sa.n = in.n;
+    sa.n_sweeps = in.n_sweeps; sa.n = in.n; sa.sweep_id0 = shard ? shard->sweep_id0 : 0;
     sa.xyzi = in.xyzi; sa.rgb = in.rgb; sa.orig = in.orig;
     sa.f_index = in.f_index; sa.f_height = in.f_height; sa.f_var = in.f_var;
     sa.f_R = in.f_R; sa.f_G = in.f_G; sa.f_B = in.f_B; sa.f_I = in.f_I;
@@ -417,6 +435,29 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
             if (laser) src = 2;
         }
         GEM_HIP(h, launch_sort(sbin, sa, src, with_src, ev));
+    }
+    if (shard) {
+        // where the strips begin in the sorted records: one 32-ary search per boundary, then the only host round trip of the path
+        gem_handle::Shard& sd = h->shard;
+        sd.valid = false;
+        if (!h->sh_host) GEM_HIP(h, hipHostMalloc(&h->sh_host, kShardHostBytes, hipHostMallocDefault));
+        if ((rc = ensure(h, h->sh_dev, 4096 + sizeof(float) * 512))) return rc;
+        uint32_t* host = static_cast<uint32_t*>(h->sh_host);
+        for (int k = 0; k <= shard->nstrips; ++k) {
+            const int tile_row = shard->strip_rows[k] >= h->L ? geo.tiles_per_row : shard->strip_rows[k] / 32;
+            host[k] = (uint32_t)(tile_row * geo.tiles_per_row) << 10;                // first cell id of the strip
+        }
+        uint32_t* d_ids = static_cast<uint32_t*>(h->sh_dev.p), *d_bounds = d_ids + 16;
+        GEM_HIP(h, hipMemcpyAsync(d_ids, host, sizeof(uint32_t) * (shard->nstrips + 1), hipMemcpyHostToDevice, h->stream));
+        GEM_HIP(h, launch_strip_bounds(h->stream, final_b ? sa.key_b : sa.key_a, sa.total, geo.id_bits, d_ids, d_bounds, shard->nstrips + 1));
+        GEM_HIP(h, hipMemcpyAsync(host + 32, d_bounds, sizeof(uint32_t) * (shard->nstrips + 1), hipMemcpyDeviceToHost, h->stream));
+        GEM_HIP(h, hipStreamSynchronize(h->stream));
+        sd.hv = final_b ? sa.hv_b : sa.hv_a; sd.key = final_b ? sa.key_b : sa.key_a;
+        sd.nstrips = shard->nstrips;
+        for (int k = 0; k <= shard->nstrips; ++k) sd.bounds[k] = host[32 + k];
+        sd.valid = true;
+        h->stats.points_in = in.n;
+        return GEM_OK;
     }
     if (overlap) {
         GEM_HIP(h, hipEventRecord(pb.bin_done, sbin));
@@ -746,7 +787,8 @@ void gem_destroy(gem_handle* h)
     for (auto& ep : h->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
     if (h->layers.elevation) hipFree(h->layers.elevation);      // base of the single layer allocation
     if (h->d_counters) hipFree(h->d_counters);
-    for (Arena* a : {&h->stage, &h->scratch, &h->dbg}) if (a->p) hipFree(a->p);
+    for (Arena* a : {&h->stage, &h->scratch, &h->dbg, &h->sh_dev, &h->sh_recv_hv, &h->sh_recv_key}) if (a->p) hipFree(a->p);
+    if (h->sh_host) hipHostFree(h->sh_host);
     for (auto& b : h->pb) {
         for (Arena* a : {&b.rec, &b.srt, &b.seg, &b.flag, &b.gflag, &b.tables, &b.s_hv1, &b.s_hv2, &b.s_key1, &b.s_key2, &b.s_src1, &b.s_src2,
                          &b.s_cnt1, &b.s_cnt2, &b.s_misc}) if (a->p) hipFree(a->p);
@@ -1252,9 +1294,9 @@ int gem_comm_unique_id(void* out_128_bytes)
     return GEM_OK;
 }
 
-int gem_comm_init(gem_handle* h, const void* unique_id_128_bytes, int nranks, int rank)
+static int comm_init_common(gem_handle* h, const void* unique_id_128_bytes, int nranks, int rank, bool tile_strips)
 {
-    if (!h || !unique_id_128_bytes || nranks <= 0 || rank < 0 || rank >= nranks) return GEM_ERR_INVALID;
+    if (!h || !unique_id_128_bytes || nranks <= 0 || nranks > kMaxRanks || rank < 0 || rank >= nranks) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
     { const int rcd = flush_deferred(h); if (rcd) return rcd; }   // the strip changes below
@@ -1262,10 +1304,31 @@ int gem_comm_init(gem_handle* h, const void* unique_id_128_bytes, int nranks, in
     memcpy(&id, unique_id_128_bytes, sizeof(id));
     ncclResult_t r = ncclCommInitRank(&h->comm, nranks, id, rank);
     if (r != ncclSuccess) { h->comm = nullptr; return fail(h, GEM_ERR_COMM, ncclGetErrorString(r)); }
-    h->nranks = nranks; h->rank = rank;
+    h->nranks = nranks; h->rank = rank; h->tile_strips = tile_strips;
     // row strips in STORAGE coordinates: Move never migrates data between devices
-    h->row0 = (int)((long long)h->L * rank / nranks);
-    h->row1 = (int)((long long)h->L * (rank + 1) / nranks);
+    const int tile_rows = (h->L + 31) / 32;
+    for (int k = 0; k <= nranks; ++k)
+        h->strip_row[k] = tile_strips ? std::min(h->L, 32 * (int)((long long)tile_rows * k / nranks)) : (int)((long long)h->L * k / nranks);
+    h->row0 = h->strip_row[rank]; h->row1 = h->strip_row[rank + 1];
+    return GEM_OK;
+}
+
+int gem_comm_init(gem_handle* h, const void* unique_id_128_bytes, int nranks, int rank)
+{
+    return comm_init_common(h, unique_id_128_bytes, nranks, rank, false);
+}
+
+int gem_comm_init_tiles(gem_handle* h, const void* unique_id_128_bytes, int nranks, int rank)
+{
+    return comm_init_common(h, unique_id_128_bytes, nranks, rank, true);
+}
+
+int gem_get_strip(gem_handle* h, int* out_row0, int* out_row1)
+{
+    if (!h) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (out_row0) *out_row0 = h->row0;
+    if (out_row1) *out_row1 = h->row1;
     return GEM_OK;
 }
 
@@ -1279,23 +1342,188 @@ int gem_allgather_layers(gem_handle* h, int with_attributes)
     if (rc) return rc;
     const int nl = with_attributes ? 6 : 2;
     void* ptrs[6] = {h->layers.elevation, h->layers.variance, h->layers.intensity, h->layers.colorR, h->layers.colorG, h->layers.colorB};
-    const bool even = (h->L % h->nranks) == 0;
+    bool even = true;
+    for (int k = 0; k < h->nranks; ++k) even = even && h->strip_row[k + 1] - h->strip_row[k] == h->strip_row[1] - h->strip_row[0];
     ncclResult_t r = ncclGroupStart();
     for (int l = 0; l < nl && r == ncclSuccess; ++l) {
         unsigned char* base = static_cast<unsigned char*>(ptrs[l]);
         if (even) {
-            const size_t count = (size_t)(h->L / h->nranks) * h->L;      // 4-byte elements per rank
+            const size_t count = (size_t)(h->strip_row[1] - h->strip_row[0]) * h->L;      // 4-byte elements per rank
             r = ncclAllGather(base + (size_t)h->rank * count * 4, base, count, ncclFloat, h->comm, h->stream);   // in place
         } else {
             for (int k = 0; k < h->nranks && r == ncclSuccess; ++k) {
-                const size_t r0 = (size_t)((long long)h->L * k / h->nranks), r1 = (size_t)((long long)h->L * (k + 1) / h->nranks);
-                r = ncclBroadcast(base + r0 * h->L * 4, base + r0 * h->L * 4, (r1 - r0) * h->L, ncclFloat, k, h->comm, h->stream);
+                const size_t r0 = (size_t)h->strip_row[k], r1 = (size_t)h->strip_row[k + 1];
+                if (r1 > r0) r = ncclBroadcast(base + r0 * h->L * 4, base + r0 * h->L * 4, (r1 - r0) * h->L, ncclFloat, k, h->comm, h->stream);
             }
         }
     }
     ncclResult_t r2 = ncclGroupEnd();
     if (r != ncclSuccess || r2 != ncclSuccess) return fail(h, GEM_ERR_COMM, ncclGetErrorString(r != ncclSuccess ? r : r2));
     return GEM_OK;
+}
+
+// ---- multi-GPU with the POINTS sharded (SURVEY 8e stage B) ---------------------------------------------------------------------
+// Rank r holds a contiguous index range of the batch's points.  It projects, bins and sorts them for the WHOLE map
+// (gem_shard_sort_device); the sorted records of every strip go to the strip's owner, which walks its cells through the
+// sources in rank order -- ranks hold ascending index ranges, so rank order is input order and the result is the
+// single-device one bit for bit (gem_shard_fuse_device).  gem_add_sharded_device does both with an RCCL exchange in between.
+static int shard_checks(gem_handle* h, int n_global_sweeps, SortGeometry* geo)
+{
+    if (h->track_lowest) return fail(h, GEM_ERR_INVALID, "sharded path: lowest tracking is not supported (use the replicated path)");
+    *geo = sort_geometry(h, n_global_sweeps);
+    if (!geo->ok) return fail(h, GEM_ERR_INVALID, "sharded path: map or batch too large for the record key");
+    return GEM_OK;
+}
+
+int gem_shard_sort_device(gem_handle* h, int n_local_sweeps, const gem_frame_params* params, const void* d_xyzi, const long long* offsets,
+                          int first_global_sweep, int n_global_sweeps, int nstrips, const int* strip_rows,
+                          uint32_t* out_bounds, const void** out_d_hv, const void** out_d_key)
+{
+    if (!h || n_local_sweeps < 0 || nstrips <= 0 || nstrips > kMaxRanks || !strip_rows || first_global_sweep < 0 ||
+        first_global_sweep + n_local_sweeps > n_global_sweeps || (n_local_sweeps > 0 && (!params || !offsets || !d_xyzi)))
+        return h ? fail(h, GEM_ERR_INVALID, "gem_shard_sort_device: bad argument") : GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    for (int k = 0; k <= nstrips; ++k) {
+        const bool ok = (strip_rows[k] % 32 == 0 || strip_rows[k] >= h->L) && strip_rows[k] >= 0 && (k == 0 || strip_rows[k] >= strip_rows[k - 1]);
+        if (!ok) return fail(h, GEM_ERR_INVALID, "gem_shard_sort_device: strips must be whole rows of 32x32 tiles, ascending");
+    }
+    if (strip_rows[0] != 0 || strip_rows[nstrips] < h->L) return fail(h, GEM_ERR_INVALID, "gem_shard_sort_device: the strips must cover the map");
+    SortGeometry geo;
+    int rc = shard_checks(h, n_global_sweeps, &geo);
+    if (rc) return rc;
+    gem_handle::Shard& sd = h->shard;
+    const long long n = n_local_sweeps > 0 ? offsets[n_local_sweeps] - offsets[0] : 0;
+    if (n >= (1ll << 31)) return fail(h, GEM_ERR_INVALID, "gem_shard_sort_device: shard too large");
+    if (n == 0) {                                        // an empty shard contributes nothing to any strip
+        sd.valid = true; sd.hv = nullptr; sd.key = nullptr; sd.nstrips = nstrips;
+        for (int k = 0; k <= nstrips; ++k) sd.bounds[k] = 0;
+    } else {
+        for (int s = 0; s < n_local_sweeps; ++s) if (offsets[s + 1] < offsets[s]) return fail(h, GEM_ERR_INVALID, "gem_shard_sort_device: offsets not monotone");
+        PassInput in; in.src = 0; in.n_sweeps = n_local_sweeps; in.n = n; in.params = params; in.device_input = true;
+        std::vector<long long> off0(n_local_sweeps + 1);
+        for (int s = 0; s <= n_local_sweeps; ++s) off0[s] = offsets[s] - offsets[0];
+        in.offsets = off0.data(); in.var_updates = nullptr;
+        in.xyzi = static_cast<const float4*>(d_xyzi) + offsets[0];
+        ShardOpts so{first_global_sweep, nstrips, strip_rows};
+        if ((rc = run_sort_pipeline(h, in, 0, geo, &so))) return rc;
+    }
+    sd.n_global_sweeps = n_global_sweeps;
+    if (out_bounds) for (int k = 0; k <= nstrips; ++k) out_bounds[k] = sd.bounds[k];
+    if (out_d_hv) *out_d_hv = sd.hv;
+    if (out_d_key) *out_d_key = sd.key;
+    return GEM_OK;
+}
+
+static int shard_fuse_locked(gem_handle* h, int n_src, const void* const* d_hv, const void* const* d_key, const uint32_t* counts,
+                             int n_global_sweeps, const float* var_updates_global)
+{
+    SortGeometry geo;
+    int rc = shard_checks(h, n_global_sweeps, &geo);
+    if (rc) return rc;
+    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
+    WalkArgs wa{};
+    wa.n_src = std::max(n_src, 2);                       // always the multi-source form (a single source is followed by an empty one)
+    for (int s = 0; s < kMaxRanks; ++s) {
+        const bool on = s < n_src && counts[s] > 0;
+        wa.src_hv[s] = on ? static_cast<const uint2*>(d_hv[s]) : nullptr;
+        wa.src_key[s] = on ? static_cast<const uint32_t*>(d_key[s]) : nullptr;
+        wa.src_n[s] = on ? counts[s] : 0u;
+    }
+    wa.T = geo.T; wa.tiles_per_row = geo.tiles_per_row; wa.L = h->L; wa.row0 = h->row0; wa.row1 = h->row1;
+    wa.id_bits = geo.id_bits; wa.bin_shift = geo.dshift[geo.n_passes - 1]; wa.n_sweeps = n_global_sweeps;
+    wa.mahal = h->cfg.mahalanobis_threshold; wa.var_floor = h->cfg.variance_floor;
+    wa.dense = (h->n_pending > 0 || h->floor_dirty || var_updates_global != nullptr) ? 1 : 0;
+    wa.n_pending = h->n_pending;
+    for (int i = 0; i < kMaxPending; ++i) wa.pending[i] = h->pending[i];
+    wa.elevation = h->layers.elevation; wa.variance = h->layers.variance; wa.lowest = h->layers.lowest;
+    wa.start0 = h->start[0]; wa.start1 = h->start[1];
+    wa.counters = h->counting ? h->d_counters : nullptr;
+    wa.count_per_pass = 0;
+    wa.walk_stride = 1;
+    if (h->walk_permute) for (int pr : {1021, 1031, 2053, 4099, 509}) if ((16ll * geo.T) % pr != 0) { wa.walk_stride = pr; break; }
+    if (var_updates_global) {
+        if (n_global_sweeps > 512) return fail(h, GEM_ERR_INVALID, "sharded path: more than 512 sweeps");
+        if (!h->sh_host) GEM_HIP(h, hipHostMalloc(&h->sh_host, kShardHostBytes, hipHostMallocDefault));
+        if ((rc = ensure(h, h->sh_dev, 4096 + sizeof(float) * 512))) return rc;
+        float* hostf = reinterpret_cast<float*>(static_cast<unsigned char*>(h->sh_host) + 4096);
+        GEM_HIP(h, hipStreamSynchronize(h->stream));     // the staging buffer's previous upload has been read
+        memcpy(hostf, var_updates_global, sizeof(float) * n_global_sweeps);
+        float* dv = reinterpret_cast<float*>(static_cast<unsigned char*>(h->sh_dev.p) + 4096);
+        GEM_HIP(h, hipMemcpyAsync(dv, hostf, sizeof(float) * n_global_sweeps, hipMemcpyHostToDevice, h->stream));
+        wa.var_updates = dv;
+    }
+    if (h->counting) GEM_HIP(h, hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
+    { Timed t(h, 9); GEM_HIP(h, launch_walk(h->stream, wa, 0, t.events())); }
+    h->n_pending = 0;
+    h->floor_dirty = false;
+    h->main_reads_pb = true;
+    return GEM_OK;
+}
+
+int gem_shard_fuse_device(gem_handle* h, int n_src, const void* const* d_hv, const void* const* d_key, const uint32_t* counts,
+                          int n_global_sweeps, const float* var_updates_global)
+{
+    if (!h || n_src <= 0 || n_src > kMaxRanks || !d_hv || !d_key || !counts || n_global_sweeps <= 0)
+        return h ? fail(h, GEM_ERR_INVALID, "gem_shard_fuse_device: bad argument") : GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    return shard_fuse_locked(h, n_src, d_hv, d_key, counts, n_global_sweeps, var_updates_global);
+}
+
+int gem_add_sharded_device(gem_handle* h, int n_local_sweeps, const gem_frame_params* params, const void* d_xyzi, const long long* offsets,
+                           int first_global_sweep, int n_global_sweeps, const float* var_updates_global)
+{
+    if (!h) return GEM_ERR_INVALID;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (!h->comm || !h->tile_strips) return fail(h, GEM_ERR_COMM, "gem_add_sharded_device: gem_comm_init_tiles not called");
+    }
+    const int W = h->nranks;
+    int rc = gem_shard_sort_device(h, n_local_sweeps, params, d_xyzi, offsets, first_global_sweep, n_global_sweeps, W, h->strip_row,
+                                   nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    gem_handle::Shard& sd = h->shard;
+    // every rank learns what it receives from whom: an all-gather of the strip boundaries (W + 1 words per rank)
+    uint32_t* host = static_cast<uint32_t*>(h->sh_host);
+    if (!host) { GEM_HIP(h, hipHostMalloc(&h->sh_host, kShardHostBytes, hipHostMallocDefault)); host = static_cast<uint32_t*>(h->sh_host); }
+    if ((rc = ensure(h, h->sh_dev, 4096 + sizeof(float) * 512))) return rc;
+    uint32_t* d_mine = static_cast<uint32_t*>(h->sh_dev.p) + 16, *d_all = static_cast<uint32_t*>(h->sh_dev.p) + 64;   // [W][16]
+    for (int k = 0; k < 16; ++k) host[k] = k <= W ? sd.bounds[k] : 0u;
+    GEM_HIP(h, hipMemcpyAsync(d_mine, host, 16 * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    ncclResult_t r = ncclAllGather(d_mine, d_all, 16, ncclUint32, h->comm, h->stream);
+    if (r != ncclSuccess) return fail(h, GEM_ERR_COMM, ncclGetErrorString(r));
+    GEM_HIP(h, hipMemcpyAsync(host + 64, d_all, (size_t)W * 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    GEM_HIP(h, hipStreamSynchronize(h->stream));
+    uint32_t cnt[kMaxRanks], off[kMaxRanks + 1];
+    off[0] = 0;
+    for (int s = 0; s < W; ++s) {
+        cnt[s] = host[64 + s * 16 + h->rank + 1] - host[64 + s * 16 + h->rank];
+        off[s + 1] = off[s] + ((cnt[s] + 3u) & ~3u);        // every source segment starts at a multiple of four records
+    }
+    if ((rc = ensure(h, h->sh_recv_hv, (size_t)off[W] * 8 + 64))) return rc;
+    if ((rc = ensure(h, h->sh_recv_key, (size_t)off[W] * 4 + 64))) return rc;
+    uint2* rhv = static_cast<uint2*>(h->sh_recv_hv.p); uint32_t* rkey = static_cast<uint32_t*>(h->sh_recv_key.p);
+    // the exchange: every strip's records to its owner, received in source-rank order
+    r = ncclGroupStart();
+    for (int p = 0; p < W && r == ncclSuccess; ++p) {
+        const uint32_t sc = sd.bounds[p + 1] - sd.bounds[p];
+        if (sc > 0) {
+            r = ncclSend(sd.hv + sd.bounds[p], (size_t)sc * 2, ncclUint32, p, h->comm, h->stream);
+            if (r == ncclSuccess) r = ncclSend(sd.key + sd.bounds[p], sc, ncclUint32, p, h->comm, h->stream);
+        }
+        if (r == ncclSuccess && cnt[p] > 0) {
+            r = ncclRecv(rhv + off[p], (size_t)cnt[p] * 2, ncclUint32, p, h->comm, h->stream);
+            if (r == ncclSuccess) r = ncclRecv(rkey + off[p], cnt[p], ncclUint32, p, h->comm, h->stream);
+        }
+    }
+    ncclResult_t r2 = ncclGroupEnd();
+    if (r != ncclSuccess || r2 != ncclSuccess) return fail(h, GEM_ERR_COMM, ncclGetErrorString(r != ncclSuccess ? r : r2));
+    const void* phv[kMaxRanks]; const void* pkey[kMaxRanks];
+    for (int s = 0; s < W; ++s) { phv[s] = rhv + off[s]; pkey[s] = rkey + off[s]; }
+    return shard_fuse_locked(h, W, phv, pkey, cnt, n_global_sweeps, var_updates_global);
 }
 
 } // extern "C"

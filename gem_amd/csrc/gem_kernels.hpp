@@ -6,6 +6,7 @@
 namespace gem {
 
 constexpr int kMaxPending = 4;  // queued Mapvar_update increments folded into the next fuse
+constexpr int kMaxRanks = 8;    // devices of one node the tiling spans
 
 // (sweep, tile, unit) descriptor word, 16 bits:  start << 7 | count  (a unit holds 64 records; 0 = empty)
 constexpr int      kSegCountBits  = 7;
@@ -98,6 +99,7 @@ struct SortArgs {
     const long long*  sweep_first;     // [n_sweeps+1]  first point of each sweep in the concatenated cloud
     const int*        sweep_orig0;     // [n_sweeps]    original index of the sweep's first point, or NULL
     int               n_sweeps;
+    int               sweep_id0;       // id of the first sweep in the record keys (0; the first GLOBAL sweep of a multi-GPU shard)
     long long         n;               // total points
     const float4*   xyzi; const uint32_t* rgb; const int* orig;                       // SRC 0
     const int* f_index; const float* f_height; const float* f_var;                    // SRC 1: Fuse()'s arrays (GPU:1154)
@@ -144,6 +146,9 @@ struct WalkArgs {
     const int* f_R; const int* f_G; const int* f_B; const float* f_I;
     unsigned long long* counters;      // optional: [1] += distinct touched cells (per sweep unless count_per_pass)
     int   count_per_pass;
+    // multi-GPU strip owner (gem_add_sharded_device): the sorted records received from every rank, walked in rank order
+    int   n_src;                       // <= 1: the single source above (hv / key / src, searched through bin_base)
+    const uint2* src_hv[kMaxRanks]; const uint32_t* src_key[kMaxRanks]; uint32_t src_n[kMaxRanks];
 };
 
 struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };   // optional dispatch time-stamps
@@ -151,6 +156,7 @@ struct SortShape { int nt, chunk; size_t lds; };
 SortShape  sort_shape(int bins, bool attr);   // workgroup shape of a pass with that many bins
 hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, const LaunchEvents ev[9]);   // project, scan, scatter | count, scan, scatter | (count, scan, scatter)
 hipError_t launch_walk(hipStream_t st, const WalkArgs& a, int flags, LaunchEvents ev);
+hipError_t launch_strip_bounds(hipStream_t st, const uint32_t* keys, const uint32_t* n_records, int id_bits, const uint32_t* ids, uint32_t* out, int n);
 constexpr int kSortMaxBins = 8000;     // bins per pass the sorted pipeline handles (LDS of k_sort_scatter)
 
 hipError_t launch_project(hipStream_t st, const FrameConst& fc, int n, float* x, float* y, float* z, const int* orig,

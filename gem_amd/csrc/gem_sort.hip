@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void k_sort_project(SortArgs a)
     // every constant after every store (measured: 105 us instead of 25 for the 32 sweeps of C4)
     const FrameConst fc = a.sweep_chunk0 ? a.frames[cr.sweep] : a.frame0;
     const long long base = cr.first + (long long)(tid >> 6) * (K * 64) + (tid & 63);
-    const uint32_t sweep_bits = (uint32_t)cr.sweep << a.id_bits;
+    const uint32_t sweep_bits = (uint32_t)(cr.sweep + a.sweep_id0) << a.id_bits;   // (a shard of a multi-GPU batch numbers its sweeps globally)
     const uint32_t d0mask = (1u << a.dbits[0]) - 1u;
     __syncthreads();
     // blocks of eight points: the loads of a block are in flight together, then each point is projected, stored and counted
@@ -393,41 +393,27 @@ __global__ __launch_bounds__(64) void k_fuse_walk(WalkArgs a)
     __shared__ float vu[HAS_VU ? kWalkMaxSweeps : 1];
     const int lane = (int)threadIdx.x;
     // Block -> group of 64 cells through a stride permutation (walk_stride is coprime with the number of groups): the groups
-    // under the sensor carry chains a hundred times longer than the rim's, and neighbours in index would land on neighbouring
-    // SIMDs, which then issue two or three long chains each while the rest of the chip idles (measured: 89 -> 4x us on C4).
+    // under the sensor carry chains a hundred times longer than the rim's; consecutive blocks should not be neighbours.
     const uint32_t grp = (uint32_t)(((unsigned long long)blockIdx.x * (unsigned)a.walk_stride) % (unsigned)gridDim.x);
     const int tile = (int)(grp >> 4), q = (int)(grp & 15);
+    const int tr = tile / a.tiles_per_row, tc = tile - tr * a.tiles_per_row;
+    if ((tr << 5) >= a.row1 || (tr << 5) + 32 <= a.row0) return;       // a tile row outside this device's strip
     const uint32_t idmask = (1u << a.id_bits) - 1u;
     const uint32_t id0 = ((uint32_t)tile << 10) | ((uint32_t)q << 6);  // the cell ids of this wave: id0 .. id0 + 63
-    // the records of these cells lie inside the run of the pass-2 bin that holds id0 (64 divides the bin width)
-    const uint32_t bin = id0 >> a.bin_shift;
-    const uint32_t run_lo = a.bin_base[bin], run_hi = a.bin_base[bin + 1];
-    if (run_lo == run_hi && !a.dense) return;
-    // ---- 32-ary search, both ends at once: lanes 0-31 look for the first record with id >= id0, lanes 32-63 for id >= id0 + 64
-    uint32_t lo = run_lo, hi = run_hi;                                 // ids below `lo` are < target, ids from `hi` on are >= target
-    {
-        const uint32_t target = id0 + (uint32_t)(lane >> 5) * 64u, l5 = (uint32_t)lane & 31u;
-        while (__ballot(lo < hi) != 0) {                               // wave-uniform
-            const uint32_t n = hi - lo, s = (n + 32u) / 33u;           // probes lo + j s + s - 1, j = 0..31
-            const uint32_t pos = lo + l5 * s + s - 1u;
-            const bool probe = lo < hi && pos < hi;
-            const uint32_t id = probe ? (a.key[pos] & idmask) : 0xffffffffu;
-            const uint64_t bl = __ballot(probe && id < target);
-            const uint32_t k = (uint32_t)__popc((uint32_t)(bl >> (lane & 32)));   // a prefix of the probes: the ids are sorted
-            // probes 0 .. k-1 are below the target, probe k (if there is one: k < 32 and inside the range) is not
-            if (lo < hi) { const uint32_t nl = lo + k * s; if (k < 32u) hi = min(hi, nl + s - 1u); lo = nl; }
-        }
+    uint32_t run_lo = 0, run_hi = 0;
+    if (a.n_src <= 1) {
+        // one source (the device's own sort): the records of these cells lie inside the run of the last pass's bin that
+        // holds id0 (64 divides the bin width)
+        const uint32_t bin = id0 >> a.bin_shift;
+        run_lo = a.bin_base[bin]; run_hi = a.bin_base[bin + 1];
+        if (run_lo == run_hi && !a.dense) return;
     }
-    const uint32_t rb = (uint32_t)__shfl((int)lo, 0, 64), re = (uint32_t)__shfl((int)lo, 32, 64);
-    if (rb == re && !a.dense) return;
-                                  // nothing reaches these cells and nothing is pending
 
-    const int tr = tile / a.tiles_per_row, tc = tile - tr * a.tiles_per_row;
     const int row = (tr << 5) + (q << 1) + (lane >> 5), col = (tc << 5) + (lane & 31);
     const int L = a.L;
     const bool owned = row >= a.row0 && row < a.row1 && col < L;
     const size_t g = owned ? (size_t)row * L + col : 0;
-    const float e0 = a.elevation[g], s0 = a.variance[g];               // in flight behind the boundary scan
+    const float e0 = a.elevation[g], s0 = a.variance[g];               // in flight behind the search
     size_t lgeo = 0; float lw = 0.0f, lw0 = 0.0f;
     if constexpr (LOWEST) {                                            // map_lowest is indexed by the GEOGRAPHIC cell (GPU:430)
         int gr = row - a.start0, gc = col - a.start1;
@@ -435,46 +421,10 @@ __global__ __launch_bounds__(64) void k_fuse_walk(WalkArgs a)
         lgeo = owned ? (size_t)gr * L + gc : 0;
         lw0 = lw = a.lowest[lgeo];
     }
-    cstart[lane] = 0u; cend[lane] = 0u;
     if constexpr (HAS_VU) for (int i = lane; i < a.n_sweeps; i += 64) vu[i] = a.var_updates[i];
-    __syncthreads();
-    // ---- cell boundaries of the wave's run: the records are sorted by cell, so a cell starts -- and the one before it ends --
-    //      where the key's cell changes.  Sixteen loads in flight per round: the run of a wave under the sensor is thousands of
-    //      records long, and one load per round made this loop a chain of memory latencies (half of the kernel's time).
-    {
-        uint32_t carry = 0xffffffffu;                                  // cell of the record before the round's first (wave-uniform)
-        auto scan_rounds = [&](auto Uc, uint32_t p_begin, uint32_t p_end) {
-            constexpr int U = decltype(Uc)::value;
-            for (uint32_t p0 = p_begin; p0 < p_end; p0 += 64u * U) {   // wave-uniform
-                uint32_t c[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) { const uint32_t p = p0 + 64u * u + (uint32_t)lane; c[u] = a.key[min(p, re - 1u)] & 63u; }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const uint32_t p = p0 + 64u * u + (uint32_t)lane;
-                    const bool live = p < re;
-                    const uint32_t cell = live ? c[u] : 0xfffffffeu;
-                    uint32_t prev = (uint32_t)__shfl_up((int)cell, 1, 64);
-                    if (lane == 0) prev = carry;
-                    carry = (uint32_t)__builtin_amdgcn_readlane((int)cell, 63);
-                    if (live && cell != prev) { cstart[cell] = p; if (prev < 64u) cend[prev] = p; }
-                    if (p + 1u == re) cend[cell] = re;
-                }
-            }
-        };
-        // long runs (the waves under the sensor, a depth camera's near field) in rounds of 16 loads, the rest in rounds of 2
-        const uint32_t long_part = re - rb >= 2048u ? ((re - rb) / 1024u) * 1024u : 0u;
-        if (long_part) scan_rounds(std::integral_constant<int, 16>{}, rb, rb + long_part);
-        scan_rounds(std::integral_constant<int, 2>{}, rb + long_part, re);
-    }
-    __syncthreads();
-    const uint32_t first = cstart[lane], n = cend[lane] - first;
 
     float ce = e0, cs = s0;
-    // Mapvar_update increments queued before this pass, then the one of sweep 0 (GPU:540-547)
-    for (int k = 0; k < a.n_pending; ++k) if (cs != kInitVariance) cs += a.pending[k];
     uint32_t cur = 0;                                                  // "inside sweep cur, its increment applied"
-    if constexpr (HAS_VU) { if (cs != kInitVariance) cs += vu[0]; }
     // From sweep `cur` to sweep `to`: the floor that ends every Fuse (GPU:533-534), then the next sweep's increment.  The lanes of
     // a wave stand at unrelated sweeps, so this loop runs as long as the lane with the widest gap needs; the increment of the
     // lane's NEXT sweep is kept in a register (fetched behind the previous use), so that the common one-sweep gap costs no LDS
@@ -482,7 +432,6 @@ __global__ __launch_bounds__(64) void k_fuse_walk(WalkArgs a)
     // 69 -> 144 us on C4.)
     const uint32_t last_sw = (uint32_t)(a.n_sweeps > 0 ? a.n_sweeps - 1 : 0);
     float u1 = 0.0f;
-    if constexpr (HAS_VU) u1 = vu[min(1u, last_sw)];
     auto advance = [&](uint32_t to) {
         while (cur < to) {
             if (cs < a.var_floor) cs = a.var_floor;
@@ -491,8 +440,65 @@ __global__ __launch_bounds__(64) void k_fuse_walk(WalkArgs a)
             u1 = vu[min(cur + 1u, last_sw)];
         }
     };
-    uint32_t wlast = 0xffffffffu, sweeps_seen = 0, last_sweep = 0xffffffffu;
-    {   // The cell's own run.  The 64 lanes read 64 different streams, and a wave load whose lanes fall into 64 different cache
+    uint32_t wlast = 0xffffffffu, sweeps_seen = 0, last_sweep = 0xffffffffu, n_total = 0;
+
+    // ---- one SOURCE of records sorted by cell id: keys / {h, var} / source words, the part [lo0, hi0) that may hold this wave's
+    //      cells.  A single device has one source; a strip owner of the multi-GPU tiling walks the sources in rank order, which
+    //      is the input order of the points (gem_add_sharded_device).
+    auto walk_source = [&](const uint32_t* __restrict__ keys, const uint2* __restrict__ hvs, const uint32_t* __restrict__ srcs,
+                           uint32_t lo0, uint32_t hi0) {
+        // 32-ary search, both ends at once: lanes 0-31 look for the first record with id >= id0, lanes 32-63 for id >= id0 + 64
+        uint32_t lo = lo0, hi = hi0;                                   // ids below `lo` are < target, ids from `hi` on are >= target
+        {
+            const uint32_t target = id0 + (uint32_t)(lane >> 5) * 64u, l5 = (uint32_t)lane & 31u;
+            while (__ballot(lo < hi) != 0) {                           // wave-uniform
+                const uint32_t n = hi - lo, s = (n + 32u) / 33u;       // probes lo + j s + s - 1, j = 0..31
+                const uint32_t pos = lo + l5 * s + s - 1u;
+                const bool probe = lo < hi && pos < hi;
+                const uint32_t id = probe ? (keys[pos] & idmask) : 0xffffffffu;
+                const uint64_t bl = __ballot(probe && id < target);
+                const uint32_t k = (uint32_t)__popc((uint32_t)(bl >> (lane & 32)));   // a prefix of the probes: the ids are sorted
+                // probes 0 .. k-1 are below the target, probe k (if there is one: k < 32 and inside the range) is not
+                if (lo < hi) { const uint32_t nl = lo + k * s; if (k < 32u) hi = min(hi, nl + s - 1u); lo = nl; }
+            }
+        }
+        const uint32_t rb = (uint32_t)__shfl((int)lo, 0, 64), re = (uint32_t)__shfl((int)lo, 32, 64);
+        if (rb == re) return;                                          // wave-uniform: this source has nothing for these cells
+        __syncthreads();                                               // (the previous source's boundaries have been read)
+        cstart[lane] = 0u; cend[lane] = 0u;
+        __syncthreads();
+        // cell boundaries of the wave's run: the records are sorted by cell, so a cell starts -- and the one before it ends --
+        // where the key's cell changes.  Rounds of sixteen loads for long runs: the run of a wave under the sensor is thousands
+        // of records long, and one load per round made this loop a chain of memory latencies (half of the kernel's time).
+        {
+            uint32_t carry = 0xffffffffu;                              // cell of the record before the round's first (wave-uniform)
+            auto scan_rounds = [&](auto Uc, uint32_t p_begin, uint32_t p_end) {
+                constexpr int U = decltype(Uc)::value;
+                for (uint32_t p0 = p_begin; p0 < p_end; p0 += 64u * U) {   // wave-uniform
+                    uint32_t c[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { const uint32_t p = p0 + 64u * u + (uint32_t)lane; c[u] = keys[min(p, re - 1u)] & 63u; }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t p = p0 + 64u * u + (uint32_t)lane;
+                        const bool live = p < re;
+                        const uint32_t cell = live ? c[u] : 0xfffffffeu;
+                        uint32_t prev = (uint32_t)__shfl_up((int)cell, 1, 64);
+                        if (lane == 0) prev = carry;
+                        carry = (uint32_t)__builtin_amdgcn_readlane((int)cell, 63);
+                        if (live && cell != prev) { cstart[cell] = p; if (prev < 64u) cend[prev] = p; }
+                        if (p + 1u == re) cend[cell] = re;
+                    }
+                }
+            };
+            const uint32_t long_part = re - rb >= 2048u ? ((re - rb) / 1024u) * 1024u : 0u;
+            if (long_part) scan_rounds(std::integral_constant<int, 16>{}, rb, rb + long_part);
+            scan_rounds(std::integral_constant<int, 2>{}, rb + long_part, re);
+        }
+        __syncthreads();
+        const uint32_t first = cstart[lane], n = cend[lane] - first;
+        n_total += n;
+        // The cell's own run.  The 64 lanes read 64 different streams, and a wave load whose lanes fall into 64 different cache
         // lines occupies the CU's vector L1 for 64 cycles whatever its width: with one 8-byte and one 4-byte load per step the
         // waves of a CU queue up at the L1 (125 us for the 32 sweeps of C4).  So the records come in GROUPS of four steps, as
         // 16-byte loads -- two {h, var} pairs, four keys per request: 0.75 requests per step instead of 2 -- and three groups
@@ -501,12 +507,12 @@ __global__ __launch_bounds__(64) void k_fuse_walk(WalkArgs a)
         struct Group { Quad h01, h23, k4, s4; };
         const uint32_t nmax = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_max(n), 63);    // the wave's longest run: no loads beyond it
         const uint32_t glast = n ? (n - 1u) >> 2 : 0u;
-        const uint2* hp = a.hv + (n ? first : 0u);
-        const uint32_t* kp = a.key + (n ? first : 0u);
-        const uint32_t* sp = a.src + (n ? first : 0u);
-        auto load_group = [&](uint32_t g, Group& G) {
-            if (4u * g < nmax) {                                       // wave-uniform
-                const uint32_t r = 4u * min(g, glast);
+        const uint2* hp = hvs + (n ? first : rb);
+        const uint32_t* kp = keys + (n ? first : rb);
+        const uint32_t* sp = srcs + (n ? first : rb);
+        auto load_group = [&](uint32_t gi, Group& G) {
+            if (4u * gi < nmax) {                                      // wave-uniform
+                const uint32_t r = 4u * min(gi, glast);
                 G.h01 = *reinterpret_cast<const Quad*>(hp + r);
                 G.h23 = *reinterpret_cast<const Quad*>(hp + r + 2u);
                 if (KEYED) G.k4 = *reinterpret_cast<const Quad*>(kp + r);
@@ -536,14 +542,26 @@ __global__ __launch_bounds__(64) void k_fuse_walk(WalkArgs a)
         };
         Group A{}, B{}, C{};
         load_group(0u, A); load_group(1u, B); load_group(2u, C);
-        for (uint32_t g = 0; 4u * g < nmax; g += 3u) {                 // wave-uniform
-            run_group(4u * g, A);       load_group(g + 3u, A);
-            if (4u * g + 4u >= nmax) break;
-            run_group(4u * g + 4u, B);  load_group(g + 4u, B);
-            if (4u * g + 8u >= nmax) break;
-            run_group(4u * g + 8u, C);  load_group(g + 5u, C);
+        for (uint32_t gi = 0; 4u * gi < nmax; gi += 3u) {              // wave-uniform
+            run_group(4u * gi, A);       load_group(gi + 3u, A);
+            if (4u * gi + 4u >= nmax) break;
+            run_group(4u * gi + 4u, B);  load_group(gi + 4u, B);
+            if (4u * gi + 8u >= nmax) break;
+            run_group(4u * gi + 8u, C);  load_group(gi + 5u, C);
         }
+    };
+
+    __syncthreads();                                                   // vu is in LDS
+    // Mapvar_update increments queued before this pass, then the one of sweep 0 (GPU:540-547)
+    for (int k = 0; k < a.n_pending; ++k) if (cs != kInitVariance) cs += a.pending[k];
+    if constexpr (HAS_VU) { if (cs != kInitVariance) cs += vu[0]; u1 = vu[min(1u, last_sw)]; }
+    if (a.n_src <= 1) {
+        walk_source(a.key, a.hv, a.src, run_lo, run_hi);
+    } else {
+        for (int sidx = 0; sidx < a.n_src; ++sidx)                     // rank order = input order
+            walk_source(a.src_key[sidx], a.src_hv[sidx], nullptr, 0u, a.src_n[sidx]);
     }
+    if (__ballot(n_total != 0) == 0 && !a.dense) return;               // nothing reached these cells and nothing is pending
     if constexpr (HAS_VU) advance(last_sw);
     if (cs < a.var_floor) cs = a.var_floor;                            // GPU:533-534, on every cell
 
@@ -567,10 +585,29 @@ __global__ __launch_bounds__(64) void k_fuse_walk(WalkArgs a)
         }
     }
     if (a.counters) {                                                  // distinct touched cells: per pass, or summed over the sweeps
-        const uint32_t mine = COUNT_SWEEPS ? sweeps_seen : (n ? 1u : 0u);
+        const uint32_t mine = COUNT_SWEEPS ? sweeps_seen : (n_total ? 1u : 0u);
         const uint32_t s = wave_inclusive_scan(mine);
         if (lane == 63 && s) atomicAdd(&a.counters[1], (unsigned long long)s);
     }
+}
+
+// The boundaries of the tile-row strips in a device's sorted records (multi-GPU tiling): out[k] = first record whose cell id is
+// >= ids[k].  One wave per boundary, the 32-ary search of k_fuse_walk over the whole array.
+__global__ __launch_bounds__(64) void k_strip_bounds(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ n_records, int id_bits,
+                                                     const uint32_t* __restrict__ ids, uint32_t* __restrict__ out)
+{
+    const int lane = (int)threadIdx.x;
+    const uint32_t idmask = (1u << id_bits) - 1u, target = ids[blockIdx.x], l5 = (uint32_t)lane & 31u;
+    uint32_t lo = 0, hi = *n_records;
+    while (__ballot(lo < hi) != 0) {
+        const uint32_t n = hi - lo, s = (n + 32u) / 33u;
+        const uint32_t pos = lo + l5 * s + s - 1u;
+        const bool probe = lane < 32 && lo < hi && pos < hi;
+        const uint32_t id = probe ? (keys[pos] & idmask) : 0xffffffffu;
+        const uint32_t k = (uint32_t)__popc((uint32_t)__ballot(probe && id < target));
+        if (lo < hi) { const uint32_t nl = lo + k * s; if (k < 32u) hi = min(hi, nl + s - 1u); lo = nl; }
+    }
+    if (lane == 0) out[blockIdx.x] = lo;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -693,6 +730,13 @@ static hipError_t launch_walk_f(hipStream_t st, const WalkArgs& a, int mode, Lau
     case 2:  GEM_LAUNCH((k_fuse_walk<FLAGS, 2>), grid, block, 0, st, ev, a); break;
     default: GEM_LAUNCH((k_fuse_walk<FLAGS, 3>), grid, block, 0, st, ev, a); break;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_strip_bounds(hipStream_t st, const uint32_t* keys, const uint32_t* n_records, int id_bits, const uint32_t* ids, uint32_t* out, int n)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_strip_bounds, dim3(n), dim3(64), 0, st, keys, n_records, id_bits, ids, out);
     return hipGetLastError();
 }
 

@@ -29,6 +29,39 @@ def all_strips(length: int, world: int):
     return [strip_bounds(length, world, r) for r in range(world)]
 
 
+def tile_strip_rows(length: int, world: int):
+    """Strip boundaries [world + 1] made of whole rows of 32 x 32-cell tiles; identical to gem_comm_init_tiles()."""
+    tile_rows = (length + 31) // 32
+    return [min(length, 32 * ((tile_rows * k) // world)) for k in range(world + 1)]
+
+
+def shard_batch(offsets, world: int, rank: int):
+    """Rank `rank`'s contiguous share [N r / W, N (r+1) / W) of a batch of sweeps (offsets[n_sweeps + 1] into the
+    concatenated cloud): returns (first_global_sweep, local_offsets) -- the local sweeps are first_global_sweep ..
+    first_global_sweep + len(local_offsets) - 2, the first / last possibly a part of a sweep that a neighbour also holds.
+    Ranks hold ascending index ranges: rank order is input order."""
+    off = [int(v) for v in offsets]
+    n, ns = off[-1], len(off) - 1
+    lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+    if lo >= hi:
+        return 0, [lo]
+    first = next(s for s in range(ns) if off[s + 1] > lo)
+    last = max(s for s in range(ns) if off[s] < hi)
+    # (empty sweeps inside the range stay in the list: local sweep i IS global sweep first + i)
+    return first, [max(off[first], lo)] + [min(max(off[s + 1], lo), hi) for s in range(first, last + 1)]
+
+
+def route_sorted_records(bounds_by_rank, rank: int):
+    """Stage-B routing table.  bounds_by_rank[s][k] = first record of strip k in rank s's sorted records.  Returns
+    (send, recv): send[d] = (begin, end) of what this rank sends to strip owner d; recv[s] = number of records it gets
+    from rank s -- to be concatenated in ascending s, which is the input order of the points."""
+    mine = bounds_by_rank[rank]
+    world = len(bounds_by_rank)
+    send = [(int(mine[d]), int(mine[d + 1])) for d in range(world)]
+    recv = [int(bounds_by_rank[s][rank + 1]) - int(bounds_by_rank[s][rank]) for s in range(world)]
+    return send, recv
+
+
 class _DeviceArray:
     """Zero-copy view of device memory for torch.as_tensor (CUDA array interface v2)."""
 
@@ -36,30 +69,35 @@ class _DeviceArray:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
-def exchange_strips_torch(tensors: Sequence, length: int, world: int, rank: int, group=None) -> None:
-    """In-place all-gather of row strips: tensors are [L, L] (row-major) and rank r's rows are valid."""
+def exchange_strips_torch(tensors: Sequence, length: int, world: int, rank: int, group=None, strip_rows=None) -> None:
+    """In-place all-gather of row strips: tensors are [L, L] (row-major) and rank r's rows are valid.  strip_rows[world + 1]
+    gives the strip boundaries (default: the even split of gem_comm_init)."""
     import torch.distributed as dist
-    even = length % world == 0
+    rows = list(strip_rows) if strip_rows is not None else [strip_bounds(length, world, r)[0] for r in range(world)] + [length]
+    even = all(rows[k + 1] - rows[k] == rows[1] - rows[0] for k in range(world))
     backend = dist.get_backend(group)
     for t in tensors:
         if even and backend == "nccl":
-            r0, r1 = strip_bounds(length, world, rank)
-            dist.all_gather_into_tensor(t, t[r0:r1], group=group)          # in place: input is output's own slice
+            dist.all_gather_into_tensor(t, t[rows[rank]:rows[rank + 1]], group=group)      # in place: input is output's own slice
         else:
             for src in range(world):                                        # uneven strips / gloo: one broadcast per owner
-                r0, r1 = strip_bounds(length, world, src)
-                if r1 > r0:
-                    dist.broadcast(t[r0:r1], src=src, group=group)
+                if rows[src + 1] > rows[src]:
+                    dist.broadcast(t[rows[src]:rows[src + 1]], src=src, group=group)
 
 
 class TiledElevationMap:
     """One rank's share of a map tiled over `world` ranks.  `make_map(length, resolution, strip=(row0, rows))`
-    builds the local map (gem_amd.ElevationMap in production; tests inject a CPU stand-in)."""
+    builds the local map (gem_amd.ElevationMap in production; tests inject a CPU stand-in).
+
+    tile_strips=True makes the strips whole rows of 32 x 32-cell tiles, which add_sharded() needs (SURVEY 8e stage B: every
+    rank bins only ITS share of the points; the sorted records travel to the strip owners)."""
 
     def __init__(self, length: int, resolution: float, rank: int, world: int, make_map: Optional[Callable] = None,
-                 exchange: str = "rccl", unique_id: Optional[bytes] = None, **map_kwargs):
+                 exchange: str = "rccl", unique_id: Optional[bytes] = None, tile_strips: bool = False, **map_kwargs):
         self.length, self.resolution, self.rank, self.world = int(length), float(resolution), int(rank), int(world)
-        self.row0, self.row1 = strip_bounds(length, world, rank)
+        self.tile_strips = bool(tile_strips)
+        self.strip_rows = tile_strip_rows(length, world) if tile_strips else [strip_bounds(length, world, r)[0] for r in range(world)] + [length]
+        self.row0, self.row1 = self.strip_rows[rank], self.strip_rows[rank + 1]
         if make_map is None:
             from .api import ElevationMap
             make_map = ElevationMap
@@ -69,9 +107,49 @@ class TiledElevationMap:
         if exchange == "rccl":
             if unique_id is None:
                 raise ValueError("exchange='rccl' needs the ncclUniqueId created by rank 0 (ElevationMap.comm_unique_id())")
-            self.map.comm_init(unique_id, world, rank)
+            (self.map.comm_init_tiles if tile_strips else self.map.comm_init)(unique_id, world, rank)
         elif exchange != "torch":
             raise ValueError("exchange must be 'rccl' or 'torch'")
+
+    # -- stage B: the points sharded, the sorted records routed to the strip owners -----------------------------------------------
+    def add_sharded(self, frames, xyzi, offsets, var_updates=None, group=None) -> None:
+        """for s: Mapvar_update(var_updates[s]); add(frames[s], cloud s) on the tiled map, every rank working on its own
+        contiguous share of the points (`xyzi` is the whole concatenated batch, or at least this rank's share, on this
+        rank's device; `frames` / `offsets` / `var_updates` describe the whole batch and are identical on all ranks)."""
+        if not self.tile_strips:
+            raise ValueError("add_sharded needs tile_strips=True")
+        n_global = len(frames)
+        first, local = shard_batch(offsets, self.world, self.rank)
+        local_frames = [frames[first + i] for i in range(len(local) - 1)]
+        pb = self.map.pack_batch(local_frames, local, None)
+        if self.exchange == "rccl":
+            self.map.add_sharded(pb, xyzi, first, n_global, var_updates)
+            return
+        # the exchange carried by torch.distributed (gloo on CPU stand-ins, NCCL == RCCL on devices)
+        import torch
+        import torch.distributed as dist
+        bounds, hv, key = self.map.shard_sort_tensors(pb, xyzi, first, n_global, self.strip_rows)
+        gathered = [torch.zeros(self.world + 1, dtype=torch.int64, device=hv.device) for _ in range(self.world)]    # (NCCL carries device tensors only)
+        dist.all_gather(gathered, torch.as_tensor(bounds, dtype=torch.int64).to(hv.device), group=group)
+        send, recv = route_sorted_records([g.tolist() for g in gathered], self.rank)
+        hv_in = [torch.empty((c, 2), dtype=hv.dtype, device=hv.device) for c in recv]
+        key_in = [torch.empty((c,), dtype=key.dtype, device=key.device) for c in recv]
+        hv_out = [hv[a:b].contiguous() for a, b in send]
+        key_out = [key[a:b].contiguous() for a, b in send]
+        if dist.get_backend(group) == "gloo":                      # gloo has no all_to_all: W rounds of pairwise exchanges
+            for shift in range(self.world):
+                dst, src = (self.rank + shift) % self.world, (self.rank - shift) % self.world
+                if shift == 0:
+                    hv_in[self.rank].copy_(hv_out[self.rank]); key_in[self.rank].copy_(key_out[self.rank])
+                    continue
+                ops = [dist.P2POp(dist.isend, hv_out[dst], dst, group), dist.P2POp(dist.isend, key_out[dst], dst, group),
+                       dist.P2POp(dist.irecv, hv_in[src], src, group), dist.P2POp(dist.irecv, key_in[src], src, group)]
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+        else:
+            dist.all_to_all(hv_in, hv_out, group=group)
+            dist.all_to_all(key_in, key_out, group=group)
+        self.map.shard_fuse_tensors(hv_in, key_in, n_global, var_updates)      # ascending source rank = input order
 
     # the map operations every rank performs identically
     def move(self, position):
@@ -104,7 +182,7 @@ class TiledElevationMap:
         names = ("elevation", "variance") + (("intensity", "color_r", "color_g", "color_b") if with_attributes else ())
         if hasattr(self.map, "synchronize"):
             self.map.synchronize()               # torch's stream does not know about the handle's stream
-        exchange_strips_torch(self.layer_tensors(names), self.length, self.world, self.rank, group)
+        exchange_strips_torch(self.layer_tensors(names), self.length, self.world, self.rank, group, self.strip_rows)
 
     def layer(self, name):
         return self.map.layer(name)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GEM_ABI_VERSION 5
+#define GEM_ABI_VERSION 6
 
 typedef enum gem_status {
     GEM_OK = 0,
@@ -209,10 +209,37 @@ int  gem_set_timing(gem_handle* h, int enabled);      /* record hipEvents around
 int  gem_set_counting(gem_handle* h, int enabled);    /* count binned points / touched cells on device */
 int  gem_get_stats(gem_handle* h, gem_stats* out, int reset);
 
-/* ---- multi-GPU: RCCL all-gather of the fused strips over xGMI ------------------------ */
+/* ---- multi-GPU: RCCL all-gather of the fused strips over xGMI ------------------------
+ *      One process per GPU, one handle per process.  gem_comm_init splits the map into row strips in STORAGE coordinates
+ *      (rank r owns rows [L r / W, L (r+1) / W): Move never migrates data); gem_comm_init_tiles makes the strips whole rows of
+ *      32 x 32-cell tiles, which the sharded path below needs.  gem_allgather_layers completes every rank's copy of the layers
+ *      (in-place ncclAllGather when the strips are equal, grouped ncclBroadcasts otherwise), enqueued on the handle's stream.
+ *      Stage A (replicated binning): every rank calls gem_add* with the WHOLE cloud and fuses only its strip.             */
 int  gem_comm_unique_id(void* out_128_bytes);
 int  gem_comm_init(gem_handle* h, const void* unique_id_128_bytes, int nranks, int rank);
+int  gem_comm_init_tiles(gem_handle* h, const void* unique_id_128_bytes, int nranks, int rank);
+int  gem_get_strip(gem_handle* h, int* out_row0, int* out_row1);
 int  gem_allgather_layers(gem_handle* h, int with_attributes);   /* elevation+variance (+intensity, colours) */
+
+/*      Stage B (points sharded): rank r holds a contiguous index range of the batch -- sweeps first_global_sweep ..
+ *      first_global_sweep + n_local_sweeps - 1 of n_global_sweeps (a sweep may be split between two neighbouring ranks: both
+ *      pass it, the lower rank holds its head).  gem_add_sharded_device = for s: Mapvar_update(var_updates_global[s]);
+ *      add(sweep s) on the map tiled over the ranks: each rank projects / bins / sorts its own points for the whole map, the
+ *      sorted records of every strip travel to the strip's owner (ncclSend / ncclRecv, one group), and the owner walks its
+ *      cells through the sources in rank order -- ascending index ranges, so rank order is input order and every cell sees
+ *      its points exactly as on one device.  Follow with gem_allgather_layers.  var_updates_global (n_global_sweeps values,
+ *      identical on all ranks) may be NULL.  No colours, no lowest tracking on this path.
+ *      The two halves are exported for hosts that carry the exchange themselves (gem_amd/tiling.py with torch.distributed):
+ *      gem_shard_sort_device returns the device arrays of the sorted records {h, var} (8 bytes) / keys (4 bytes) and
+ *      out_bounds[nstrips + 1], the first record of every strip; gem_shard_fuse_device walks this handle's strip through
+ *      n_src sources (device pointers and record counts, in input order).                                               */
+int  gem_add_sharded_device(gem_handle* h, int n_local_sweeps, const gem_frame_params* params, const void* d_xyzi,
+                            const long long* offsets, int first_global_sweep, int n_global_sweeps, const float* var_updates_global);
+int  gem_shard_sort_device(gem_handle* h, int n_local_sweeps, const gem_frame_params* params, const void* d_xyzi,
+                           const long long* offsets, int first_global_sweep, int n_global_sweeps, int nstrips, const int* strip_rows,
+                           uint32_t* out_bounds, const void** out_d_hv, const void** out_d_key);
+int  gem_shard_fuse_device(gem_handle* h, int n_src, const void* const* d_hv, const void* const* d_key, const uint32_t* counts,
+                           int n_global_sweeps, const float* var_updates_global);
 
 #ifdef __cplusplus
 }
