@@ -75,6 +75,7 @@ SIGNATURES = {
     "gem_comm_unique_id": (c_int, [c_void_p]),
     "gem_comm_init": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "gem_allgather_layers": (c_int, [c_void_p, c_int]),
+    "gem_show": (c_int, [c_void_p, c_double, c_double, POINTER(c_double), c_void_p, c_void_p, c_void_p, POINTER(c_int), c_void_p]),
     "gem_comm_init_tiles": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "gem_get_strip": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     "gem_add_sharded_device": (c_int, [c_void_p, c_int, POINTER(FrameParams), c_void_p, POINTER(c_longlong), c_int, c_int, POINTER(c_float)]),

@@ -385,6 +385,20 @@ class ElevationMap:
                                               p(out["traver"]), None), "gem_map_feature")
         return out
 
+    # -- the feed of ElevationMap::show (ElevationMap.cpp:85-149) ------------------------------------------------------------------
+    def show(self, map_length: float = 0.0, resolution: float = 0.0, position=None):
+        """visualMap_'s nine layers ([9, L, L], grid_map's column-major layout, NaN for cells without elevation / traversability),
+        the coloured point cloud (device-compacted, reference order) and the orthomosaic, from the resident layers (gem_show)."""
+        L = self.length
+        visual = np.empty((9, L * L), np.float32); xyz = np.empty((L * L, 3), np.float32); rgb = np.empty((L * L, 3), np.uint8)
+        img = np.empty((L, L, 3), np.uint8)
+        n = C.c_int()
+        pos = None if position is None else (C.c_double * 2)(float(position[0]), float(position[1]))
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._check(self._lib.gem_show(self._h, float(map_length), float(resolution), pos, vp(visual), vp(xyz), vp(rgb), C.byref(n), vp(img)), "gem_show")
+        k = int(n.value)
+        return {"visual": visual.reshape(9, L, L), "points_xyz": xyz[:k].copy(), "points_rgb": rgb[:k].copy(), "image_bgr": img, "count": k}
+
     # -- layers ----------------------------------------------------------------------------------------
     def layer(self, name_or_id, layout: int = _lib.LAYOUT_STORAGE_ROWMAJOR) -> np.ndarray:
         lid = LAYER_BY_NAME[name_or_id] if isinstance(name_or_id, str) else int(name_or_id)

@@ -81,6 +81,7 @@ struct gem_handle {
     long long sort_min_points = 200000;
     bool walk_permute = true;           // k_fuse_walk: blocks mapped to cell groups through a stride permutation
     int  sort_passes = 0;               // 0 = by map size (two digits up to 2^20 cells, else three); 2 / 3 force it
+    bool bin_priority = false;          // create the second stream with high priority (measured: no effect on C4 / C5)
     int dbg_sweep = 0;                  // debug stamps of the dense path: which sweep (GEM_DBG_SWEEP)
     bool track_lowest = false;          // also maintain map_lowest in the fuse kernels (gem_set_lowest_tracking, for gem_raytracing)
     unsigned dense_min = 2048;          // records of one sweep in one 16x16 tile above which the tile is counting-sorted (k_fuse_list, dense path)
@@ -251,6 +252,17 @@ struct PassInput {
 constexpr int       kUnit = 64;                      // points per unit (one wave of k_bin_wave)
 constexpr long long kSweepPoints = 2048ll * kUnit;   // a single cloud longer than this is processed as a batch of sweeps of this size
 
+// The second stream carries the map-independent half of a big pass (projection / binning / sorting) next to the fusion of the
+// pass before.  High priority: its kernels are the bandwidth-bound ones, the fusion is a few long chains -- when both are
+// resident the sort should get the slots that free up (debug knob "bin_priority": 0 = default priority).
+static hipError_t create_bin_stream(gem_handle* h)
+{
+    int lo = 0, hi = 0;
+    if (h->bin_priority && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
+        return hipStreamCreateWithPriority(&h->bin_stream, hipStreamNonBlocking, hi);
+    return hipStreamCreateWithFlags(&h->bin_stream, hipStreamNonBlocking);
+}
+
 static int ceil_log2(int v) { int b = 0; while ((1 << b) < v) ++b; return b; }
 
 // the key geometry of the sorted pipeline for this map, and whether a pass of `n_sweeps` sweeps fits the 32-bit record key
@@ -301,7 +313,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     h->T = T;
 
     bool overlap = h->overlap && in.n >= h->overlap_min_points && h->stream == h->own_stream && !h->counting && !shard;
-    if (overlap && !h->bin_stream && hipStreamCreateWithFlags(&h->bin_stream, hipStreamNonBlocking) != hipSuccess) {
+    if (overlap && !h->bin_stream && create_bin_stream(h) != hipSuccess) {
         h->bin_stream = nullptr; overlap = false; (void)hipGetLastError();
     }
     { const int rcd = flush_deferred(h); if (rcd) return rcd; }
@@ -557,7 +569,7 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     // The cross-stream event pair costs ~3 us per pass (measured), so it only pays for big passes
     // (batches / aggregated clouds: C4 379 -> 313 us); single sweeps stay on one stream.
     bool overlap = h->overlap && in.n >= h->overlap_min_points && h->stream == h->own_stream && !h->counting && !h->dbg_on;
-    if (overlap && !h->bin_stream && hipStreamCreateWithFlags(&h->bin_stream, hipStreamNonBlocking) != hipSuccess) {
+    if (overlap && !h->bin_stream && create_bin_stream(h) != hipSuccess) {
         h->bin_stream = nullptr; overlap = false; (void)hipGetLastError();
     }
     // one launch per frame for a stream of single sweeps (k_frame): needs the other half of the double buffer
@@ -1179,6 +1191,43 @@ int gem_map_feature(gem_handle* h, float* elevation, float* variance, int* color
     return GEM_OK;
 }
 
+// ElevationMap::show's cell loop (ElevationMap.cpp:85-149) on the resident layers: visualMap_'s nine layers in grid_map's own
+// layout, the coloured point cloud (compacted on the device, in the reference's iteration order) and the orthomosaic.
+int gem_show(gem_handle* h, double map_length, double resolution, const double position[2],
+             float* visual, float* points_xyz, unsigned char* points_rgb, int* out_count, unsigned char* image_bgr)
+{
+    if (!h) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    int rc = flush_pending(h, false);
+    if (rc) return rc;
+    const size_t cells = (size_t)h->cells, blocks = (cells + 1023) / 1024;
+    // scratch: block counts | total | visual 9 L^2 floats | xyz 3 L^2 floats | rgb 3 L^2 bytes | image 3 L^2 bytes
+    const size_t o_cnt = 0, o_total = o_cnt + blocks * 4, o_vis = (o_total + 4 + 255) & ~(size_t)255, o_xyz = o_vis + cells * 36,
+                 o_rgb = o_xyz + cells * 12, o_img = (o_rgb + cells * 3 + 255) & ~(size_t)255, total_bytes = o_img + cells * 3;
+    if ((rc = ensure(h, h->scratch, total_bytes))) return rc;
+    unsigned char* d = static_cast<unsigned char*>(h->scratch.p);
+    const double res = resolution > 0.0 ? resolution : (double)h->res;
+    const double len = map_length > 0.0 ? map_length : (double)h->L * res;
+    const double px = position ? position[0] : (double)h->center[0], py = position ? position[1] : (double)h->center[1];
+    if (image_bgr) GEM_HIP(h, hipMemsetAsync(d + o_img, 0, cells * 3, h->stream));          // cv::Mat(..., Scalar(0, 0, 0)), EM.cpp:87
+    GEM_HIP(h, launch_show(h->stream, h->layers, h->L, h->start[0], h->start[1], len, res, px, py, reinterpret_cast<uint32_t*>(d + o_cnt),
+                           visual ? reinterpret_cast<float*>(d + o_vis) : nullptr, (points_xyz || points_rgb) ? reinterpret_cast<float*>(d + o_xyz) : nullptr,
+                           points_rgb ? d + o_rgb : nullptr, image_bgr ? d + o_img : nullptr, reinterpret_cast<uint32_t*>(d + o_total)));
+    uint32_t n = 0;
+    GEM_HIP(h, hipMemcpyAsync(&n, d + o_total, 4, hipMemcpyDeviceToHost, h->stream));
+    if (visual) GEM_HIP(h, hipMemcpyAsync(visual, d + o_vis, cells * 36, hipMemcpyDeviceToHost, h->stream));
+    if (image_bgr) GEM_HIP(h, hipMemcpyAsync(image_bgr, d + o_img, cells * 3, hipMemcpyDeviceToHost, h->stream));
+    GEM_HIP(h, hipStreamSynchronize(h->stream));
+    if (n) {                                            // only the kept cells' points travel
+        if (points_xyz) GEM_HIP(h, hipMemcpyAsync(points_xyz, d + o_xyz, (size_t)n * 12, hipMemcpyDeviceToHost, h->stream));
+        if (points_rgb) GEM_HIP(h, hipMemcpyAsync(points_rgb, d + o_rgb, (size_t)n * 3, hipMemcpyDeviceToHost, h->stream));
+        GEM_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    if (out_count) *out_count = (int)n;
+    return GEM_OK;
+}
+
 int gem_set_lowest_tracking(gem_handle* h, int enabled)
 {
     if (!h) return GEM_ERR_INVALID;
@@ -1261,6 +1310,7 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "sort_path")          h->sort_path = value != 0;
     else if (k == "sort_min_points")    h->sort_min_points = value;
     else if (k == "walk_permute")       h->walk_permute = value != 0;
+    else if (k == "bin_priority")       h->bin_priority = value != 0;
     else if (k == "sort_passes")        { if (value != 0 && value != 2 && value != 3) return fail(h, GEM_ERR_INVALID, "sort_passes: 0, 2 or 3"); h->sort_passes = (int)value; }
     else return fail(h, GEM_ERR_INVALID, "gem_debug_set: unknown key");
     return GEM_OK;

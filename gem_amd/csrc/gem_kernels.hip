@@ -1072,6 +1072,95 @@ __global__ __launch_bounds__(256) void k_export_gridmap(const void* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
+// The feed of ElevationMap::show (EM.cpp:85-149): the reference walks all L^2 cells on the host in grid_map's
+// iteration order (linear index of the column-major matrix = buffer index), copies nine layers into visualMap_ where the cell
+// holds an elevation AND a traversability, pushes a coloured point per such cell and paints the orthomosaic.  Here two small
+// kernels do it on the resident layers: k_show_count counts the kept cells per block of 1024 linear indices, k_show_emit turns
+// the counts of the blocks before it into its offset (order preserved: the point list equals the reference's) and writes the
+// column-major layers (NaN elsewhere), the compacted points and the image.  Positions are grid_map's getPositionFromIndex in
+// double (GridMapMath.cpp): mapPosition + (mapLength / 2 - resolution / 2) - resolution * unwrapped index.
+// ------------------------------------------------------------------------------------------
+struct ShowArgs {
+    LayerPtrs m; int L, sx, sy;
+    double off, res, px, py;                 // off = 0.5 * map_length - 0.5 * resolution
+    uint32_t* block_count;                   // [blocks]
+    float* visual; float* xyz; unsigned char* rgb; unsigned char* image; uint32_t* total;
+};
+
+__device__ __forceinline__ bool show_keep(const ShowArgs& a, size_t lin, size_t& index, int& ix, int& iy)
+{
+    ix = (int)(lin % (size_t)a.L); iy = (int)(lin / (size_t)a.L);       // EM.cpp:98-99: the buffer index of the linear index
+    index = (size_t)ix * a.L + iy;                                      // EM.cpp:100
+    const float tr = a.m.traver[index];
+    return a.m.elevation[index] != kEmptyElevation && tr != -10.0f && !(tr != tr);   // EM.cpp:101
+}
+
+__global__ __launch_bounds__(1024) void k_show_count(ShowArgs a)
+{
+    __shared__ uint32_t scratch[16];
+    const size_t lin = (size_t)blockIdx.x * 1024 + threadIdx.x, cells = (size_t)a.L * a.L;
+    size_t index; int ix, iy;
+    const bool keep = lin < cells && show_keep(a, lin, index, ix, iy);
+    uint32_t total;
+    block_exclusive_scan<1024>(keep ? 1u : 0u, scratch, &total);
+    if (threadIdx.x == 0) a.block_count[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void k_show_emit(ShowArgs a)
+{
+    __shared__ uint32_t scratch[16];
+    __shared__ uint32_t s_base;
+    const size_t lin = (size_t)blockIdx.x * 1024 + threadIdx.x, cells = (size_t)a.L * a.L;
+    // kept cells in the blocks before this one
+    uint32_t part = 0;
+    for (int b = (int)threadIdx.x; b < (int)blockIdx.x; b += 1024) part += a.block_count[b];
+    uint32_t before;
+    block_exclusive_scan<1024>(part, scratch, &before);
+    if (threadIdx.x == 0) s_base = before;
+    size_t index = 0; int ix = 0, iy = 0;
+    const bool keep = lin < cells && show_keep(a, lin, index, ix, iy);
+    uint32_t in_block;
+    const uint32_t rank = block_exclusive_scan<1024>(keep ? 1u : 0u, scratch, &in_block);
+    __syncthreads();
+    const uint32_t n = s_base + rank;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *a.total = s_base + in_block;
+    if (lin >= cells) return;
+    const float nan = __builtin_nanf("");
+    float vals[9] = {nan, nan, nan, nan, nan, nan, nan, nan, nan};
+    if (keep) {
+        const float cr = (float)a.m.colorR[index], cg = (float)a.m.colorG[index], cb = (float)a.m.colorB[index];    // EM.cpp:103-111
+        vals[0] = a.m.elevation[index]; vals[1] = a.m.variance[index]; vals[2] = a.m.rough[index]; vals[3] = a.m.slope[index];
+        vals[4] = a.m.traver[index]; vals[5] = cr; vals[6] = cg; vals[7] = cb; vals[8] = a.m.intensity[index];
+        int ux = ix - a.sx, uy = iy - a.sy;                             // getIndexFromBufferIndex
+        ux += ux < 0 ? a.L : 0; uy += uy < 0 ? a.L : 0;
+        const unsigned char r8 = (unsigned char)(int)cr, g8 = (unsigned char)(int)cg, b8 = (unsigned char)(int)cb;
+        if (a.xyz) {
+            const double px = (a.px + a.off) + a.res * (double)(-ux);   // getPositionFromIndex (doubles)
+            const double py = (a.py + a.off) + a.res * (double)(-uy);
+            a.xyz[3 * (size_t)n + 0] = (float)px; a.xyz[3 * (size_t)n + 1] = (float)py; a.xyz[3 * (size_t)n + 2] = vals[0];   // EM.cpp:116-118
+        }
+        if (a.rgb) { a.rgb[3 * (size_t)n + 0] = r8; a.rgb[3 * (size_t)n + 1] = g8; a.rgb[3 * (size_t)n + 2] = b8; }
+        if (a.image) { unsigned char* p = a.image + ((size_t)ux * a.L + uy) * 3; p[0] = b8; p[1] = g8; p[2] = r8; }          // EM.cpp:124-126
+    }
+    if (a.visual) {
+#pragma unroll
+        for (int l = 0; l < 9; ++l) a.visual[(size_t)l * cells + lin] = vals[l];
+    }
+}
+
+hipError_t launch_show(hipStream_t st, const LayerPtrs& m, int L, int sx, int sy, double map_length, double resolution, double px, double py,
+                       uint32_t* block_count, float* visual, float* xyz, unsigned char* rgb, unsigned char* image, uint32_t* total)
+{
+    ShowArgs a{};
+    a.m = m; a.L = L; a.sx = sx; a.sy = sy; a.off = 0.5 * map_length - 0.5 * resolution; a.res = resolution; a.px = px; a.py = py;
+    a.block_count = block_count; a.visual = visual; a.xyz = xyz; a.rgb = rgb; a.image = image; a.total = total;
+    const int blocks = (int)(((size_t)L * L + 1023) / 1024);
+    hipLaunchKernelGGL(k_show_count, dim3(blocks), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(k_show_emit, dim3(blocks), dim3(1024), 0, st, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // k_map_feature : traversability stage that follows the fusion every frame (G_Mapfeature,
 // GPU:549-670, with the Jacobi eigen-solver computerEigenvalue, GPU:66-187).  One thread per cell, one workgroup per 16x16 cells:
 // plane fit over the valid cells of the 5x5 neighbourhood (bounds in unrolled coordinates, wrapped

@@ -176,6 +176,8 @@ hipError_t launch_dense_variance(hipStream_t st, float* variance, int cells, int
 hipError_t launch_update_height(hipStream_t st, float* elevation, int cells, float dz);
 hipError_t launch_map_feature(hipStream_t st, const float* elevation, float* traver, float* rough, float* slope,
                               int L, float res, int sx, int sy, int row0, int row1);
+hipError_t launch_show(hipStream_t st, const LayerPtrs& m, int L, int sx, int sy, double map_length, double resolution, double px, double py,
+                       uint32_t* block_count, float* visual, float* xyz, unsigned char* rgb, unsigned char* image, uint32_t* total);
 hipError_t launch_export_gridmap(hipStream_t st, const void* src, const float* elevation, float* dst, int L, int is_int);
 
 } // namespace gem

@@ -185,6 +185,21 @@ int  gem_layer_device_ptr(gem_handle* h, int layer, void** out_device_ptr);
 int  gem_map_feature(gem_handle* h, float* elevation, float* variance, int* colorR, int* colorG, int* colorB,
                      float* rough, float* slope, float* traver, float* intensity);
 
+/* ---- the feed of ElevationMap::show (EM.cpp:85-149, called EMg.cpp:413 right after Map_feature): the reference copies
+ *      nine L*L arrays to the host and loops over all cells there.  gem_show does that loop on the resident layers:
+ *        visual      9 x L*L floats, grid_map::Matrix layout (Eigen column-major by BUFFER index) of visualMap_'s layers in the order
+ *                    elevation, variance, rough, slope, traver, color_r, color_g, color_b, intensity (EM.cpp:44); NaN where the cell
+ *                    has no elevation or no traversability (EM.cpp:89, 101)
+ *        points_*    the coloured cloud of EM.cpp:113-122, one point per kept cell in grid_map's iteration order, compacted on the
+ *                    device: xyz n x 3 floats (x, y from grid_map's getPositionFromIndex in double, z = elevation), rgb n x 3 bytes;
+ *                    both arrays must hold L*L points; *out_count = n
+ *        image_bgr   the L x L x 3 orthomosaic of EM.cpp:87, 124-126 (unwrapped row, column; b, g, r)
+ *      map_length / resolution / position are visualMap_'s geometry (doubles, EMg.cpp:178; position = what Move returned,
+ *      EM.cpp:172-177); pass 0 / 0 / NULL to use length * resolution, the handle's resolution and centre.  Any output may be NULL.
+ *      Run gem_map_feature first: rough / slope / traver are its layers.                                                      */
+int  gem_show(gem_handle* h, double map_length, double resolution, const double position[2],
+              float* visual, float* points_xyz, unsigned char* points_rgb, int* out_count, unsigned char* image_bgr);
+
 /* ---- loop-closure re-anchoring: Map_optmove (GPU:1215-1233, called EMg.cpp:1020) relabels the
  *      map centre to opt_position snapped to the old centre's cell lattice (the circular buffer is not shifted,
  *      nothing is cleared) and adds height_update to every valid elevation (G_update_mapheight, GPU:1195-1202);

@@ -133,6 +133,10 @@ void   gemo_motion_init(gemo_motion_state* s, double covariance_scale);
 double gemo_motion_update(gemo_motion_state* s, const double pos[3], const double R_IB[9],
                           const double cov6x6[36], const double map_R[9]);
 
+/* EM.cpp:85-149 (ElevationMap::show): the cell loop behind the visualMap_ layers, the point cloud and the orthomosaic.  gem_oracle_show.c */
+int gemo_show(const gemo_map* m, const float* rough, const float* slope, double map_length, double resolution, const double map_position[2],
+              float* visual, float* points_xyz, unsigned char* points_rgb, unsigned char* image_bgr);
+
 /* GPU:1304-1318 (Raytracing): G_Raytracing (GPU:708-891) then G_Clear_maplowest (GPU:232-239).  gem_oracle_raytrace.c */
 void gemo_raytracing(gemo_map* m);
 void gemo_set_obstacle_threshold(gemo_map* m, float t);

@@ -40,7 +40,7 @@ class OMotion(C.Structure):
 
 def build(force: bool = False) -> Path:
     srcs = [HERE / "gem_oracle.c", HERE / "gem_oracle_motion.c", HERE / "gem_oracle_feature.c", HERE / "gem_oracle_raytrace.c",
-            HERE / "gem_oracle_mt.c", HERE / "gem_oracle.h"]
+            HERE / "gem_oracle_mt.c", HERE / "gem_oracle_show.c", HERE / "gem_oracle.h"]
     if force or not LIB.exists() or any(s.stat().st_mtime > LIB.stat().st_mtime for s in srcs):
         subprocess.run(["make", "-C", str(HERE), "-B" if force else "-s", "libgem_oracle.so"], check=True,
                        capture_output=True)
@@ -74,6 +74,8 @@ def lib() -> C.CDLL:
         l.gemo_add.argtypes = [POINTER(OMap), POINTER(OFrame), c_int, c_void_p, c_void_p, c_void_p, POINTER(c_longlong)]
         l.gemo_add_batch_mt.restype = c_longlong
         l.gemo_add_batch_mt.argtypes = [POINTER(OMap), c_int, POINTER(OFrame), c_void_p, POINTER(c_longlong), c_void_p, c_int]
+        l.gemo_show.restype = c_int
+        l.gemo_show.argtypes = [POINTER(OMap), c_void_p, c_void_p, c_double, c_double, POINTER(c_double), c_void_p, c_void_p, c_void_p, c_void_p]
         l.gemo_motion_init.argtypes = [POINTER(OMotion), c_double]
         l.gemo_motion_update.restype = c_double
         l.gemo_motion_update.argtypes = [POINTER(OMotion)] + [POINTER(c_double)] * 4
@@ -202,6 +204,21 @@ class OracleMap:
         out = {k: np.zeros(n, np.float32) for k in ("rough", "slope", "traver")}
         self._l.gemo_map_feature(self._m, _vp(out["rough"]), _vp(out["slope"]), _vp(out["traver"]))
         return {k: v.reshape(self.length, self.length) for k, v in out.items()}
+
+    def show(self, rough=None, slope=None, map_length=None, resolution=None, position=None):
+        """ElevationMap::show's cell loop (ElevationMap.cpp:85-149): dict(visual [9, L, L] column-major layers with NaN, points_xyz,
+        points_rgb, image_bgr).  rough / slope: the arrays Map_feature returned (default zeros)."""
+        L = self.length
+        res = float(np.float32(self.resolution)) if resolution is None else float(resolution)
+        length = L * res if map_length is None else float(map_length)
+        c = self.pose()[0] if position is None else position
+        pos = (c_double * 2)(float(c[0]), float(c[1]))
+        visual = np.empty((9, L * L), np.float32); xyz = np.empty((L * L, 3), np.float32); rgb = np.empty((L * L, 3), np.uint8)
+        img = np.empty((L, L, 3), np.uint8)
+        r = None if rough is None else np.ascontiguousarray(rough, np.float32)
+        s = None if slope is None else np.ascontiguousarray(slope, np.float32)
+        n = self._l.gemo_show(self._m, _vp(r), _vp(s), length, res, pos, _vp(visual), _vp(xyz), _vp(rgb), _vp(img))
+        return {"visual": visual.reshape(9, L, L), "points_xyz": xyz[:n].copy(), "points_rgb": rgb[:n].copy(), "image_bgr": img, "count": n}
 
     def layer(self, name: str) -> np.ndarray:
         m = self._m.contents

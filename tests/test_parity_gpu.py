@@ -263,8 +263,15 @@ def test_set_get_layers_and_gridmap_layout(oracle_mod):
     c = synth.random_cloud(8, 3000, 2.0)
     gpu.add(f, c); ref.add(f, c)
     e = gpu.layer("elevation")
-    gm = gpu.layer("elevation", layout=_lib.LAYOUT_GRIDMAP_COLMAJOR_NAN)
-    assert np.array_equal(np.isnan(gm), e == -10) and np.array_equal(gm[e != -10], e[e != -10])
+    # grid_map layout (EM.cpp:98-111: matrix(index_x, index_y) = flat[index_x * L + index_y], Eigen column-major, NaN for cells
+    # without elevation) against the ORACLE's layers, for a float and an int layer, and the raw column-major bytes
+    eo, vo = ref.layer("elevation"), ref.layer("variance")
+    for name, want in (("elevation", eo), ("variance", vo)):
+        gm = gpu.layer(name, layout=_lib.LAYOUT_GRIDMAP_COLMAJOR_NAN)          # viewed as [row, col]
+        assert np.array_equal(np.isnan(gm), eo == -10), name
+        assert np.array_equal(gm[eo != -10], want[eo != -10]), name
+        assert gm.base is not None and gm.base.flags["C_CONTIGUOUS"]           # the buffer itself is column-major: base[col, row]
+        assert np.array_equal(np.nan_to_num(gm.base, nan=-10.0)[3], np.where(eo == -10, F32(-10), want)[:, 3]), name
     new_e = np.where(e == -10, e, e + 1.0).astype(F32)
     gpu.set_layer("elevation", new_e); ref.set_layer("elevation", new_e)
     gpu.add(f, c); ref.add(f, c)

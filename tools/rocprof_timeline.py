@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel timeline of a rocprofv3 --kernel-trace run of tools/bench_configs.py: for every configuration (split at the long
-idle gaps between them), the LAST complete pass: kernel, stream / queue, start relative to the pass's first kernel, duration.
+idle gaps between them), two passes from the middle of its timed loop: kernel, stream / queue, start relative to the pass's first kernel, duration.
 Shows what overlaps with what when the product runs its two streams.
 
     tools/rocprof_timeline.py TRACE_DIR > profiles/rNN_xxx_timeline.txt
@@ -33,8 +33,10 @@ def main():
         walks = [i for i, r in enumerate(sec) if r[2].startswith("gem::k_fuse_walk") or r[2].startswith("gem::k_fuse_list") or r[2].startswith("gem::k_frame")]
         if len(walks) < 3:
             continue
-        # the last complete pass: from the first kernel after the third-last fuse kernel's start to the last fuse kernel's end
-        a, b = walks[-3] + 1, walks[-1]
+        # two passes from the MIDDLE of the section (the steady timed loop; the section ends with the instrumented passes):
+        # from the first kernel after a fuse kernel's start to the end of the second fuse kernel after it
+        mid = len(walks) // 2
+        a, b = walks[mid - 2] + 1, walks[mid]
         part = sec[a:b + 1]
         t0 = part[0][0]
         print(f"\n## section {si}: {len(sec)} dispatches; the last two passes (us relative to the first kernel shown)")
