@@ -51,6 +51,7 @@ SIGNATURES = {
     "gem_last_error": (c_char_p, [c_void_p]),
     "gem_set_stream": (c_int, [c_void_p, c_void_p]),
     "gem_synchronize": (c_int, [c_void_p]),
+    "gem_wait_event": (c_int, [c_void_p, c_void_p]),
     "gem_move": (c_int, [c_void_p, POINTER(c_float), POINTER(c_float), POINTER(c_int), POINTER(c_float)]),
     "gem_get_pose": (c_int, [c_void_p, POINTER(c_float), POINTER(c_int)]),
     "gem_process_points": (c_int, [c_void_p, POINTER(FrameParams), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

@@ -267,6 +267,12 @@ class ElevationMap:
     def synchronize(self) -> None:
         self._check(self._lib.gem_synchronize(self._h), "gem_synchronize")
 
+    def wait_event(self, hip_event) -> None:
+        """Everything enqueued from now on waits (on the device) for this event -- a hipEvent_t handle, or a torch.cuda.Event that
+        has been recorded on the stream producing the next call's device buffers (gem_wait_event)."""
+        h = getattr(hip_event, "cuda_event", hip_event)
+        self._check(self._lib.gem_wait_event(self._h, C.c_void_p(int(h))), "gem_wait_event")
+
     # -- Move (ElevationMapping::updateMapLocation -> Move, EMg.cpp:1032) ------------------------
     def move(self, position):
         pos = (C.c_float * 3)(*[float(v) for v in position])

@@ -828,6 +828,21 @@ int gem_set_stream(gem_handle* h, void* hip_stream)
     return GEM_OK;
 }
 
+// Stream-ordered inputs: everything this handle enqueues from now on -- on its own stream and on its binning stream -- waits
+// for `hip_event` (recorded by the caller on whatever stream produces the device buffers it is about to pass).
+int gem_wait_event(gem_handle* h, void* hip_event)
+{
+    if (!h || !hip_event) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    hipEvent_t ev = static_cast<hipEvent_t>(hip_event);
+    GEM_HIP(h, hipStreamWaitEvent(h->stream, ev, 0));
+    if (h->bin_stream) GEM_HIP(h, hipStreamWaitEvent(h->bin_stream, ev, 0));
+    // (a binning stream created later starts behind an event recorded on the handle's stream: see main_reads_pb)
+    h->main_reads_pb = true;
+    return GEM_OK;
+}
+
 int gem_synchronize(gem_handle* h)
 {
     if (!h) return GEM_ERR_INVALID;

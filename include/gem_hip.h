@@ -119,6 +119,10 @@ int  gem_abi_version(void);
 /* stream the handle enqueues on (a hipStream_t passed as void*); NULL = the handle's own stream */
 int  gem_set_stream(gem_handle* h, void* hip_stream);
 int  gem_synchronize(gem_handle* h);
+/* Stream-ordered device inputs: a caller whose cloud is produced on ANOTHER stream records a hipEvent_t there and hands it over
+ * before the *_device call; all work the handle enqueues afterwards (on either of its internal streams) waits for it on the
+ * device -- no host synchronisation.  Without it, device buffers must be complete when a *_device entry is called.          */
+int  gem_wait_event(gem_handle* h, void* hip_event);
 
 /* ---- Move (GPU:1004-1083, called EMg.cpp:1032) -------------------------------------------------- */
 int  gem_move(gem_handle* h, const float position[3], float out_center[2], int out_start[2],
@@ -141,9 +145,9 @@ int  gem_fuse(gem_handle* h, int n, const int* index, const int* R, const int* G
  *      Nothing returns to the host.  This is the ElevationMap::add-shaped entry.                  */
 int  gem_add(gem_handle* h, const gem_frame_params* p, int n, const float* xyzi,
              const uint32_t* rgb, const int* orig_index);
-/*      gem_add_device takes device pointers and only enqueues.  The buffers must be complete when the call is
- *      made and stay untouched until gem_synchronize (or any call that returns map data) -- they are not ordered
- *      against the handle's internal streams.  The order of operations the caller issues is the order the map sees;
+/*      gem_add_device takes device pointers and only enqueues.  The buffers must be complete when the call is made -- or
+ *      their producer's event must have been passed to gem_wait_event -- and stay untouched until gem_synchronize (or
+ *      any call that returns map data).  The order of operations the caller issues is the order the map sees;
  *      underneath, a stream of single colourless sweeps runs as ONE launch per frame (binning of the new cloud next
  *      to the fusion of the previous frame's records), the newest frame's fusion being launched by the next call
  *      that needs it.                                                                                          */

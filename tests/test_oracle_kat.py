@@ -333,3 +333,61 @@ def test_all_core_oracle_equals_the_sequential_one(oracle_mod):
     for k in range(3):
         seq.add(wl.frames[k], clouds[k])
     assert np.array_equal(mt.layer("variance"), seq.layer("variance")) and np.array_equal(mt.layer("elevation"), seq.layer("elevation"))
+
+
+# ---- the reference's CPU noise models (SL.cpp:121-153, Stereo.cpp:72-104, Perfect.cpp:74-102): closed forms ------------------
+# The reference never calls these on its GPU path and nothing in its tree pins their outputs; kindr / PCL / ROS are absent, so they
+# cannot be compiled here either.  What pins the oracle's restatement (and, in tests/test_parity_gpu.py, the kernel's) are these
+# hand-derived cases: with a level sensor (J_s = e_z, no rotation variance) the height variance IS the normal variance of the
+# model, with the sensor's x axis along map z it is the lateral one -- each a closed formula of the point, evaluated here in
+# plain Python from the reference's source lines.
+def model_frame(kind, params, Js=(0, 0, 1), width=0):
+    f = ident_frame(Js=list(Js))
+    f.model = SensorModel(kind, tuple(params), float("inf"), float("-inf"), original_width=width)
+    return f
+
+
+def test_structured_light_normal_and_lateral_variance(oracle_mod):
+    a, b, c, d, e, k = 0.000611, 0.003587, 0.3515, 0.0007, 2.0, 0.01576       # realsense_d435.yaml shape, d / e made non-trivial
+    m = oracle_mod.OracleMap(200, 0.1)
+    pts = [(0.4, -0.2, 0.8), (1.5, 0.7, 2.25), (0.1, 0.1, 0.3515)]
+    x, y, z = (np.array(v, F32) for v in zip(*pts))
+    out = m.process_points(model_frame(1, (a, b, c, d, e, k)), x, y, z)
+    for i, zi in enumerate(z):
+        zd = float(zi)                                                       # SL.cpp:128 measurementDistance = point.z (float)
+        dev_n = F32(a + b * (zd - c) * (zd - c) + d * zd ** e)               # SL.cpp:130-133: double expression, stored in a float
+        assert out["var"][i] == dev_n * dev_n, i                             # SL.cpp:134, :147 with J_s = (0, 0, 1)
+    out = m.process_points(model_frame(1, (a, b, c, d, e, k), Js=(1, 0, 0)), x, y, z)
+    for i, zi in enumerate(z):
+        dev_l = F32(k * float(zi))                                           # SL.cpp:135
+        assert out["var"][i] == dev_l * dev_l, i                             # SL.cpp:136, J_s = (1, 0, 0) picks varianceLateral
+
+
+def test_stereo_normal_and_lateral_variance(oracle_mod):
+    p1, p2, p3, p4, p5, lat, f = 0.1, 0.001, 380.0, 1.0, 0.002, 0.001, 30.0
+    W = 640
+    m = oracle_mod.OracleMap(200, 0.1)
+    pts = [(0.4, -0.2, 0.8), (1.5, 0.7, 2.25), (-0.3, 0.2, 5.0)]
+    orig = np.array([0, 17 * W + 5, 239 * W + 639], np.int32)               # pixel (I, J) = (index / width, index % width), Stereo.cpp:108-116
+    x, y, z = (np.array(v, F32) for v in zip(*pts))
+    out = m.process_points(model_frame(2, (p1, p2, p3, p4, p5, lat, f), width=W), x, y, z, orig_index=orig)
+    for i, zi in enumerate(z):
+        I, J = int(orig[i]) // W, int(orig[i]) % W
+        disp = f / float(zi)                                                 # Stereo.cpp:78
+        vn = (f / disp ** 2) ** 2 * ((p5 * disp + p2) * np.sqrt((p3 * disp + p4 - J) ** 2 + (240 - I) ** 2) + p1)   # :88-91
+        assert abs(out["var"][i] - F32(vn)) <= 2e-7 * abs(vn), i             # double pow / sqrt, then one float rounding
+    out = m.process_points(model_frame(2, (p1, p2, p3, p4, p5, lat, f), Js=(1, 0, 0), width=W), x, y, z, orig_index=orig)
+    for i in range(3):
+        dist = np.sqrt(x[i] * x[i] + (y[i] * y[i] + z[i] * z[i]))           # Stereo.cpp:85 pointVector.norm() (float)
+        vl = F32((lat * float(dist)) ** 2)                                   # :92 pow(lateral_factor * distance, 2)
+        assert abs(out["var"][i] - vl) <= 2e-7 * vl, i
+
+
+def test_perfect_sensor_has_only_the_rotation_term(oracle_mod):
+    m = oracle_mod.OracleMap(200, 0.1)
+    f = model_frame(3, ())
+    out = m.process_points(f, [1.0], [2.0], [0.5])
+    assert out["var"][0] == 0.0                                              # Perfect.cpp:86-88: zero sensor variance
+    f.rotation_variance = np.diag([1e-4, 2e-4, 3e-4]).astype(F32)
+    out = m.process_points(f, [1.0], [2.0], [0.5])
+    assert abs(out["var"][0] - (4.0 * 1e-4 + 1.0 * 2e-4)) < 1e-9            # Jq = e_z^T skew(p) = (-y, x, 0)
