@@ -78,7 +78,7 @@ struct gem_handle {
     bool overlap = true;
     long long overlap_min_points = 1000000;
     bool sort_path = true;              // passes of at least sort_min_points points run the sorted pipeline (gem_sort.hip)
-    long long sort_min_points = 200000;
+    long long sort_min_points = 200000, sort_min_points_batch = 1000000;     // single cloud / batch of sweeps
     bool walk_permute = true;           // k_fuse_walk: blocks mapped to cell groups through a stride permutation
     int  sort_passes = 0;               // 0 = by map size (two digits up to 2^20 cells, else three); 2 / 3 force it
     bool bin_priority = false;          // create the second stream with high priority (measured: no effect on C4 / C5)
@@ -488,7 +488,10 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     // Big passes (batches of sweeps, aggregated clouds, depth images) go through the sorted pipeline: a global two-digit counting
     // sort of the in-map points by (tile, cell), then one walk per cell (gem_sort.hip).  Small ones -- a single LiDAR sweep -- keep
     // the tile pipeline below, whose one or two launches cost less than the sort's seven.
-    if (h->sort_path && in0.n >= h->sort_min_points && in0.n < (1ll << 31)) {
+    // Measured crossover (tools/dbg/crossover.py): batches of LiDAR sweeps -- a few points per cell and sweep -- are faster on the tile
+    // pipeline up to about 8 sweeps (1 M points); a single dense cloud (a depth image: hundreds of points per cell) from ~150 k points.
+    const long long sort_from = in0.n_sweeps > 1 ? h->sort_min_points_batch : h->sort_min_points;
+    if (h->sort_path && in0.n >= sort_from && in0.n < (1ll << 31)) {
         int attr = 0;
         if (in0.src == 0 && in0.rgb) attr = 1;
         if (in0.src == 1 && in0.f_R && in0.f_G && in0.f_B && in0.f_I) attr = 2;
@@ -1323,7 +1326,7 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "overlap")            h->overlap = value != 0;
     else if (k == "overlap_min_points") h->overlap_min_points = value;
     else if (k == "sort_path")          h->sort_path = value != 0;
-    else if (k == "sort_min_points")    h->sort_min_points = value;
+    else if (k == "sort_min_points")    { h->sort_min_points = value; h->sort_min_points_batch = value; }
     else if (k == "walk_permute")       h->walk_permute = value != 0;
     else if (k == "bin_priority")       h->bin_priority = value != 0;
     else if (k == "sort_passes")        { if (value != 0 && value != 2 && value != 3) return fail(h, GEM_ERR_INVALID, "sort_passes: 0, 2 or 3"); h->sort_passes = (int)value; }

@@ -465,6 +465,7 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
 
     // ---- the single read of the tile ---------------------------------------------------------------
     float ce[CPT], cs[CPT], lw[CPT];
+    float ce0[CPT], cs0[CPT];                                            // as loaded: only cells that changed are written back
     size_t lgeo[CPT];
     bool  owned[CPT];
 #pragma unroll
@@ -478,6 +479,7 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
         const size_t g = owned[q] ? (size_t)row * L + col : 0;
         if constexpr (MODE == 2) { ce[q] = st.e[q]; cs[q] = st.s[q]; }
         else { ce[q] = a.elevation[g]; cs[q] = a.variance[g]; }
+        ce0[q] = ce[q]; cs0[q] = cs[q];
         if constexpr (LOWEST) {
             // map_lowest is indexed by the GEOGRAPHIC cell (GPU:430 PointsToIndex), not by the circular-buffer cell
             int gr = row - a.start0, gc = col - a.start1;
@@ -968,8 +970,10 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
         if (owned[q]) {
             const int c = tid + NT * q;
             const size_t g = (size_t)(row_base + (c >> TS)) * L + col_base + (c & (TE - 1));
-            a.elevation[g] = ce[q];
-            a.variance[g] = cs[q];
+            // A sweep touches a fraction of a tile's cells: writing the tile back whole was 1.8 MB of the 4.3 MB a C2 frame wrote
+            // (profiles/r01f_c2_bench.txt).  (A tile resumed by the dense copy of the loop has lost its loaded values: written whole.)
+            if (MODE == 2 || __float_as_uint(ce[q]) != __float_as_uint(ce0[q])) a.elevation[g] = ce[q];
+            if (MODE == 2 || __float_as_uint(cs[q]) != __float_as_uint(cs0[q])) a.variance[g] = cs[q];
             if constexpr (LOWEST) a.lowest[lgeo[q]] = lw[q];
         }
     }
