@@ -332,8 +332,26 @@ def run_c5_distributed(args, torch, dist, world, rank, local_rank, dev):
     return out
 
 
+_REAL_STDOUT = None
+
+
+def emit(obj) -> None:
+    """The ONE JSON line, on the process's real stdout."""
+    line = (json.dumps(obj) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, line)
+
+
 def main():
     args = parse()
+    # Libraries underneath write to stdout on their own (RCCL prints a version banner at communicator creation, the compiled
+    # reference printf's from its Init): everything but the JSON line goes to stderr.
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from gem_amd import ElevationMap, synth
@@ -352,7 +370,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         out = run_c5_distributed(args, torch, dist, world, rank, local_rank, dev)
         if rank == 0:
-            print(json.dumps(out))
+            emit(out)
             if not out["parity_checked"]:
                 dist.destroy_process_group()
                 raise SystemExit("parity check FAILED: the tiled map differs from the committed digest")
@@ -461,7 +479,7 @@ def main():
         out["cpu_reference_literal"] = lit
         if allc.get("replay_matches_timed_map") is False:
             failed = True
-    print(json.dumps(out))
+    emit(out)
     if failed:
         raise SystemExit("parity check FAILED: see parity_checked / cpu_baseline.replay_matches_timed_map in the line above")
 
