@@ -252,6 +252,29 @@ public:
         return v;
     }
     void synchronize() { check(gem_synchronize(h_), "gem_synchronize"); }
+    // device inputs produced on another stream: everything enqueued from now on waits for this hipEvent_t (gem_wait_event)
+    void waitEvent(void* hipEvent) { check(gem_wait_event(h_, hipEvent), "gem_wait_event"); }
+
+    // ElevationMap::show's cell loop (ElevationMap.cpp:85-149) on the resident layers: visualMap_'s nine layers
+    // (visualMapLayers() order, grid_map::Matrix memory, NaN for cells without elevation / traversability), the coloured
+    // point cloud in grid_map's iteration order and the orthomosaic.  Geometry = visualMap_'s (doubles, ElevationMapping.cpp:178);
+    // 0 / 0 / nullptr: length * resolution, the map's resolution and centre.
+    struct Shown {
+        std::vector<float> visual;            // 9 x length^2
+        std::vector<float> pointsXYZ;         // n x 3
+        std::vector<unsigned char> pointsRGB; // n x 3
+        std::vector<unsigned char> imageBGR;  // length x length x 3
+        int count = 0;
+    };
+    Shown show(double mapLength = 0.0, double resolution = 0.0, const double position[2] = nullptr) const
+    {
+        const size_t cells = static_cast<size_t>(length_) * length_;
+        Shown s;
+        s.visual.resize(9 * cells); s.pointsXYZ.resize(3 * cells); s.pointsRGB.resize(3 * cells); s.imageBGR.resize(3 * cells);
+        check(gem_show(h_, mapLength, resolution, position, s.visual.data(), s.pointsXYZ.data(), s.pointsRGB.data(), &s.count, s.imageBGR.data()), "gem_show");
+        s.pointsXYZ.resize(3 * static_cast<size_t>(s.count)); s.pointsRGB.resize(3 * static_cast<size_t>(s.count));
+        return s;
+    }
 
     void check(int rc, const char* what) const { if (rc != GEM_OK) throw Error(rc, std::string(what) + ": " + gem_last_error(h_)); }
 

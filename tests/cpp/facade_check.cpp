@@ -98,6 +98,28 @@ int main(int argc, char** argv)
         CHECK(m2.layer(GEM_LAYER_VARIANCE) == v2);
         const std::vector<float> gm = m2.gridMapLayer(GEM_LAYER_ELEVATION);
         CHECK(std::isnan(gm[0]));
+        // ElevationMap::show's feed: an isolated cell has no traversability (fewer than 8 neighbours), so nothing is kept ...
+        m2.mapFeature();
+        gem::ElevationMap::Shown sh = m2.show();
+        CHECK(sh.count == 0 && std::isnan(sh.visual[0]) && sh.pointsXYZ.empty());
+        // ... give every cell one and the fused cells appear, in grid_map's iteration order, with grid_map's positions
+        std::vector<float> trav(static_cast<size_t>(L) * L, 0.5f);
+        CHECK(gem_set_layer(m2.handle(), GEM_LAYER_TRAVER, trav.data()) == GEM_OK);
+        sh = m2.show();
+        int touched = 0;
+        for (float ev : e2) touched += ev != -10.f;
+        CHECK(sh.count == touched && touched > 0);
+        CHECK(static_cast<int>(sh.pointsXYZ.size()) == 3 * touched);
+        // the point of storage cell (ix, iy) sits at centre + (L res / 2 - res / 2) - res * index (start index 0, centre 0)
+        const int c0 = idx[3], ix = c0 / L, iy = c0 % L;
+        bool found = false;
+        for (int k = 0; k < sh.count; ++k) {
+            const float px = sh.pointsXYZ[3 * k], py = sh.pointsXYZ[3 * k + 1], pz = sh.pointsXYZ[3 * k + 2];
+            const double wx = (0.0 + (0.5 * (L * (double)0.1f) - 0.5 * (double)0.1f)) + (double)0.1f * (double)(-ix);
+            const double wy = (0.0 + (0.5 * (L * (double)0.1f) - 0.5 * (double)0.1f)) + (double)0.1f * (double)(-iy);
+            if (px == (float)wx && py == (float)wy) { found = true; CHECK(pz == e2[c0]); }
+        }
+        CHECK(found);
     }
     std::printf(fails ? "FAILED (%d)\n" : "OK\n", fails);
     return fails;
