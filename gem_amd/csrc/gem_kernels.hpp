@@ -134,7 +134,8 @@ struct PassArgs {
 struct WalkArgs {
     const uint2* hv; const uint32_t* key; const uint32_t* src; const uint32_t* bin_base;
     int   T, tiles_per_row, L, row0, row1, id_bits, bin_shift, n_sweeps;
-    int   walk_stride;                 // block -> cell-group permutation: a prime that does not divide 16 T
+    int   walk_order;                  // 1: blocks take the tile rows centre-first (center_tr = the tile row holding the map centre)
+    int   center_tr;
     float mahal, var_floor;
     int   dense;                       // 1: visit every cell (pending variance increments / floor not yet established)
     int   n_pending; float pending[kMaxPending];
