@@ -164,12 +164,13 @@ def pmc_traffic(kernel_prefix: str):
     best = None
     for f in sorted((ROOT / "profiles").glob("r*_c2_bench.json")):
         try:
-            c = json.loads(f.read_text()).get("counters", {})
+            doc = json.loads(f.read_text())
         except Exception:
             continue
-        for k, v in c.items():
+        for k, v in doc.get("counters", {}).items():
             if k.split("<")[0].split("(")[0].endswith(kernel_prefix) and "hbm_bytes_high" in v:
-                best = (f.name, v)
+                us = doc.get("kernels", {}).get(k, {}).get("avg_us")        # the kernel's duration in the profiled run
+                best = (f.name, v, us)
     return best
 
 
@@ -442,6 +443,11 @@ def main():
         traffic = pm[1]["hbm_bytes_high"]
         traffic_note = (f"profiles/{pm[0]} (rocprofv3 --pmc passes of this command, tools/profile_c2.sh): FETCH_SIZE {pm[1]['FETCH_SIZE']:.0f} KB "
                         f"(doubled per the guide) + WRITE_SIZE {pm[1]['WRITE_SIZE']:.0f} KB per launch; uncorrected {pm[1]['hbm_bytes_low']:.0f} B")
+        if pm[2]:
+            # the counters were collected on a committed build: if the kernel has changed since, its duration gives it away
+            stale = abs(pm[2] - dom_us) > 0.25 * dom_us
+            traffic_note += (f"; kernel duration in that run {pm[2]:.2f} us vs {dom_us:.2f} us now" +
+                             (" -- MORE THAN 25 % APART: the counters may describe an older kernel, re-run tools/profile_c2.sh" if stale else ""))
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                 "us_per_launch": {"k_frame": us_frame, "k_bin_wave": us_bin, "k_fuse_list": us_fuse},
