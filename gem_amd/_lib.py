@@ -36,6 +36,10 @@ class FrameParams(C.Structure):
                 ("B_r_BS_skew", c_float * 9), ("filter", RejectFilter), ("original_width", c_int)]
 
 
+class Camera(C.Structure):
+    _fields_ = [("lidar_to_image", c_double * 12), ("width", c_int), ("height", c_int)]
+
+
 class Stats(C.Structure):
     _fields_ = [("points_in", c_longlong), ("points_binned", c_longlong), ("cells_touched", c_longlong),
                 ("ms_bin", c_float), ("ms_fuse", c_float), ("launches_bin", c_int), ("launches_fuse", c_int),
@@ -76,6 +80,8 @@ SIGNATURES = {
     "gem_comm_unique_id": (c_int, [c_void_p]),
     "gem_comm_init": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "gem_allgather_layers": (c_int, [c_void_p, c_int]),
+    "gem_colorize": (c_int, [c_void_p, POINTER(Camera), c_int, c_void_p, c_void_p, C.c_size_t, c_void_p]),
+    "gem_colorize_device": (c_int, [c_void_p, POINTER(Camera), c_int, c_void_p, c_void_p, C.c_size_t, c_void_p]),
     "gem_show": (c_int, [c_void_p, c_double, c_double, POINTER(c_double), c_void_p, c_void_p, c_void_p, POINTER(c_int), c_void_p]),
     "gem_comm_init_tiles": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "gem_get_strip": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),

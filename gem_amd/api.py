@@ -405,6 +405,49 @@ class ElevationMap:
         k = int(n.value)
         return {"visual": visual.reshape(9, L, L), "points_xyz": xyz[:k].copy(), "points_rgb": rgb[:k].copy(), "image_bgr": img, "count": k}
 
+    # -- the step in front of the path: input colourisation (EMg.cpp:349-381) -------------------------------
+    @staticmethod
+    def lidar_to_image(tcamera, tlidar) -> np.ndarray:
+        """P_lidar2img = T.camera (3x4) * T.lidar (4x4) in double, sums over k = 0..3 in order (EMg.cpp:343)."""
+        a = np.asarray(tcamera, np.float64).reshape(3, 4); b = np.asarray(tlidar, np.float64).reshape(4, 4)
+        out = np.empty((3, 4), np.float64)
+        for r in range(3):
+            for c in range(4):
+                acc = a[r, 0] * b[0, c]
+                for k in range(1, 4):
+                    acc = acc + a[r, k] * b[k, c]
+                out[r, c] = acc
+        return out
+
+    def colorize(self, lidar_to_image, image_bgr, xyzi):
+        """Colours of a cloud from a BGR8 camera image, with the reference's draw-while-sampling order dependence (gem_colorize).
+        Host arrays: returns (rgb uint32 [n] 0x00RRGGBB, xyzi copy with intensity zeroed outside the image).  Device tensors
+        (image uint8 [H, W, 3], xyzi float32 [n, 4], both on the handle's device): xyzi is updated IN PLACE and the returned rgb is
+        an int32 tensor holding the same words; only enqueues."""
+        cam = _lib.Camera()
+        P = np.asarray(lidar_to_image, np.float64).reshape(12)
+        for k in range(12):
+            cam.lidar_to_image[k] = float(P[k])
+        if hasattr(image_bgr, "is_cuda"):
+            import torch
+            if not (image_bgr.is_cuda and xyzi.is_cuda and image_bgr.dtype == torch.uint8 and xyzi.dtype == torch.float32):
+                raise ValueError("colorize: device tensors must be uint8 [H, W, 3] and float32 [n, 4]")
+            if not (xyzi.is_contiguous() and image_bgr.stride(2) == 1 and image_bgr.stride(1) == 3):
+                raise ValueError("colorize: xyzi must be contiguous, image rows packed BGR")
+            cam.height, cam.width = int(image_bgr.shape[0]), int(image_bgr.shape[1])
+            rgb = torch.empty(xyzi.shape[0], dtype=torch.int32, device=xyzi.device)
+            self._check(self._lib.gem_colorize_device(self._h, C.byref(cam), int(xyzi.shape[0]), C.c_void_p(xyzi.data_ptr()),
+                                                      C.c_void_p(image_bgr.data_ptr()), int(image_bgr.stride(0)), C.c_void_p(rgb.data_ptr())),
+                        "gem_colorize_device")
+            return rgb, xyzi
+        img = np.ascontiguousarray(image_bgr, np.uint8)
+        pts = np.ascontiguousarray(xyzi, np.float32).copy()
+        cam.height, cam.width = int(img.shape[0]), int(img.shape[1])
+        rgb = np.zeros(pts.shape[0], np.uint32)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._check(self._lib.gem_colorize(self._h, C.byref(cam), int(pts.shape[0]), vp(pts), vp(img), int(img.strides[0]), vp(rgb)), "gem_colorize")
+        return rgb, pts
+
     # -- layers ----------------------------------------------------------------------------------------
     def layer(self, name_or_id, layout: int = _lib.LAYOUT_STORAGE_ROWMAJOR) -> np.ndarray:
         lid = LAYER_BY_NAME[name_or_id] if isinstance(name_or_id, str) else int(name_or_id)

@@ -113,6 +113,7 @@ struct gem_handle {
     void* sh_host = nullptr;            // pinned staging of the small tables (kShardHostBytes)
 
     Arena dbg;          // optional k_fuse phase stamps
+    Arena color;        // gem_colorize: its own sort arrays and tables (never shared with a pass in flight on the binning stream)
     bool  dbg_on = false;
     int fuse_variant = 12;
 };
@@ -802,7 +803,7 @@ void gem_destroy(gem_handle* h)
     for (auto& ep : h->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
     if (h->layers.elevation) hipFree(h->layers.elevation);      // base of the single layer allocation
     if (h->d_counters) hipFree(h->d_counters);
-    for (Arena* a : {&h->stage, &h->scratch, &h->dbg, &h->sh_dev, &h->sh_recv_hv, &h->sh_recv_key}) if (a->p) hipFree(a->p);
+    for (Arena* a : {&h->stage, &h->scratch, &h->dbg, &h->color, &h->sh_dev, &h->sh_recv_hv, &h->sh_recv_key}) if (a->p) hipFree(a->p);
     if (h->sh_host) hipHostFree(h->sh_host);
     for (auto& b : h->pb) {
         for (Arena* a : {&b.rec, &b.srt, &b.seg, &b.flag, &b.gflag, &b.tables, &b.s_hv1, &b.s_hv2, &b.s_key1, &b.s_key2, &b.s_src1, &b.s_src2,
@@ -1243,6 +1244,98 @@ int gem_show(gem_handle* h, double map_length, double resolution, const double p
         GEM_HIP(h, hipStreamSynchronize(h->stream));
     }
     if (out_count) *out_count = (int)n;
+    return GEM_OK;
+}
+
+// ---- input colourisation (EMg.cpp:349-381): device-resident cloud and image -> 0x00RRGGBB per point, intensity zeroed outside
+static int colorize_device(gem_handle* h, const gem_camera* cam, int n, float* d_xyzi, const unsigned char* d_image, size_t stride, uint32_t* d_rgb)
+{
+    if (!cam || n < 0 || (n > 0 && (!d_xyzi || !d_image || !d_rgb))) return fail(h, GEM_ERR_INVALID, "gem_colorize: null argument");
+    if (cam->width <= 0 || cam->height <= 0 || (long long)cam->width * cam->height > (1ll << 26))
+        return fail(h, GEM_ERR_INVALID, "gem_colorize: image size out of range");
+    if (stride == 0) stride = (size_t)cam->width * 3;
+    if (stride < (size_t)cam->width * 3) return fail(h, GEM_ERR_INVALID, "gem_colorize: row stride below width * 3");
+    if (n == 0) return GEM_OK;
+    const long long pixels = (long long)cam->width * cam->height;
+    // the key is the pixel: digits of about equal width, at most ten bits (see sort_geometry)
+    SortArgs sa{};
+    sa.id_bits = std::max(2, ceil_log2((int)std::min<long long>(pixels, 1ll << 30)));
+    sa.n_passes = sa.id_bits <= 10 ? 1 : (sa.id_bits <= 20 ? 2 : 3);
+    int shift = 0, bins_hi = 1;
+    for (int i = 0; i < sa.n_passes; ++i) {
+        const int left = sa.n_passes - i;
+        const int bits = i == sa.n_passes - 1 ? sa.id_bits - shift : (sa.id_bits - shift + left - 1) / left;
+        sa.dshift[i] = shift; sa.dbits[i] = bits;
+        sa.dbins[i] = i == sa.n_passes - 1 ? (int)((pixels - 1) >> shift) + 1 : 1 << bits;
+        if (i > 0) bins_hi = std::max(bins_hi, sa.dbins[i]);
+        shift += bits;
+    }
+    const size_t N = (size_t)n, NC = (N + 4095) / 4096;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~(size_t)255; return at; };
+    const size_t o_hv1 = take(N * 8 + 64), o_hv2 = take(N * 8 + 64), o_key1 = take(N * 4 + 64), o_key2 = take(N * 4 + 64);
+    const size_t o_cnt1 = take(NC * sa.dbins[0] * 4), o_cnt2 = take(NC * bins_hi * 4 + 16);
+    size_t o_seg[3] = {0, 0, 0};
+    for (int i = 0; i < sa.n_passes; ++i) o_seg[i] = take((size_t)sa.dbins[i] * 16);
+    const size_t o_total = take(16), o_base = take(((size_t)sa.dbins[sa.n_passes - 1] + 1) * 4);
+    const size_t o_first = take((size_t)pixels * 4), o_pix = take(N * 4), o_link = take(N * 4);
+    int rc;
+    if ((rc = ensure(h, h->color, o))) return rc;
+    unsigned char* d = static_cast<unsigned char*>(h->color.p);
+    sa.n_sweeps = 1; sa.n = n; sa.xyzi = reinterpret_cast<const float4*>(d_xyzi);
+    for (int k = 0; k < 12; ++k) sa.cam.P[k] = cam->lidar_to_image[k];
+    sa.cam.width = cam->width; sa.cam.height = cam->height;
+    sa.tiles_per_row = 1; sa.T = 1; sa.n_chunks1 = (int)NC;
+    for (int i = 0; i < sa.n_passes; ++i) {
+        sa.cnt[i] = reinterpret_cast<uint32_t*>(d + (i == 0 ? o_cnt1 : o_cnt2));
+        sa.segtot[i] = reinterpret_cast<uint32_t*>(d + o_seg[i]);
+    }
+    sa.total = reinterpret_cast<uint32_t*>(d + o_total); sa.bin_base = reinterpret_cast<uint32_t*>(d + o_base);
+    sa.hv_a = reinterpret_cast<uint2*>(d + o_hv2); sa.hv_b = reinterpret_cast<uint2*>(d + o_hv1);
+    sa.key_a = reinterpret_cast<uint32_t*>(d + o_key2); sa.key_b = reinterpret_cast<uint32_t*>(d + o_key1);
+    const LaunchEvents ev[9] = {};
+    GEM_HIP(h, hipMemsetAsync(d + o_first, 0xff, (size_t)pixels * 4, h->stream));
+    GEM_HIP(h, hipMemsetAsync(d + o_pix, 0xff, N * 4, h->stream));
+    GEM_HIP(h, launch_sort(h->stream, sa, 3, false, ev));
+    const bool final_b = (sa.n_passes & 1) != 0;
+    ColorArgs ca{};
+    ca.key = final_b ? sa.key_b : sa.key_a; ca.hv = final_b ? sa.hv_b : sa.hv_a; ca.total = sa.total;
+    ca.first = reinterpret_cast<uint32_t*>(d + o_first); ca.pix = reinterpret_cast<uint32_t*>(d + o_pix); ca.link = reinterpret_cast<uint32_t*>(d + o_link);
+    ca.n = n; ca.width = cam->width; ca.height = cam->height; ca.image = d_image; ca.stride = stride;
+    ca.xyzi = reinterpret_cast<float4*>(d_xyzi); ca.rgb = d_rgb;
+    GEM_HIP(h, launch_colorize(h->stream, ca));
+    return GEM_OK;
+}
+
+int gem_colorize_device(gem_handle* h, const gem_camera* cam, int n, float* d_xyzi, const unsigned char* d_image_bgr, size_t row_stride,
+                        uint32_t* d_rgb)
+{
+    if (!h) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    return colorize_device(h, cam, n, d_xyzi, d_image_bgr, row_stride, d_rgb);
+}
+
+int gem_colorize(gem_handle* h, const gem_camera* cam, int n, float* xyzi, const unsigned char* image_bgr, size_t row_stride, uint32_t* rgb)
+{
+    if (!h) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    if (!cam || n < 0 || (n > 0 && (!xyzi || !image_bgr || !rgb))) return fail(h, GEM_ERR_INVALID, "gem_colorize: null argument");
+    if (cam->width <= 0 || cam->height <= 0) return fail(h, GEM_ERR_INVALID, "gem_colorize: image size out of range");
+    if (n == 0) return GEM_OK;
+    if (row_stride == 0) row_stride = (size_t)cam->width * 3;
+    { const int rcd = flush_deferred(h); if (rcd) return rcd; }       // the staging arena may hold a deferred frame's cloud
+    const size_t N = (size_t)n, b_xyzi = (N * 16 + 255) & ~(size_t)255, b_rgb = (N * 4 + 255) & ~(size_t)255, b_img = row_stride * cam->height;
+    int rc;
+    if ((rc = ensure(h, h->stage, b_xyzi + b_rgb + b_img))) return rc;
+    unsigned char* d = static_cast<unsigned char*>(h->stage.p);
+    GEM_HIP(h, hipMemcpyAsync(d, xyzi, N * 16, hipMemcpyHostToDevice, h->stream));
+    GEM_HIP(h, hipMemcpyAsync(d + b_xyzi + b_rgb, image_bgr, b_img, hipMemcpyHostToDevice, h->stream));
+    if ((rc = colorize_device(h, cam, n, reinterpret_cast<float*>(d), d + b_xyzi + b_rgb, row_stride, reinterpret_cast<uint32_t*>(d + b_xyzi)))) return rc;
+    GEM_HIP(h, hipMemcpyAsync(xyzi, d, N * 16, hipMemcpyDeviceToHost, h->stream));
+    GEM_HIP(h, hipMemcpyAsync(rgb, d + b_xyzi, N * 4, hipMemcpyDeviceToHost, h->stream));
+    GEM_HIP(h, hipStreamSynchronize(h->stream));
     return GEM_OK;
 }
 

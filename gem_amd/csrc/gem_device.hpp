@@ -42,6 +42,30 @@ struct FrameConst {
     int    row0, row1;
 };
 
+// Lidar -> image projection of the input colourisation (EMg.cpp:321-345: P_lidar2img = T.camera (3x4) * T.lidar (4x4), in
+// double), by value like FrameConst.
+struct CameraConst {
+    double P[12];            // row-major 3 x 4
+    int    width, height;    // of the BGR image
+};
+
+// EMg.cpp:350-367: P_img = P_lidar2img * (x, y, z, 1) in double; P_x, P_y are FLOATS; cv::Point's members are ints, so the
+// assignment truncates; the pixel is sampled when 0 < x < width, 0 < y < height and P_img.z > 0.  Returns y * width + x, or -1.
+// The sums run k = 0..3 (Eigen's gemv order depends on its version and on alignment; a different order moves P_img by an ulp of
+// a double, which reaches the truncated pixel only on a double-rounding tie).  A float outside the int range (or NaN: z = 0)
+// converts to INT_MIN on x86 (cvttss2si) and fails the "> 0" test: outside.
+__host__ __device__ inline int camera_pixel(const CameraConst& c, float x, float y, float z)
+{
+    const double v0 = (double)x, v1 = (double)y, v2 = (double)z;
+    double r[3];
+    for (int k = 0; k < 3; ++k) r[k] = ((c.P[4 * k] * v0 + c.P[4 * k + 1] * v1) + c.P[4 * k + 2] * v2) + c.P[4 * k + 3];
+    const float px = (float)(r[0] / r[2]), py = (float)(r[1] / r[2]);
+    if (!(px > -2147483648.0f && px < 2147483648.0f && py > -2147483648.0f && py < 2147483648.0f)) return -1;
+    const int ix = (int)px, iy = (int)py;
+    if (ix > 0 && ix < c.width && iy > 0 && iy < c.height && r[2] > 0.0) return iy * c.width + ix;
+    return -1;
+}
+
 struct Projected {
     float h, var, xt, yt;
     int   row, col;          // storage row / column, -1 if outside the map (or the point was rejected)

@@ -105,6 +105,7 @@ struct SortArgs {
     const int* f_index; const float* f_height; const float* f_var;                    // SRC 1: Fuse()'s arrays (GPU:1154)
     const int* f_R; const int* f_G; const int* f_B; const float* f_I;
     int keep_sentinel;                 // keep records with h == -1 (GPU:482) for the LOWEST walk
+    CameraConst cam;                   // SRC 3 (input colourisation): id = the pixel a point samples, record = {point index, 0}
     int tiles_per_row, T;              // 32x32-cell tiles
     int id_bits;
     int n_passes;                      // counting-sort passes over the id: two digits, three for maps with more than 2^20 cells
@@ -179,6 +180,18 @@ hipError_t launch_map_feature(hipStream_t st, const float* elevation, float* tra
                               int L, float res, int sx, int sy, int row0, int row1);
 hipError_t launch_show(hipStream_t st, const LayerPtrs& m, int L, int sx, int sy, double map_length, double resolution, double px, double py,
                        uint32_t* block_count, float* visual, float* xyz, unsigned char* rgb, unsigned char* image, uint32_t* total);
+
+// input colourisation (EMg.cpp:349-381) on the records sorted by pixel
+struct ColorArgs {
+    const uint32_t* key; const uint2* hv; const uint32_t* total;       // records sorted by pixel (stable: ascending point index inside a pixel)
+    uint32_t* first;                   // [width * height] first record of every pixel, ~0 = none   (pre-set to ~0)
+    uint32_t* pix;                     // [n] the pixel of every point, ~0 = not in the image          (pre-set to ~0)
+    uint32_t* link;                    // [n] the earlier point whose circle this point samples, itself = the image
+    int n, width, height;
+    const unsigned char* image; size_t stride;     // BGR8 rows
+    float4* xyzi; uint32_t* rgb;       // intensity zeroed / 0x00RRGGBB written
+};
+hipError_t launch_colorize(hipStream_t st, const ColorArgs& a);
 hipError_t launch_export_gridmap(hipStream_t st, const void* src, const float* elevation, float* dst, int L, int is_int);
 
 } // namespace gem

@@ -48,11 +48,17 @@ constexpr uint32_t kKeyInvalid = 0xffffffffu;   // key of a rejected / outside p
 // ------------------------------------------------------------------------------------------
 struct Binned { bool valid; uint32_t id; float h, v; bool colour_ok; };
 
-// SRC: 0 = XYZI cloud, sensor model taken from the frame; 2 = XYZI cloud, every frame uses the laser model; 1 = Fuse()'s arrays
+// SRC: 0 = XYZI cloud, sensor model taken from the frame; 2 = XYZI cloud, every frame uses the laser model; 1 = Fuse()'s arrays;
+//      3 = XYZI cloud binned by camera pixel (the input colourisation, k_color_* below)
 template <int SRC>
 __device__ __forceinline__ Binned bin_one(const SortArgs& a, const FrameConst& fc, const float4& p, long long i, int orig_fallback)
 {
     Binned b; b.valid = false; b.id = 0; b.h = 0.0f; b.v = 0.0f; b.colour_ok = false;
+    if constexpr (SRC == 3) {                                          // input colourisation: bin by the sampled pixel
+        const int pixel = camera_pixel(a.cam, p.x, p.y, p.z);
+        b.valid = pixel >= 0; b.id = (uint32_t)pixel; b.h = __uint_as_float((uint32_t)i);
+        return b;
+    }
     int row, col; float h, v; bool colour_ok = false;
     if (SRC != 1) {
         const Projected r = SRC == 2 ? project_point<0>(fc, p.x, p.y, p.z, 0)
@@ -669,6 +675,7 @@ static hipError_t launch_project(hipStream_t st, const SortArgs& a, int src, Lau
     const size_t lds = (size_t)a.dbins[0] * 4;
     if (src == 0)      GEM_LAUNCH((k_sort_project<0>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
     else if (src == 2) GEM_LAUNCH((k_sort_project<2>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
+    else if (src == 3) GEM_LAUNCH((k_sort_project<3>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
     else               GEM_LAUNCH((k_sort_project<1>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
     return hipGetLastError();
 }
@@ -765,6 +772,94 @@ hipError_t launch_walk(hipStream_t st, const WalkArgs& a, int flags, LaunchEvent
     case 6: return launch_walk_f<6>(st, a, mode, ev);
     default: return hipErrorInvalidValue;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Input colourisation (EMg.cpp:349-381), the step in front of the path.  The reference loops over the points ON THE HOST: point
+// i samples the BGR image at its pixel and then draws cv::circle(img, pixel, 1, sampled colour) INTO the image it samples from,
+// so a later point whose pixel lies on an earlier point's circle gets that point's colour instead of the image's.  A radius-1,
+// thickness-1 circle of OpenCV's Bresenham rasteriser (imgproc/src/drawing.cpp, Circle(): dx = 1, dy = 0 is its only round) is
+// the four edge neighbours of the centre, clipped to the image; the centre itself is not drawn.
+// Hence: colour(i) = colour(j) for the LATEST j < i that sampled a 4-neighbour of i's pixel, else the image at i's pixel -- a
+// forest over the points whose roots read the untouched image.  With the records {pixel, point} sorted by pixel (the counting
+// sort above, stable: ascending point index inside a pixel) the parent is four short searches, and the root comes from
+// pointer jumping.
+//   k_color_first   : per sorted record: pix[point] = pixel; first[pixel] = position of the pixel's first record
+//   k_color_parent  : per point: the latest earlier point on a neighbouring pixel -> link[i] (itself for a root)
+//   k_color_resolve : per point: root by path halving (every value ever stored in link[i] is an ancestor of i, so the racing
+//                     updates of other threads, and stale reads of them, only shorten the way), colour from the image at the
+//                     root's pixel; points outside the image get colour 0 and intensity 0 (EMg.cpp:372-377)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_color_first(ColorArgs a)
+{
+    const uint32_t M = *a.total;
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= M) return;
+    const uint32_t key = a.key[s];
+    a.pix[a.hv[s].x] = key;
+    if (s == 0u || a.key[s - 1u] != key) a.first[key] = s;
+}
+
+__global__ __launch_bounds__(256) void k_color_parent(ColorArgs a)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (uint32_t)a.n) return;
+    const uint32_t p = a.pix[i];
+    uint32_t parent = i;
+    if (p != 0xffffffffu) {
+        const uint32_t M = *a.total;
+        const int x = (int)(p % (uint32_t)a.width), y = (int)(p / (uint32_t)a.width);
+        bool have = false;
+        auto look = [&](int qx, int qy) {
+            if (qx < 0 || qx >= a.width || qy < 0 || qy >= a.height) return;
+            const uint32_t q = (uint32_t)(qy * a.width + qx);
+            const uint32_t s0 = a.first[q];
+            if (s0 == 0xffffffffu) return;
+            // records of pixel q that come from points before i: a prefix of the pixel's run; galloping, then bisection
+            auto before = [&](uint32_t s) { return s < M && a.key[s] == q && a.hv[s].x < i; };
+            if (!before(s0)) return;
+            uint32_t lo = s0, step = 1u, hi;                           // before(lo) holds, before(hi) does not
+            for (;;) { hi = lo + step; if (!before(hi)) break; lo = hi; step <<= 1; }
+            while (hi - lo > 1u) { const uint32_t mid = lo + ((hi - lo) >> 1); if (before(mid)) lo = mid; else hi = mid; }
+            const uint32_t j = a.hv[lo].x;
+            if (!have || j > parent) { parent = j; have = true; }
+        };
+        look(x - 1, y); look(x + 1, y); look(x, y - 1); look(x, y + 1);
+    }
+    a.link[i] = parent;
+}
+
+__global__ __launch_bounds__(256) void k_color_resolve(ColorArgs a)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (uint32_t)a.n) return;
+    if (a.pix[i] == 0xffffffffu) {
+        a.rgb[i] = 0u;
+        reinterpret_cast<float*>(a.xyzi + i)[3] = 0.0f;
+        return;
+    }
+    volatile uint32_t* link = a.link;
+    uint32_t r = i;
+    for (;;) {
+        const uint32_t up = link[r];
+        if (up == r) break;
+        const uint32_t up2 = link[up];
+        if (up2 != up) link[r] = up2;
+        r = up2;
+    }
+    const uint32_t p = a.pix[r];
+    const unsigned char* px = a.image + (size_t)(p / (uint32_t)a.width) * a.stride + (size_t)(p % (uint32_t)a.width) * 3u;
+    a.rgb[i] = ((uint32_t)px[2] << 16) | ((uint32_t)px[1] << 8) | (uint32_t)px[0];
+}
+
+hipError_t launch_colorize(hipStream_t st, const ColorArgs& a)
+{
+    if (a.n <= 0) return hipSuccess;
+    const dim3 grid((a.n + 255) / 256), block(256);
+    hipLaunchKernelGGL(k_color_first, grid, block, 0, st, a);
+    hipLaunchKernelGGL(k_color_parent, grid, block, 0, st, a);
+    hipLaunchKernelGGL(k_color_resolve, grid, block, 0, st, a);
+    return hipGetLastError();
 }
 
 } // namespace gem

@@ -276,6 +276,37 @@ public:
         return s;
     }
 
+    // The colourisation loop of ElevationMapping::Callback (ElevationMapping.cpp:321-381) on the cloud as the node holds it:
+    // P_lidar2img = Tcamera (3x4) * TLidar (4x4), every point takes the BGR pixel it lands on (b, g, r fields), draws its
+    // radius-1 circle for the later points, and points outside the image get b = g = r = 0 and intensity 0.
+    // image = cv::Mat::data of the BGR8 image, step = cv::Mat::step (0: width * 3); the image is not modified.
+    static std::array<double, 12> lidarToImage(const std::array<double, 12>& Tcamera, const Mat4& TLidar)
+    {
+        std::array<double, 12> P{};
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 4; ++c) {
+                double acc = Tcamera[4 * r] * TLidar[c];
+                for (int k = 1; k < 4; ++k) acc = acc + Tcamera[4 * r + k] * TLidar[4 * k + c];
+                P[4 * r + c] = acc;
+            }
+        return P;
+    }
+    void colorize(const std::array<double, 12>& lidar2img, int width, int height, const unsigned char* image, size_t step,
+                  PointXYZRGBICT* cloud, int n) const
+    {
+        gem_camera cam{};
+        for (int k = 0; k < 12; ++k) cam.lidar_to_image[k] = lidar2img[k];
+        cam.width = width; cam.height = height;
+        std::vector<float> xyzi(4 * static_cast<size_t>(n));
+        std::vector<std::uint32_t> rgb(static_cast<size_t>(n));
+        for (int i = 0; i < n; ++i) { xyzi[4 * i] = cloud[i].x; xyzi[4 * i + 1] = cloud[i].y; xyzi[4 * i + 2] = cloud[i].z; xyzi[4 * i + 3] = cloud[i].intensity; }
+        check(gem_colorize(h_, &cam, n, xyzi.data(), image, step, rgb.data()), "gem_colorize");
+        for (int i = 0; i < n; ++i) {
+            cloud[i].r = static_cast<std::uint8_t>(rgb[i] >> 16); cloud[i].g = static_cast<std::uint8_t>(rgb[i] >> 8); cloud[i].b = static_cast<std::uint8_t>(rgb[i]);
+            cloud[i].intensity = xyzi[4 * i + 3];
+        }
+    }
+
     void check(int rc, const char* what) const { if (rc != GEM_OK) throw Error(rc, std::string(what) + ": " + gem_last_error(h_)); }
 
 private:

@@ -19,13 +19,14 @@
 #ifndef GEM_HIP_H
 #define GEM_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define GEM_ABI_VERSION 6
+#define GEM_ABI_VERSION 7
 
 typedef enum gem_status {
     GEM_OK = 0,
@@ -203,6 +204,21 @@ int  gem_map_feature(gem_handle* h, float* elevation, float* variance, int* colo
  *      Run gem_map_feature first: rough / slope / traver are its layers.                                                      */
 int  gem_show(gem_handle* h, double map_length, double resolution, const double position[2],
               float* visual, float* points_xyz, unsigned char* points_rgb, int* out_count, unsigned char* image_bgr);
+
+/* ---- input colourisation (EMg.cpp:349-381, the loop of ElevationMapping::Callback in front of the path): every
+ *      point is projected into the camera image with P_lidar2img = T.camera (3x4) * T.lidar (4x4) (doubles, EMg.cpp:342-345;
+ *      row-major here), takes the BGR pixel it lands on, and draws cv::circle(img, pixel, 1, that colour) into the image the
+ *      later points sample -- gem_colorize reproduces that order dependence (the latest earlier point on a 4-neighbour pixel
+ *      hands its colour on).  Points that fall outside the image (or behind the camera) get colour 0 and INTENSITY 0
+ *      (EMg.cpp:372-377): xyzi is updated in place.  rgb[i] = 0x00RRGGBB, the `rgb` input of gem_add*.  row_stride = bytes per
+ *      image row (0 = width * 3).  The image itself is left as it was (the reference's drawn-on copy is discarded, EMg.cpp:316). */
+typedef struct gem_camera {
+    double lidar_to_image[12];   /* row-major 3 x 4 */
+    int    width, height;
+} gem_camera;
+int  gem_colorize(gem_handle* h, const gem_camera* cam, int n, float* xyzi, const unsigned char* image_bgr, size_t row_stride, uint32_t* rgb);
+int  gem_colorize_device(gem_handle* h, const gem_camera* cam, int n, float* d_xyzi, const unsigned char* d_image_bgr, size_t row_stride,
+                         uint32_t* d_rgb);           /* device pointers; only enqueues on the handle's stream */
 
 /* ---- loop-closure re-anchoring: Map_optmove (GPU:1215-1233, called EMg.cpp:1020) relabels the
  *      map centre to opt_position snapped to the old centre's cell lattice (the circular buffer is not shifted,

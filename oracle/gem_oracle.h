@@ -27,6 +27,9 @@
 #ifndef GEM_ORACLE_H
 #define GEM_ORACLE_H
 
+#include <stddef.h>
+#include <stdint.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -136,6 +139,10 @@ double gemo_motion_update(gemo_motion_state* s, const double pos[3], const doubl
 /* EM.cpp:85-149 (ElevationMap::show): the cell loop behind the visualMap_ layers, the point cloud and the orthomosaic.  gem_oracle_show.c */
 int gemo_show(const gemo_map* m, const float* rough, const float* slope, double map_length, double resolution, const double map_position[2],
               float* visual, float* points_xyz, unsigned char* points_rgb, unsigned char* image_bgr);
+
+/* the step in front of the path: input colourisation, EMg.cpp:349-381 (gem_oracle_color.c) */
+void gemo_lidar_to_image(const double tcamera[12], const double tlidar[16], double out[12]);
+int gemo_colorize(const double P[12], int width, int height, unsigned char* image_bgr, size_t stride, int n, float* xyzi, uint32_t* rgb);
 
 /* GPU:1304-1318 (Raytracing): G_Raytracing (GPU:708-891) then G_Clear_maplowest (GPU:232-239).  gem_oracle_raytrace.c */
 void gemo_raytracing(gemo_map* m);

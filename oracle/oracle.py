@@ -76,6 +76,9 @@ def lib() -> C.CDLL:
         l.gemo_add_batch_mt.argtypes = [POINTER(OMap), c_int, POINTER(OFrame), c_void_p, POINTER(c_longlong), c_void_p, c_int]
         l.gemo_show.restype = c_int
         l.gemo_show.argtypes = [POINTER(OMap), c_void_p, c_void_p, c_double, c_double, POINTER(c_double), c_void_p, c_void_p, c_void_p, c_void_p]
+        l.gemo_lidar_to_image.argtypes = [c_void_p, c_void_p, c_void_p]
+        l.gemo_colorize.restype = c_int
+        l.gemo_colorize.argtypes = [c_void_p, c_int, c_int, c_void_p, C.c_size_t, c_int, c_void_p, c_void_p]
         l.gemo_motion_init.argtypes = [POINTER(OMotion), c_double]
         l.gemo_motion_update.restype = c_double
         l.gemo_motion_update.argtypes = [POINTER(OMotion)] + [POINTER(c_double)] * 4
@@ -236,6 +239,26 @@ class OracleMap:
             np.ctypeslib.as_array(getattr(m, self.INT_LAYERS[name]), (n,))[:] = np.asarray(values, np.int32).reshape(-1)
         else:
             np.ctypeslib.as_array(getattr(m, name), (n,))[:] = np.asarray(values, np.float32).reshape(-1)
+
+
+def lidar_to_image(tcamera, tlidar) -> np.ndarray:
+    """P_lidar2img = T.camera (3x4) * T.lidar (4x4), EMg.cpp:343."""
+    a = np.ascontiguousarray(tcamera, np.float64).reshape(3, 4); b = np.ascontiguousarray(tlidar, np.float64).reshape(4, 4)
+    out = np.empty((3, 4), np.float64)
+    lib().gemo_lidar_to_image(_vp(a), _vp(b), _vp(out))
+    return out
+
+
+def colorize(P, image_bgr, xyzi):
+    """The colourisation loop of ElevationMapping::Callback (EMg.cpp:349-381), point by point.  Returns dict(rgb uint32 [n]
+    0x00RRGGBB, xyzi with intensity zeroed outside the image, image = the drawn-on copy, count)."""
+    P = np.ascontiguousarray(P, np.float64).reshape(3, 4)
+    img = np.ascontiguousarray(image_bgr, np.uint8).copy()
+    assert img.ndim == 3 and img.shape[2] == 3
+    pts = np.ascontiguousarray(xyzi, np.float32).copy()
+    rgb = np.zeros(pts.shape[0], np.uint32)
+    n = lib().gemo_colorize(_vp(P), img.shape[1], img.shape[0], _vp(img), img.strides[0], pts.shape[0], _vp(pts), _vp(rgb))
+    return {"rgb": rgb, "xyzi": pts, "image": img, "count": n}
 
 
 class OracleMotion:

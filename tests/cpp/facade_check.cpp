@@ -120,6 +120,23 @@ int main(int argc, char** argv)
             if (px == (float)wx && py == (float)wy) { found = true; CHECK(pz == e2[c0]); }
         }
         CHECK(found);
+        // input colourisation (ElevationMapping.cpp:349-381): a 6 x 4 image, an identity camera; point 1 lands on point 0's
+        // circle and takes its colour, point 2 is outside
+        std::vector<unsigned char> img(6 * 4 * 3);
+        for (size_t k = 0; k < img.size(); ++k) img[k] = static_cast<unsigned char>(10 + k);
+        const std::array<double, 12> tc = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        const gem::Mat4 tl = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        const std::array<double, 12> P = gem::ElevationMap::lidarToImage(tc, tl);
+        CHECK(P == tc);
+        gem::PointXYZRGBICT cl[3] = {};
+        cl[0].x = 2.5f; cl[0].y = 1.5f; cl[0].z = 1.f; cl[0].intensity = 9.f;       // pixel (2, 1)
+        cl[1].x = 3.5f; cl[1].y = 1.5f; cl[1].z = 1.f; cl[1].intensity = 8.f;       // pixel (3, 1): on the circle of point 0
+        cl[2].x = 7.5f; cl[2].y = 1.5f; cl[2].z = 1.f; cl[2].intensity = 7.f;       // outside
+        m2.colorize(P, 6, 4, img.data(), 0, cl, 3);
+        const unsigned char* p21 = &img[(1 * 6 + 2) * 3];
+        CHECK(cl[0].b == p21[0] && cl[0].g == p21[1] && cl[0].r == p21[2] && cl[0].intensity == 9.f);
+        CHECK(cl[1].b == p21[0] && cl[1].g == p21[1] && cl[1].r == p21[2] && cl[1].intensity == 8.f);
+        CHECK(cl[2].b == 0 && cl[2].g == 0 && cl[2].r == 0 && cl[2].intensity == 0.f);
     }
     std::printf(fails ? "FAILED (%d)\n" : "OK\n", fails);
     return fails;

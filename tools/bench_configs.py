@@ -114,6 +114,30 @@ def main():
                           "note": "tracking on: k_bin_wave + k_fuse_list<LOWEST> (two launches, no deferred k_frame)"}), flush=True)
         m.close()
 
+    if "color" in want:
+        # the step in front of the path: input colourisation of a C2-sized cloud from a 1280 x 720 camera image (gem_colorize_device)
+        import numpy as np
+        rng = np.random.default_rng(3)
+        n, w, h = 131072, 1280, 720
+        pts = np.empty((n, 4), np.float32)
+        pts[:, 0] = rng.uniform(0.5, 30.0, n); pts[:, 1] = rng.normal(0, 6.0, n); pts[:, 2] = rng.normal(0, 3.0, n); pts[:, 3] = 1.0
+        tl = np.array([[0, -1, 0, 0.02], [0, 0, -1, -0.05], [1, 0, 0, 0.1], [0, 0, 0, 1]], np.float64)
+        tc = np.array([[0.8 * w, 0, 0.5 * w, 0], [0, 0.8 * w, 0.5 * h, 0], [0, 0, 1, 0]], np.float64)
+        P = ElevationMap.lidar_to_image(tc, tl)
+        img = torch.from_numpy(rng.integers(1, 256, (h, w, 3)).astype(np.uint8)).to(dev)
+        d0 = torch.from_numpy(pts).to(dev)
+        m = ElevationMap(40, 0.1)
+        d = d0.clone()
+        for _ in range(5): m.colorize(P, img, d)
+        m.synchronize(); t0 = time.perf_counter()
+        for _ in range(args.reps * 2): m.colorize(P, img, d)
+        m.synchronize(); dt = (time.perf_counter() - t0) / (args.reps * 2)
+        rgb, _ = m.colorize(P, img, d); m.synchronize()
+        print(json.dumps({"config": "colourisation of 131072 points from a 1280x720 image, device-resident", "wall_us": dt * 1e6,
+                          "points_per_s": n / dt, "coloured": int((rgb != 0).sum().item()),
+                          "note": "memset of the pixel table (3.7 MB) + k_sort_project<camera> + 2 x (scan, scatter) + count + 3 colour kernels"}), flush=True)
+        m.close()
+
     if "c3" in want:
         wl = synth.config_c3()
         d = torch.from_numpy(wl.clouds[0]).to(dev)
