@@ -282,14 +282,14 @@ SortGeometry sort_geometry(const gem_handle* h, int n_sweeps)
     for (int i = 0; i < g.n_passes; ++i) {
         const int left = g.n_passes - i;
         int bits = (g.id_bits - shift + left - 1) / left;
-        if (i == 0) bits = std::max(bits, 6);                     // a wave's 64 cells never straddle a bin of the last pass
+        if (i == 0) bits = std::max(bits, 8);                     // the 256 cells of a k_fuse_walk workgroup never straddle a bin of the last pass
         if (i == g.n_passes - 1) bits = g.id_bits - shift;
         g.dshift[i] = shift; g.dbits[i] = bits;
         g.dbins[i] = i == g.n_passes - 1 ? (int)(((((long long)g.T) << 10) - 1) >> shift) + 1 : 1 << bits;
         shift += bits;
     }
     const long long max_sweeps = std::min<long long>(512, (1ll << (32 - g.id_bits)) - 1);     // the sweep field is never all ones
-    g.ok = g.id_bits <= 26 && n_sweeps <= max_sweeps && g.dshift[g.n_passes - 1] >= 6;
+    g.ok = g.id_bits <= 26 && n_sweeps <= max_sweeps && g.dshift[g.n_passes - 1] >= 8;
     for (int i = 0; i < g.n_passes; ++i) g.ok = g.ok && g.dbins[i] <= kSortMaxBins && g.dbits[i] >= 1;
     return g;
 }
@@ -418,7 +418,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     // centre rows first while (nearly) all of the walk's waves are resident at once: the start order then decides when the long
     // chains under the sensor begin (C4: 62 -> 52 us); a walk of many rounds reads its records front to back instead (C5:
     // 91 us in memory order, 100-120 us in any other)
-    wa.walk_order = (h->walk_permute && 16ll * T <= 16384) ? 1 : 0;
+    wa.walk_order = (h->walk_permute && 4ll * T <= 4096) ? 1 : 0;
     wa.center_tr = ((h->L / 2 + h->start[0]) % h->L) >> 5;
     wa.T = T; wa.tiles_per_row = geo.tiles_per_row; wa.L = h->L; wa.row0 = h->row0; wa.row1 = h->row1;
     wa.id_bits = geo.id_bits; wa.bin_shift = geo.dshift[geo.n_passes - 1]; wa.n_sweeps = in.n_sweeps;
@@ -1601,7 +1601,7 @@ static int shard_fuse_locked(gem_handle* h, int n_src, const void* const* d_hv, 
     wa.start0 = h->start[0]; wa.start1 = h->start[1];
     wa.counters = h->counting ? h->d_counters : nullptr;
     wa.count_per_pass = 0;
-    wa.walk_order = (h->walk_permute && 16ll * geo.T <= 16384) ? 1 : 0;
+    wa.walk_order = (h->walk_permute && 4ll * geo.T <= 4096) ? 1 : 0;
     wa.center_tr = ((h->L / 2 + h->start[0]) % h->L) >> 5;
     if (var_updates_global) {
         if (n_global_sweeps > 512) return fail(h, GEM_ERR_INVALID, "sharded path: more than 512 sweeps");

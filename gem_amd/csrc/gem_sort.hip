@@ -389,23 +389,30 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void k_sort_scatter(PassAr
 // count the touched cells per sweep (statistics).
 constexpr int kWalkMaxSweeps = 512;
 
+constexpr int kWalkNT = 256;                    // threads of a k_fuse_walk workgroup: 256 consecutive cells (eight rows of a tile)
+
 template <int FLAGS, int MODE>
-__global__ __launch_bounds__(64) void k_fuse_walk(WalkArgs a)
+__global__ __launch_bounds__(kWalkNT) void k_fuse_walk(WalkArgs a)
 {
     constexpr int ATTR = FLAGS & 3;
     constexpr bool LOWEST = (FLAGS & 4) != 0;
     constexpr bool HAS_VU = (MODE & 1) != 0, COUNT_SWEEPS = (MODE & 2) != 0, KEYED = HAS_VU || COUNT_SWEEPS;
-    __shared__ uint32_t cstart[64], cend[64];
+    constexpr int NT = kWalkNT, NW = NT / 64;
+    __shared__ uint32_t cstart[NT], cend[NT], hist[128];
+    __shared__ float sh_e[NT], sh_s[NT], sh_l[LOWEST ? NT : 1];
+    __shared__ uint16_t perm[NT];
     __shared__ float vu[HAS_VU ? kWalkMaxSweeps : 1];
-    const int lane = (int)threadIdx.x;
-    // Block -> group of 64 cells, CENTRE ROWS FIRST: the map is robot-centric, the groups under the sensor carry chains a hundred
-    // times longer than the rim's, and a wave takes as long as its longest chain -- so the tile rows start in the order c, c-1,
-    // c+1, c-2, ... from the row holding the map centre in storage coordinates (wrapped: a bijection); inside a row the tiles
-    // keep their memory order (C4's walk alone 62 -> 52 us; ordering the columns centre-first too cost an aggregated cloud,
-    // whose records then are not read front to back, 115 -> 120 us).
-    int tile, q = (int)(blockIdx.x & 15);
+    const int tid = (int)threadIdx.x, lane = lane_id(), w = tid >> 6;
+    // Block -> 256 cells (a quarter of a tile), CENTRE ROWS FIRST: the map is robot-centric, the cells under the sensor carry
+    // chains a hundred times longer than the rim's, and a wave takes as long as its longest chain -- so the tile rows start in
+    // the order c, c-1, c+1, c-2, ... from the row holding the map centre in storage coordinates (wrapped: a bijection); inside a
+    // row the tiles keep their memory order (C4's walk alone 62 -> 52 us; ordering the columns centre-first too cost an
+    // aggregated cloud, whose records then are not read front to back, 115 -> 120 us).
+    // The four waves of a workgroup land on the CU's four SIMDs: a long chain still has a SIMD to itself, and the search and the
+    // boundary scan below are shared by four times as many cells as with one wave per workgroup.
+    int tile, q4 = (int)(blockIdx.x & 3);
     {
-        const int tpr = a.tiles_per_row, rnk = (int)(blockIdx.x >> 4);
+        const int tpr = a.tiles_per_row, rnk = (int)(blockIdx.x >> 2);
         if (a.walk_order) {
             const int bi = rnk / tpr, bj = rnk - bi * tpr;
             const int oi = (bi & 1) ? -((bi + 1) >> 1) : (bi >> 1);
@@ -416,29 +423,130 @@ __global__ __launch_bounds__(64) void k_fuse_walk(WalkArgs a)
     const int tr = tile / a.tiles_per_row, tc = tile - tr * a.tiles_per_row;
     if ((tr << 5) >= a.row1 || (tr << 5) + 32 <= a.row0) return;       // a tile row outside this device's strip
     const uint32_t idmask = (1u << a.id_bits) - 1u;
-    const uint32_t id0 = ((uint32_t)tile << 10) | ((uint32_t)q << 6);  // the cell ids of this wave: id0 .. id0 + 63
+    const uint32_t id0 = ((uint32_t)tile << 10) | ((uint32_t)q4 << 8); // the cell ids of this workgroup: id0 .. id0 + 255
     uint32_t run_lo = 0, run_hi = 0;
     if (a.n_src <= 1) {
         // one source (the device's own sort): the records of these cells lie inside the run of the last pass's bin that
-        // holds id0 (64 divides the bin width)
+        // holds id0 (256 divides the bin width)
         const uint32_t bin = id0 >> a.bin_shift;
         run_lo = a.bin_base[bin]; run_hi = a.bin_base[bin + 1];
         if (run_lo == run_hi && !a.dense) return;
     }
 
-    const int row = (tr << 5) + (q << 1) + (lane >> 5), col = (tc << 5) + (lane & 31);
+    // ---- the thread's OWN cell (cell tid of the workgroup): its map values are fetched now, coalesced, in flight behind the search
     const int L = a.L;
+    const int row_t = (tr << 5) + (q4 << 3) + (tid >> 5), col_t = (tc << 5) + (tid & 31);
+    const bool owned_t = row_t >= a.row0 && row_t < a.row1 && col_t < L;
+    const size_t g_t = owned_t ? (size_t)row_t * L + col_t : 0;
+    const float e_t = a.elevation[g_t], s_t = a.variance[g_t];
+    float l_t = 0.0f;
+    if constexpr (LOWEST) {                                            // map_lowest is indexed by the GEOGRAPHIC cell (GPU:430)
+        int gr = row_t - a.start0, gc = col_t - a.start1;
+        gr += gr < 0 ? L : 0; gc += gc < 0 ? L : 0;
+        l_t = a.lowest[owned_t ? (size_t)gr * L + gc : 0];
+    }
+    if constexpr (HAS_VU) for (int i = tid; i < a.n_sweeps; i += NT) vu[i] = a.var_updates[i];
+
+    // ---- where the cells of this workgroup begin and end in one SOURCE of records sorted by cell id (keys[lo0, hi0) may hold
+    //      them): cstart / cend in LDS; false if the source has nothing for these cells.  Block-uniform.
+    uint32_t rb = 0;
+    auto find_bounds = [&](const uint32_t* __restrict__ keys, uint32_t lo0, uint32_t hi0) -> bool {
+        // 32-ary search, both ends at once: lanes 0-31 look for the first record with id >= id0, lanes 32-63 for id >= id0 + 256
+        // (every wave of the workgroup runs the same search: the probes of the other three hit the L1)
+        uint32_t lo = lo0, hi = hi0;                                   // ids below `lo` are < target, ids from `hi` on are >= target
+        {
+            const uint32_t target = id0 + (uint32_t)(lane >> 5) * (uint32_t)NT, l5 = (uint32_t)lane & 31u;
+            while (__ballot(lo < hi) != 0) {                           // wave-uniform
+                const uint32_t n = hi - lo, s = (n + 32u) / 33u;       // probes lo + j s + s - 1, j = 0..31
+                const uint32_t pos = lo + l5 * s + s - 1u;
+                const bool probe = lo < hi && pos < hi;
+                const uint32_t id = probe ? (keys[pos] & idmask) : 0xffffffffu;
+                const uint64_t bl = __ballot(probe && id < target);
+                const uint32_t k = (uint32_t)__popc((uint32_t)(bl >> (lane & 32)));   // a prefix of the probes: the ids are sorted
+                // probes 0 .. k-1 are below the target, probe k (if there is one: k < 32 and inside the range) is not
+                if (lo < hi) { const uint32_t nl = lo + k * s; if (k < 32u) hi = min(hi, nl + s - 1u); lo = nl; }
+            }
+        }
+        rb = (uint32_t)__shfl((int)lo, 0, 64);
+        const uint32_t re = (uint32_t)__shfl((int)lo, 32, 64);
+        __syncthreads();                                               // (the previous source's boundaries have been read)
+        cstart[tid] = 0u; cend[tid] = 0u;
+        __syncthreads();
+        if (rb == re) return false;
+        // cell boundaries of the workgroup's run: the records are sorted by cell, so a cell starts -- and the one before it
+        // ends -- where the key's cell changes.  The waves take the rounds in turn; rounds of sixteen loads for long runs: the run
+        // of the cells under the sensor is thousands of records long, and one load per round made this loop a chain of memory
+        // latencies (half of the kernel's time).
+        {
+            auto scan_rounds = [&](auto Uc, uint32_t p_begin, uint32_t p_end) {
+                constexpr int U = decltype(Uc)::value;
+                for (uint32_t p0 = p_begin + (uint32_t)w * 64u * U; p0 < p_end; p0 += (uint32_t)NW * 64u * U) {   // wave-uniform
+                    uint32_t c[U];
+                    // the cell of the record before the round's first (another wave's round): one more load
+                    uint32_t carry = p0 > rb ? (keys[p0 - 1u] & (uint32_t)(NT - 1)) : 0xffffffffu;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { const uint32_t p = p0 + 64u * u + (uint32_t)lane; c[u] = keys[min(p, re - 1u)] & (uint32_t)(NT - 1); }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t p = p0 + 64u * u + (uint32_t)lane;
+                        const bool live = p < re;
+                        const uint32_t cell = live ? c[u] : 0xfffffffeu;
+                        uint32_t prev = (uint32_t)__shfl_up((int)cell, 1, 64);
+                        if (lane == 0) prev = carry;
+                        carry = (uint32_t)__builtin_amdgcn_readlane((int)cell, 63);
+                        if (live && cell != prev) { cstart[cell] = p; if (prev < (uint32_t)NT) cend[prev] = p; }
+                        if (p + 1u == re) cend[cell] = re;
+                    }
+                }
+            };
+            const uint32_t long_part = re - rb >= 8192u ? ((re - rb) / 4096u) * 4096u : 0u;
+            if (long_part) scan_rounds(std::integral_constant<int, 16>{}, rb, rb + long_part);
+            scan_rounds(std::integral_constant<int, 2>{}, rb + long_part, re);
+        }
+        __syncthreads();
+        return true;
+    };
+
+    // ---- which cell this thread walks.  A wave lasts as long as its longest run, and the runs of 64 neighbouring cells differ
+    //      widely (a LiDAR ring crosses some cells of a row and misses the next: on C4 the lanes of a wave were busy half of the
+    //      time, 0.51 = sum of the runs / 64 x the longest; a depth image 0.57).  So the workgroup's cells are handed out in
+    //      descending order of their run length -- wave 0 takes the 64 longest, the last wave the empty ones: 0.80 on C4 -- by a
+    //      counting sort over the run lengths (exact below 64, eight steps per octave above).  Several sources (multi-GPU strip
+    //      owner): every thread keeps its own cell, the sources' runs are not known together.
+    uint32_t c = (uint32_t)tid;
+    bool have = false;
+    if (a.n_src <= 1) {
+        have = find_bounds(a.key, run_lo, run_hi);
+        sh_e[tid] = e_t; sh_s[tid] = s_t;
+        if constexpr (LOWEST) sh_l[tid] = l_t;
+        if (tid < 128) hist[tid] = 0u;
+        __syncthreads();
+        const uint32_t n_t = cend[tid] - cstart[tid];
+        uint32_t bin = n_t;
+        if (n_t >= 64u) { const uint32_t lg = 31u - (uint32_t)__clz((int)n_t); bin = 64u + min(63u, (lg - 6u) * 8u + ((n_t >> (lg - 3u)) & 7u)); }
+        const uint32_t rank = atomicAdd(&hist[bin], 1u);
+        __syncthreads();
+        if (w == 0) {                                                  // hist[b] -> cells with a longer run than bin b's
+            const uint32_t v1 = hist[127 - 2 * lane], v0 = hist[126 - 2 * lane];
+            const uint32_t incl = wave_inclusive_scan(v1 + v0), excl = incl - (v1 + v0);
+            hist[127 - 2 * lane] = excl; hist[126 - 2 * lane] = excl + v1;
+        }
+        __syncthreads();
+        perm[hist[bin] + rank] = (uint16_t)tid;
+        __syncthreads();
+        c = perm[tid];
+    }
+    const int row = (tr << 5) + (q4 << 3) + (int)(c >> 5), col = (tc << 5) + (int)(c & 31u);
     const bool owned = row >= a.row0 && row < a.row1 && col < L;
     const size_t g = owned ? (size_t)row * L + col : 0;
-    const float e0 = a.elevation[g], s0 = a.variance[g];               // in flight behind the search
+    const float e0 = a.n_src <= 1 ? sh_e[c] : e_t, s0 = a.n_src <= 1 ? sh_s[c] : s_t;
     size_t lgeo = 0; float lw = 0.0f, lw0 = 0.0f;
-    if constexpr (LOWEST) {                                            // map_lowest is indexed by the GEOGRAPHIC cell (GPU:430)
+    if constexpr (LOWEST) {
         int gr = row - a.start0, gc = col - a.start1;
         gr += gr < 0 ? L : 0; gc += gc < 0 ? L : 0;
         lgeo = owned ? (size_t)gr * L + gc : 0;
-        lw0 = lw = a.lowest[lgeo];
+        lw0 = lw = a.n_src <= 1 ? sh_l[c] : l_t;
     }
-    if constexpr (HAS_VU) for (int i = lane; i < a.n_sweeps; i += 64) vu[i] = a.var_updates[i];
 
     float ce = e0, cs = s0;
     uint32_t cur = 0;                                                  // "inside sweep cur, its increment applied"
@@ -459,61 +567,9 @@ __global__ __launch_bounds__(64) void k_fuse_walk(WalkArgs a)
     };
     uint32_t wlast = 0xffffffffu, sweeps_seen = 0, last_sweep = 0xffffffffu, n_total = 0;
 
-    // ---- one SOURCE of records sorted by cell id: keys / {h, var} / source words, the part [lo0, hi0) that may hold this wave's
-    //      cells.  A single device has one source; a strip owner of the multi-GPU tiling walks the sources in rank order, which
-    //      is the input order of the points (gem_add_sharded_device).
-    auto walk_source = [&](const uint32_t* __restrict__ keys, const uint2* __restrict__ hvs, const uint32_t* __restrict__ srcs,
-                           uint32_t lo0, uint32_t hi0) {
-        // 32-ary search, both ends at once: lanes 0-31 look for the first record with id >= id0, lanes 32-63 for id >= id0 + 64
-        uint32_t lo = lo0, hi = hi0;                                   // ids below `lo` are < target, ids from `hi` on are >= target
-        {
-            const uint32_t target = id0 + (uint32_t)(lane >> 5) * 64u, l5 = (uint32_t)lane & 31u;
-            while (__ballot(lo < hi) != 0) {                           // wave-uniform
-                const uint32_t n = hi - lo, s = (n + 32u) / 33u;       // probes lo + j s + s - 1, j = 0..31
-                const uint32_t pos = lo + l5 * s + s - 1u;
-                const bool probe = lo < hi && pos < hi;
-                const uint32_t id = probe ? (keys[pos] & idmask) : 0xffffffffu;
-                const uint64_t bl = __ballot(probe && id < target);
-                const uint32_t k = (uint32_t)__popc((uint32_t)(bl >> (lane & 32)));   // a prefix of the probes: the ids are sorted
-                // probes 0 .. k-1 are below the target, probe k (if there is one: k < 32 and inside the range) is not
-                if (lo < hi) { const uint32_t nl = lo + k * s; if (k < 32u) hi = min(hi, nl + s - 1u); lo = nl; }
-            }
-        }
-        const uint32_t rb = (uint32_t)__shfl((int)lo, 0, 64), re = (uint32_t)__shfl((int)lo, 32, 64);
-        if (rb == re) return;                                          // wave-uniform: this source has nothing for these cells
-        __syncthreads();                                               // (the previous source's boundaries have been read)
-        cstart[lane] = 0u; cend[lane] = 0u;
-        __syncthreads();
-        // cell boundaries of the wave's run: the records are sorted by cell, so a cell starts -- and the one before it ends --
-        // where the key's cell changes.  Rounds of sixteen loads for long runs: the run of a wave under the sensor is thousands
-        // of records long, and one load per round made this loop a chain of memory latencies (half of the kernel's time).
-        {
-            uint32_t carry = 0xffffffffu;                              // cell of the record before the round's first (wave-uniform)
-            auto scan_rounds = [&](auto Uc, uint32_t p_begin, uint32_t p_end) {
-                constexpr int U = decltype(Uc)::value;
-                for (uint32_t p0 = p_begin; p0 < p_end; p0 += 64u * U) {   // wave-uniform
-                    uint32_t c[U];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) { const uint32_t p = p0 + 64u * u + (uint32_t)lane; c[u] = keys[min(p, re - 1u)] & 63u; }
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const uint32_t p = p0 + 64u * u + (uint32_t)lane;
-                        const bool live = p < re;
-                        const uint32_t cell = live ? c[u] : 0xfffffffeu;
-                        uint32_t prev = (uint32_t)__shfl_up((int)cell, 1, 64);
-                        if (lane == 0) prev = carry;
-                        carry = (uint32_t)__builtin_amdgcn_readlane((int)cell, 63);
-                        if (live && cell != prev) { cstart[cell] = p; if (prev < 64u) cend[prev] = p; }
-                        if (p + 1u == re) cend[cell] = re;
-                    }
-                }
-            };
-            const uint32_t long_part = re - rb >= 2048u ? ((re - rb) / 1024u) * 1024u : 0u;
-            if (long_part) scan_rounds(std::integral_constant<int, 16>{}, rb, rb + long_part);
-            scan_rounds(std::integral_constant<int, 2>{}, rb + long_part, re);
-        }
-        __syncthreads();
-        const uint32_t first = cstart[lane], n = cend[lane] - first;
+    // ---- the run of cell c in one source (its boundaries are in LDS)
+    auto walk_run = [&](const uint32_t* __restrict__ keys, const uint2* __restrict__ hvs, const uint32_t* __restrict__ srcs) {
+        const uint32_t first = cstart[c], n = cend[c] - first;
         n_total += n;
         // The cell's own run.  The 64 lanes read 64 different streams, and a wave load whose lanes fall into 64 different cache
         // lines occupies the CU's vector L1 for 64 cycles whatever its width: with one 8-byte and one 4-byte load per step the
@@ -573,12 +629,12 @@ __global__ __launch_bounds__(64) void k_fuse_walk(WalkArgs a)
     for (int k = 0; k < a.n_pending; ++k) if (cs != kInitVariance) cs += a.pending[k];
     if constexpr (HAS_VU) { if (cs != kInitVariance) cs += vu[0]; u1 = vu[min(1u, last_sw)]; }
     if (a.n_src <= 1) {
-        walk_source(a.key, a.hv, a.src, run_lo, run_hi);
+        if (have) walk_run(a.key, a.hv, a.src);
     } else {
         for (int sidx = 0; sidx < a.n_src; ++sidx)                     // rank order = input order
-            walk_source(a.src_key[sidx], a.src_hv[sidx], nullptr, 0u, a.src_n[sidx]);
+            if (find_bounds(a.src_key[sidx], 0u, a.src_n[sidx])) walk_run(a.src_key[sidx], a.src_hv[sidx], nullptr);
     }
-    if (__ballot(n_total != 0) == 0 && !a.dense) return;               // nothing reached these cells and nothing is pending
+    if (__ballot(n_total != 0) == 0 && !a.dense) return;               // nothing reached this wave's cells and nothing is pending
     if constexpr (HAS_VU) advance(last_sw);
     if (cs < a.var_floor) cs = a.var_floor;                            // GPU:533-534, on every cell
 
@@ -741,7 +797,7 @@ hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, co
 template <int FLAGS>
 static hipError_t launch_walk_f(hipStream_t st, const WalkArgs& a, int mode, LaunchEvents ev)
 {
-    const dim3 grid(a.T * 16), block(64);
+    const dim3 grid(a.T * 4), block(kWalkNT);
     switch (mode) {
     case 0:  GEM_LAUNCH((k_fuse_walk<FLAGS, 0>), grid, block, 0, st, ev, a); break;
     case 1:  GEM_LAUNCH((k_fuse_walk<FLAGS, 1>), grid, block, 0, st, ev, a); break;

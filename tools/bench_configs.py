@@ -116,7 +116,6 @@ def main():
 
     if "color" in want:
         # the step in front of the path: input colourisation of a C2-sized cloud from a 1280 x 720 camera image (gem_colorize_device)
-        import numpy as np
         rng = np.random.default_rng(3)
         n, w, h = 131072, 1280, 720
         pts = np.empty((n, 4), np.float32)
