@@ -219,18 +219,22 @@ __device__ __forceinline__ bool fuse_step(float& e, float& s, float h, float v, 
     // the reference's own expression is evaluated only inside a +-1e-5 relative band around the threshold
     // (or for a subnormal sf, which v_rsq_f32 flushes): the decision is the reference's in every case.
     const float d  = fabsf(h - e);
-    const float mt = d * __builtin_amdgcn_rsqf(sf);
-    bool outlier = mt > mahal_thr;
-    if (__builtin_expect(fabsf(mt - mahal_thr) <= 1e-5f * fabsf(mahal_thr) || !(sf >= 1e-30f), 0))
-        outlier = d / sqrtf(sf) > mahal_thr;
+    float m = d * __builtin_amdgcn_rsqf(sf);
+    if (__builtin_expect(fabsf(m - mahal_thr) <= 1e-5f * fabsf(mahal_thr) || !(sf >= 1e-30f), 0))
+        m = d / sqrtf(sf);                                                         // a float, not a flag, leaves the rare branch
+    const bool outlier = m > mahal_thr;
     const float en = (sf * h + v * e) / (sf + v);                                  // GPU:518
     const float sn = (v * sf) / (v + sf);                                          // GPU:519
-    const bool replace = empty || (outlier && e < h);                              // GPU:484-486, 505-507
-    const bool fuse = !empty && !outlier;
-    const float e_new = replace ? h : (fuse ? en : e);
-    const float s_new = replace ? v : (fuse ? sn : sf);
+    // (bitwise, not short-circuit: `||` / `&&` become selects between i1 values, which this compiler carries through VGPRs --
+    //  five instructions per record; `|` / `&` stay operations on the wave's lane masks)
+    const bool replace = empty | (outlier & (e < h));                              // GPU:484-486, 505-507
+    // not replaced: an outlier below the cell leaves it alone (the floor is still written back), anything else is fused --
+    // two selects per value
+    const float e_new = replace ? h : (outlier ? e : en);
+    const float s_new = replace ? v : (outlier ? sf : sn);
+    const bool fuse = !outlier;
     e = e_new; s = s_new;
-    return replace || fuse;
+    return replace | fuse;
 }
 
 } // namespace gem

@@ -389,6 +389,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void k_sort_scatter(PassAr
 // count the touched cells per sweep (statistics).
 constexpr int kWalkMaxSweeps = 512;
 
+constexpr int kWalkDepth = 3;                   // groups of four records a lane has in flight
 constexpr int kWalkNT = 256;                    // threads of a k_fuse_walk workgroup: 256 consecutive cells (eight rows of a tile)
 
 template <int FLAGS, int MODE>
@@ -613,14 +614,19 @@ __global__ __launch_bounds__(kWalkNT) void k_fuse_walk(WalkArgs a)
             step(i0 + 2u, G.h23.x, G.h23.y, G.k4.z, G.s4.z);
             step(i0 + 3u, G.h23.z, G.h23.w, G.k4.w, G.s4.w);
         };
-        Group A{}, B{}, C{};
-        load_group(0u, A); load_group(1u, B); load_group(2u, C);
-        for (uint32_t gi = 0; 4u * gi < nmax; gi += 3u) {              // wave-uniform
-            run_group(4u * gi, A);       load_group(gi + 3u, A);
-            if (4u * gi + 4u >= nmax) break;
-            run_group(4u * gi + 4u, B);  load_group(gi + 4u, B);
-            if (4u * gi + 8u >= nmax) break;
-            run_group(4u * gi + 8u, C);  load_group(gi + 5u, C);
+        // kWalkDepth groups in flight.  (Six instead of three: no gain on a depth image, whose 300-point cells are bound by the
+        // recurrence itself -- about 70 dependent-issue instructions per record on one SIMD -- and C5 slower by 10 %: the
+        // registers cost a wave per SIMD.)
+        Group G[kWalkDepth];
+#pragma unroll
+        for (int d = 0; d < kWalkDepth; ++d) { G[d] = Group{}; load_group((uint32_t)d, G[d]); }
+        for (uint32_t gi = 0; 4u * gi < nmax; gi += (uint32_t)kWalkDepth) {   // wave-uniform
+#pragma unroll
+            for (int d = 0; d < kWalkDepth; ++d) {
+                if (4u * (gi + (uint32_t)d) >= nmax) break;
+                run_group(4u * (gi + (uint32_t)d), G[d]);
+                load_group(gi + (uint32_t)(d + kWalkDepth), G[d]);
+            }
         }
     };
 
