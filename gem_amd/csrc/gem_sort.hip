@@ -223,18 +223,31 @@ __global__ __launch_bounds__(1024) void k_sort_scan(uint32_t* __restrict__ cnt, 
     }
 }
 
-// Stable rank of this lane's item among the items of the same bin that precede it in the wave's share of the chunk:
-// equal bins inside one step are matched by ballots, the wave's cursor of the bin (LDS, private to the wave: its LDS
-// operations execute in order) carries the count from step to step.
-__device__ __forceinline__ uint32_t wave_rank_step(bool valid, uint32_t bin, int nbits, uint32_t* wcur, uint64_t lt)
+// Stable rank of this lane's item among the items of the same bin that precede it in the wave's share of the chunk: the
+// wave's cursor of the bin (LDS, private to the wave: its LDS operations execute in order) carries the count from step to
+// step; inside a step the lanes of a bin find each other THROUGH THE LDS: every lane stores its number into the wave's slot of
+// its bin (whichever store lands last names the group), reads the name back, ORs its bit into the wave's 64-bit mask of that
+// name and reads the mask: the lanes of the same bin.  Five LDS instructions and a handful of VALU ones for any digit width --
+// matching the digits by one ballot per bit (wave_peers) costs six VALU instructions per bit, 60 of this kernel's 185 per
+// record with ten-bit digits, and this kernel is bound by VALU issue.
+__device__ __forceinline__ uint32_t wave_rank_step(bool valid, uint32_t bin, uint32_t* wcur, uint8_t* wslot, unsigned long long* wpm,
+                                                   uint64_t lt, unsigned long long mybit)
 {
-    const uint64_t peers = wave_peers(valid, bin, nbits);
+    const uint32_t lane = (uint32_t)lane_id();
+    if (valid) wslot[bin] = (uint8_t)lane;
+    const uint32_t name = valid ? (uint32_t)wslot[bin] : lane;
+    if (valid) atomicOr(&wpm[name], mybit);
+    const uint64_t peers = valid ? (uint64_t)wpm[name] : 0ull;
+    if (valid && name == lane) wpm[name] = 0ull;                       // for the next step (after every lane's read: in order)
     const uint32_t rank = (uint32_t)__popcll(peers & lt);
     uint32_t old = 0;
     if (valid && rank == 0) old = atomicAdd(&wcur[bin], (uint32_t)__popcll(peers));
-    old = (uint32_t)__shfl((int)old, valid ? __ffsll((unsigned long long)peers) - 1 : lane_id(), 64);
+    old = (uint32_t)__shfl((int)old, valid ? __ffsll((unsigned long long)peers) - 1 : (int)lane, 64);
     return old + rank;
 }
+
+// words of LDS the ranking phase of k_sort_scatter needs: per wave a cursor per bin, a name byte per bin, 64 masks
+__host__ __device__ constexpr size_t rank_words(int nw, int bins) { return (size_t)nw * bins + (size_t)nw * ((bins + 3) / 4) + (size_t)nw * 128; }
 
 // ------------------------------------------------------------------------------------------
 // count + scatter of one digit (both passes), chunks of kSortChunk records.  Pass 1 reads the input-ordered records of
@@ -275,6 +288,8 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void k_sort_scatter(PassAr
     uint32_t* scratch = delta + bins;                                  // [16]
     uint32_t* region = scratch + 16;                                   // per-wave cursors, then (aliased) the staged records
     uint32_t* wcnt = region;                                           // [NW][bins]
+    uint8_t* wslots = reinterpret_cast<uint8_t*>(region + NW * bins);   // [NW][4 * ((bins + 3) / 4)] bytes
+    unsigned long long* wpms = reinterpret_cast<unsigned long long*>(region + NW * bins + NW * ((bins + 3) / 4));   // [NW][64]
     uint2* st_hv = reinterpret_cast<uint2*>(region);                   // [CH]
     uint32_t* st_key = region + 2 * CH;                                // [CH]
     uint32_t* st_src = region + 3 * CH;                                // [CH] (ATTR)
@@ -285,6 +300,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void k_sort_scatter(PassAr
     else { const ChunkRange cr = chunk_range<CH>(a.sweep_chunk0, a.sweep_first, nullptr, a.n_sweeps, a.n_host, chunk); first = cr.first; end = cr.end; }
     if (first >= end && !(a.bin_base && chunk == 0)) return;           // workgroup 0 of the last pass always publishes the bin bases
     for (int i = tid; i < NW * bins; i += NT) wcnt[i] = 0u;
+    for (int i = tid; i < NW * 64; i += NT) wpms[i] = 0ull;
     const long long base = first + (long long)w * (K * 64) + lane;
     uint2 hv[K]; uint32_t key[K], src[K], rk[K];
 #pragma unroll
@@ -298,8 +314,11 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void k_sort_scatter(PassAr
     // ---- 1. stable rank inside the wave's share, per-wave counts
     {
         uint32_t* wcur = wcnt + w * bins;
+        uint8_t* wslot = wslots + (size_t)w * 4 * ((bins + 3) / 4);
+        unsigned long long* wpm = wpms + w * 64;
+        const unsigned long long mybit = 1ull << lane;
 #pragma unroll
-        for (int k = 0; k < K; ++k) rk[k] = wave_rank_step(key[k] != kKeyInvalid, (key[k] >> a.shift) & a.mask, a.digit_bits, wcur, lt);
+        for (int k = 0; k < K; ++k) rk[k] = wave_rank_step(key[k] != kKeyInvalid, (key[k] >> a.shift) & a.mask, wcur, wslot, wpm, lt, mybit);
     }
     __syncthreads();
     // ---- 2. per bin: the waves in order (exclusive prefix), the chunk's local base, the way from local to global positions
@@ -699,14 +718,14 @@ __global__ __launch_bounds__(64) void k_strip_bounds(const uint32_t* __restrict_
     } while (0)
 
 // Threads of the count / scatter workgroups of a pass with `bins` bins.  LDS of k_sort_scatter: 2 bins + 16 words + the larger of
-// the per-wave cursors (threads / 64 * bins) and the staged chunk (3 or 4 words per record).
+// the ranking tables (rank_words) and the staged chunk (3 or 4 words per record).
 SortShape sort_shape(int bins, bool attr)
 {
     SortShape s;
     const size_t stage = (size_t)(attr ? 4 : 3) * kSortChunk;
-    s.nt = (size_t)8 * bins <= stage + 2048 ? 512 : 256;              // eight waves while their cursors fit under the stage
+    s.nt = rank_words(8, bins) <= stage + 2048 ? 512 : 256;           // eight waves while their ranking tables fit under the stage
     s.chunk = kSortChunk;
-    s.lds = ((size_t)2 * bins + 16 + std::max((size_t)(s.nt / 64) * bins, stage)) * 4;
+    s.lds = ((size_t)2 * bins + 16 + std::max(rank_words(s.nt / 64, bins), stage)) * 4;
     return s;
 }
 
