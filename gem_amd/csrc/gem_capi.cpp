@@ -281,7 +281,10 @@ SortGeometry sort_geometry(const gem_handle* h, int n_sweeps)
     int shift = 0;
     for (int i = 0; i < g.n_passes; ++i) {
         const int left = g.n_passes - i;
-        int bits = (g.id_bits - shift + left - 1) / left;
+        // (rounded down: the lowest digit sees the records in input order -- every bin in use, a run per bin and chunk -- and pays
+        //  for its bins; the higher digits see them sorted by the lower ones, longer runs.  600^2: 512 x 722 bins 28.7 + 26.4 us,
+        //  1024 x 361 37.7 + 21.4, 256 x 1444 27.6 + 38.8)
+        int bits = (g.id_bits - shift) / left;
         if (i == 0) bits = std::max(bits, 8);                     // the 256 cells of a k_fuse_walk workgroup never straddle a bin of the last pass
         if (i == g.n_passes - 1) bits = g.id_bits - shift;
         g.dshift[i] = shift; g.dbits[i] = bits;

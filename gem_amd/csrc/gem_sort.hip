@@ -234,11 +234,14 @@ __device__ __forceinline__ uint32_t wave_rank_step(bool valid, uint32_t bin, uin
                                                    uint64_t lt, unsigned long long mybit)
 {
     const uint32_t lane = (uint32_t)lane_id();
-    if (valid) wslot[bin] = (uint8_t)lane;
-    const uint32_t name = valid ? (uint32_t)wslot[bin] : lane;
+    // relaxed atomics, not plain accesses: the slot is read back to see ANOTHER lane's store (the compiler forwards this lane's own
+    // store to a plain load -- every lane then is its own group and the order inside a bin is left to the order in which the LDS
+    // happens to apply the lanes' cursor atomics), and the mask after the other lanes' ORs
+    if (valid) __hip_atomic_store(&wslot[bin], (uint8_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t name = valid ? (uint32_t)__hip_atomic_load(&wslot[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : lane;
     if (valid) atomicOr(&wpm[name], mybit);
-    const uint64_t peers = valid ? (uint64_t)wpm[name] : 0ull;
-    if (valid && name == lane) wpm[name] = 0ull;                       // for the next step (after every lane's read: in order)
+    const uint64_t peers = valid ? (uint64_t)__hip_atomic_load(&wpm[name], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+    if (valid && name == lane) __hip_atomic_store(&wpm[name], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // for the next step (after every lane's read: in order)
     const uint32_t rank = (uint32_t)__popcll(peers & lt);
     uint32_t old = 0;
     if (valid && rank == 0) old = atomicAdd(&wcur[bin], (uint32_t)__popcll(peers));
