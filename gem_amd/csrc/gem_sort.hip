@@ -249,8 +249,9 @@ __device__ __forceinline__ uint32_t wave_rank_step(bool valid, uint32_t bin, uin
     return old + rank;
 }
 
-// words of LDS the ranking phase of k_sort_scatter needs: per wave a cursor per bin, a name byte per bin, 64 masks
-__host__ __device__ constexpr size_t rank_words(int nw, int bins) { return (size_t)nw * bins + (size_t)nw * ((bins + 3) / 4) + (size_t)nw * 128; }
+// words of LDS the ranking phase of k_sort_scatter needs: per wave a cursor per bin, a name byte per bin (+ 64), 64 masks
+__host__ __device__ constexpr size_t slot_words(int bins) { return (size_t)((bins + 3) / 4) + 16; }   // name bytes of the bins + 64 spare ones (lanes without a record)
+__host__ __device__ constexpr size_t rank_words(int nw, int bins) { return (size_t)nw * bins + (size_t)nw * slot_words(bins) + (size_t)nw * 128; }
 
 // ------------------------------------------------------------------------------------------
 // count + scatter of one digit (both passes), chunks of kSortChunk records.  Pass 1 reads the input-ordered records of
@@ -291,8 +292,8 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void k_sort_scatter(PassAr
     uint32_t* scratch = delta + bins;                                  // [16]
     uint32_t* region = scratch + 16;                                   // per-wave cursors, then (aliased) the staged records
     uint32_t* wcnt = region;                                           // [NW][bins]
-    uint8_t* wslots = reinterpret_cast<uint8_t*>(region + NW * bins);   // [NW][4 * ((bins + 3) / 4)] bytes
-    unsigned long long* wpms = reinterpret_cast<unsigned long long*>(region + NW * bins + NW * ((bins + 3) / 4));   // [NW][64]
+    uint8_t* wslots = reinterpret_cast<uint8_t*>(region + NW * bins);   // [NW][4 * slot_words(bins)] bytes
+    unsigned long long* wpms = reinterpret_cast<unsigned long long*>(region + NW * bins + NW * slot_words(bins));   // [NW][64]
     uint2* st_hv = reinterpret_cast<uint2*>(region);                   // [CH]
     uint32_t* st_key = region + 2 * CH;                                // [CH]
     uint32_t* st_src = region + 3 * CH;                                // [CH] (ATTR)
@@ -317,11 +318,35 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void k_sort_scatter(PassAr
     // ---- 1. stable rank inside the wave's share, per-wave counts
     {
         uint32_t* wcur = wcnt + w * bins;
-        uint8_t* wslot = wslots + (size_t)w * 4 * ((bins + 3) / 4);
+        uint8_t* wslot = wslots + (size_t)w * 4 * slot_words(bins);
+        const uint32_t spare = 4u * (uint32_t)((bins + 3) / 4) + (uint32_t)lane;     // the slot of a lane without a record: its own
         unsigned long long* wpm = wpms + w * 64;
         const unsigned long long mybit = 1ull << lane;
+        // The K steps of wave_rank_step (see there), phase by phase instead of step by step: a wave's LDS operations execute in
+        // order, so step k + 1 may store its names behind step k's read-back without waiting for it -- three LDS round trips per
+        // chunk instead of three per step.
+        uint32_t bin[K], name[K]; uint64_t peers[K]; bool valid[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) rk[k] = wave_rank_step(key[k] != kKeyInvalid, (key[k] >> a.shift) & a.mask, wcur, wslot, wpm, lt, mybit);
+        for (int k = 0; k < K; ++k) {
+            valid[k] = key[k] != kKeyInvalid; bin[k] = (key[k] >> a.shift) & a.mask;
+            uint8_t* slot = wslot + (valid[k] ? bin[k] : spare);       // no branch: the eight round trips overlap
+            __hip_atomic_store(slot, (uint8_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            name[k] = (uint32_t)__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (valid[k]) atomicOr(&wpm[name[k]], mybit);
+            peers[k] = valid[k] ? (uint64_t)__hip_atomic_load(&wpm[name[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+            if (valid[k] && name[k] == (uint32_t)lane) __hip_atomic_store(&wpm[name[k]], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t rank = (uint32_t)__popcll(peers[k] & lt);
+            uint32_t old = 0;
+            if (valid[k] && rank == 0) old = atomicAdd(&wcur[bin[k]], (uint32_t)__popcll(peers[k]));
+            old = (uint32_t)__shfl((int)old, valid[k] ? __ffsll((unsigned long long)peers[k]) - 1 : lane, 64);
+            rk[k] = old + rank;
+        }
     }
     __syncthreads();
     // ---- 2. per bin: the waves in order (exclusive prefix), the chunk's local base, the way from local to global positions
