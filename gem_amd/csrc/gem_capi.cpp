@@ -73,6 +73,7 @@ struct gem_handle {
     struct Deferred { bool valid = false; FuseArgs fa{}; int ts = 0, attr = 0; } deferred;
     bool defer = true;
     hipStream_t bin_stream = nullptr;
+    hipStream_t tab_stream = nullptr;   // uploads a batched pass's tables while the binning stream is still busy with the pass before
     hipEvent_t switch_done = nullptr;   // recorded on `stream` when a pass moves its binning to `bin_stream` after passes that did not
     bool main_reads_pb = false;         // work enqueued on `stream` since the last such switch reads the pass buffers
     bool overlap = true;
@@ -138,6 +139,7 @@ int ensure(gem_handle* h, Arena& a, size_t bytes)
     // arenas may still be in use by enqueued work
     GEM_HIP(h, hipStreamSynchronize(h->stream));
     if (h->bin_stream) GEM_HIP(h, hipStreamSynchronize(h->bin_stream));
+    if (h->tab_stream) GEM_HIP(h, hipStreamSynchronize(h->tab_stream));
     if (a.p) GEM_HIP(h, hipFree(a.p));
     a.p = nullptr; a.cap = 0;
     size_t want = bytes + bytes / 4 + 4096;
@@ -384,8 +386,17 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
         memcpy(host + o_chunk0, chunk0.data(), sizeof(int) * (in.n_sweeps + 1));
         memcpy(host + o_first, in.offsets, sizeof(long long) * (in.n_sweeps + 1));
         if (in.var_updates) memcpy(host + o_var, in.var_updates, sizeof(float) * in.n_sweeps);
-        GEM_HIP(h, hipMemcpyAsync(pb.tables.p, host, total, hipMemcpyHostToDevice, sbin));
-        GEM_HIP(h, hipEventRecord(pb.tables_done, sbin)); pb.tables_recorded = true;
+        // on a stream of its own when the passes overlap: the upload (a 5 us blit + two kernel boundaries) then runs while the
+        // binning stream is still sorting the pass before, instead of at the head of this pass's chain (the buffer's last
+        // readers -- the pass before the previous one -- are done: fuse_done above)
+        hipStream_t stab = sbin;
+        if (overlap) {
+            if (!h->tab_stream && hipStreamCreateWithFlags(&h->tab_stream, hipStreamNonBlocking) != hipSuccess) { h->tab_stream = nullptr; (void)hipGetLastError(); }
+            if (h->tab_stream) stab = h->tab_stream;
+        }
+        GEM_HIP(h, hipMemcpyAsync(pb.tables.p, host, total, hipMemcpyHostToDevice, stab));
+        GEM_HIP(h, hipEventRecord(pb.tables_done, stab)); pb.tables_recorded = true;
+        if (stab != sbin) GEM_HIP(h, hipStreamWaitEvent(sbin, pb.tables_done, 0));
         unsigned char* d = static_cast<unsigned char*>(pb.tables.p);
         sa.frames = reinterpret_cast<const FrameConst*>(d + o_frames);
         sa.sweep_chunk0 = reinterpret_cast<const int*>(d + o_chunk0);
@@ -801,6 +812,7 @@ void gem_destroy(gem_handle* h)
     hipSetDevice(h->device);
     if (h->stream) { flush_deferred(h); hipStreamSynchronize(h->stream); }
     if (h->bin_stream) hipStreamSynchronize(h->bin_stream);
+    if (h->tab_stream) { hipStreamSynchronize(h->tab_stream); hipStreamDestroy(h->tab_stream); }
     if (h->comm) ncclCommDestroy(h->comm);
     fold_events(h);
     for (auto& ep : h->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
