@@ -155,6 +155,11 @@ void fill_frame(const gem_handle* h, const gem_frame_params* p, FrameConst& f)
     if (p) {
         for (int i = 0; i < 12; ++i) f.T[i] = p->T[i];
         f.lower = p->lower; f.upper = p->upper;
+        // GPU:397 compares (double)h with the double bounds.  For a float h, (double)h > lower  <=>  h > the largest float <= lower
+        // (no float lies strictly between that one and its successor, which is above `lower`), and (double)h < upper  <=>
+        // h < the smallest float >= upper; NaN bounds stay NaN (never inside).  The kernels compare floats.
+        f.lower_f = (float)p->lower; if ((double)f.lower_f > p->lower) f.lower_f = nextafterf(f.lower_f, -INFINITY);
+        f.upper_f = (float)p->upper; if ((double)f.upper_f < p->upper) f.upper_f = nextafterf(f.upper_f, INFINITY);
         for (int i = 0; i < 8; ++i) f.sp[i] = p->sensor_params[i];
         for (int i = 0; i < 3; ++i) { f.Js[i] = p->sensor_jacobian[i]; f.P[i] = p->P_mul_C_BM_T[i]; }
         for (int i = 0; i < 9; ++i) { f.Q[i] = p->rotation_variance[i]; f.C[i] = p->C_SB_T[i]; f.Bs[i] = p->B_r_BS_skew[i]; }

@@ -23,6 +23,7 @@ constexpr int   kInvalidTile    = 0x7fffffff;
 struct FrameConst {
     float  T[12];            // rows 0..2 of the sensor->map transform
     double lower, upper;     // GPU:50-51 are doubles
+    float  lower_f, upper_f; // the same window as float bounds: h > lower_f <=> (double)h > lower, h < upper_f <=> (double)h < upper (fill_frame)
     double sp[8];            // sensor-model parameters
     float  Js[3];            // sensorJacobian
     float  Q[9];             // rotationVariance
@@ -190,7 +191,7 @@ __device__ __forceinline__ Projected project_point(const FrameConst& f, float x,
     bool flag = false;
     if (f.filter_on)                                                               // GPU:393
         flag = (x > -f.fbx && x < f.fbx && y > -f.fby && y < f.fby) || (y > -f.fband && y < f.fband) || (y > f.fplane);
-    if (((double)h > f.lower && (double)h < f.upper) && !flag) {                   // GPU:397
+    if ((h > f.lower_f && h < f.upper_f) && !flag) {                               // GPU:397, doubles there: see FrameConst
         r.xt = f.T[0] * x + f.T[1] * y + f.T[2] * z + f.T[3];                      // GPU:399
         r.yt = f.T[4] * x + f.T[5] * y + f.T[6] * z + f.T[7];                      // GPU:400
         r.h = h;

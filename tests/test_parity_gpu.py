@@ -68,6 +68,39 @@ def test_process_points_nonfinite_inputs(oracle_mod):
     assert np.array_equal(g["index"], o["index"]) and np.all(g["index"] == -1)
 
 
+@pytest.mark.parametrize("bounds", [(0.1, 0.30000000000000004), (-0.7, 0.1 + 1e-9), (1e-45, 1e300), (-1e300, -1e-320), (-np.inf, 0.2),
+                                    (0.25, 0.5), (np.nan, 1.0), (0.0, np.nan), (3.5e38, np.inf)])
+def test_height_window_edges(oracle_mod, bounds):
+    """GPU:397 compares (double)h with DOUBLE bounds; the kernels compare h with float bounds chosen on the host so that the
+    decision is the same (gem_capi.cpp fill_frame): heights on either side of each bound, one float apart, on all three paths"""
+    lo, hi = bounds
+    gpu, ref = make_pair(oracle_mod, 64, 0.1)
+    f = synth._frame_for(np.eye(4), SensorModel.velodyne()); f.lower, f.upper = lo, hi
+    hs = []
+    for b in (lo, hi):
+        if np.isnan(b):
+            continue
+        with np.errstate(over="ignore"):
+            c = F32(b)
+        for k in range(-3, 4):
+            v = c
+            for _ in range(abs(k)):
+                v = np.nextafter(v, F32(np.inf if k > 0 else -np.inf), dtype=F32)
+            hs.append(v)
+    hs += [F32(0.0), F32(-0.0), F32(0.2), F32(np.inf), F32(-np.inf), F32(np.nan), F32(3.4e38), F32(-3.4e38), F32(1e-45)]
+    z = np.array(hs, F32); x = np.full(z.shape, 0.05, F32); y = np.full(z.shape, -0.05, F32)
+    g = gpu.process_points(f, x, y, z); o = ref.process_points(f, x, y, z)
+    assert np.array_equal(g["index"], o["index"]) and np.array_equal(g["height"], o["height"], equal_nan=True)
+    keep = np.isnan(z) | (np.abs(z) < 1e3)          # (heights of 1e38 in one cell fuse to NaN on both sides: nothing to compare)
+    c = np.stack([x, y, z, np.ones_like(z)], 1)[keep]
+    gpu.add(f, c); ref.add(f, c)
+    assert_maps_match(gpu, ref)
+    import torch
+    gpu.add_batch([f, f], torch.from_numpy(np.concatenate([c, c])).cuda(), np.array([0, len(c), 2 * len(c)]), None)
+    ref.add(f, c); ref.add(f, c)
+    assert_maps_match(gpu, ref)
+
+
 @pytest.mark.parametrize("model", ["structured_light", "stereo", "perfect"])
 def test_other_noise_models(oracle_mod, model):
     gpu, ref = make_pair(oracle_mod, 400, 0.025)
