@@ -35,11 +35,14 @@ struct EventPair { hipEvent_t a, b; int kind; };
 
 } // namespace
 
+struct StreamSet { hipStream_t s[4] = {nullptr, nullptr, nullptr, nullptr}; };   // own, bin, bin2, tab (see acquire_streams)
+
 struct gem_handle {
     std::mutex  mu;
     std::string err;
     int         device = 0;
     hipStream_t own_stream = nullptr;
+    StreamSet streams;                  // own, bin, bin2, tab as they were taken from the pool (given back together)
     hipStream_t stream = nullptr;
     gem_map_config cfg{};
     int   L = 0, cells = 0;
@@ -65,14 +68,18 @@ struct gem_handle {
         hipEvent_t bin_done = nullptr, fuse_done = nullptr;
         bool fuse_recorded = false;
         uint32_t epoch = 0;            // touched-flag stamp of the last pass (0 = the flag table holds no live stamps)
-    } pb[2];
-    unsigned pass = 0;
+    } pb[4];            // the tile pipeline alternates between the first two; the sorted pipeline's overlapped passes rotate through all four
+    unsigned pass = 0, sort_pass = 0;
+    int sort_streams = 2;               // binning streams the overlapped passes of the sorted pipeline alternate between (debug knob)
+    bool trace = false;                 // debug knob: one line on stderr per pass of the sorted pipeline (which streams / buffers it took)
+    int sort_ring = 2;                  // buffer sets they rotate through (debug knob; 2..4: measured equal on C4, two best on C5)
     // A stream of single device-resident sweeps runs as ONE launch per frame: k_frame fuses the previous
     // frame's records next to the binning of the new cloud.  The fuse of the newest frame is therefore
     // deferred until the next gem_add_device -- or until anything observes or modifies the map.
     struct Deferred { bool valid = false; FuseArgs fa{}; int ts = 0, attr = 0; } deferred;
     bool defer = true;
     hipStream_t bin_stream = nullptr;
+    hipStream_t bin_stream2 = nullptr;  // the sorted pipeline sorts consecutive big passes on two streams (see run_sort_pipeline)
     hipStream_t tab_stream = nullptr;   // uploads a batched pass's tables while the binning stream is still busy with the pass before
     hipEvent_t switch_done = nullptr;   // recorded on `stream` when a pass moves its binning to `bin_stream` after passes that did not
     bool main_reads_pb = false;         // work enqueued on `stream` since the last such switch reads the pass buffers
@@ -82,7 +89,6 @@ struct gem_handle {
     long long sort_min_points = 200000, sort_min_points_batch = 1000000;     // single cloud / batch of sweeps
     bool walk_permute = true;           // k_fuse_walk: blocks take the tile rows centre-first
     int  sort_passes = 0;               // 0 = by map size (two digits up to 2^20 cells, else three); 2 / 3 force it
-    bool bin_priority = false;          // create the second stream with high priority (measured: no effect on C4 / C5)
     int dbg_sweep = 0;                  // debug stamps of the dense path: which sweep (GEM_DBG_SWEEP)
     bool track_lowest = false;          // also maintain map_lowest in the fuse kernels (gem_set_lowest_tracking, for gem_raytracing)
     unsigned dense_min = 2048;          // records of one sweep in one 16x16 tile above which the tile is counting-sorted (k_fuse_list, dense path)
@@ -139,6 +145,7 @@ int ensure(gem_handle* h, Arena& a, size_t bytes)
     // arenas may still be in use by enqueued work
     GEM_HIP(h, hipStreamSynchronize(h->stream));
     if (h->bin_stream) GEM_HIP(h, hipStreamSynchronize(h->bin_stream));
+    if (h->bin_stream2) GEM_HIP(h, hipStreamSynchronize(h->bin_stream2));
     if (h->tab_stream) GEM_HIP(h, hipStreamSynchronize(h->tab_stream));
     if (a.p) GEM_HIP(h, hipFree(a.p));
     a.p = nullptr; a.cap = 0;
@@ -261,14 +268,41 @@ constexpr int       kUnit = 64;                      // points per unit (one wav
 constexpr long long kSweepPoints = 2048ll * kUnit;   // a single cloud longer than this is processed as a batch of sweeps of this size
 
 // The second stream carries the map-independent half of a big pass (projection / binning / sorting) next to the fusion of the
-// pass before.  High priority: its kernels are the bandwidth-bound ones, the fusion is a few long chains -- when both are
-// resident the sort should get the slots that free up (debug knob "bin_priority": 0 = default priority).
-static hipError_t create_bin_stream(gem_handle* h)
+// pass before.  (A high-priority stream for it was measured: no effect.)
+// Streams live as long as the process and pass from handle to handle, four at a time, each keeping its role: the runtime maps
+// every stream onto one of a few hardware queues when it is created, streams that share a queue run one after the other, and
+// which queues overlap well with which is a matter of their creation order.  Measured on C4 with all 24 assignments of four
+// consecutively created streams s0..s3 to (own, bin, bin2, tab) (`tools/dbg/roles.py`): 125 us per batch when `own` and one
+// binning stream are among {s0, s1} and the other binning stream among {s2, s3}; 140 us for the other split assignments; 185 us
+// with `own` among {s2, s3} and both binning streams among {s0, s1}.  And a handle whose streams were created after another
+// handle's had been DESTROYED found its binning streams on the queue of its own stream: no overlap at all (C5 371 -> 391 us,
+// C4 135 -> 185).  Hence: sets of four created together, roles by creation order, never destroyed.
+static std::mutex g_stream_pool_mu;
+static std::vector<StreamSet> g_stream_pool[64];
+
+static hipError_t acquire_streams(int device, StreamSet& out)
 {
-    int lo = 0, hi = 0;
-    if (h->bin_priority && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo)
-        return hipStreamCreateWithPriority(&h->bin_stream, hipStreamNonBlocking, hi);
-    return hipStreamCreateWithFlags(&h->bin_stream, hipStreamNonBlocking);
+    {
+        std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+        if (device >= 0 && device < 64 && !g_stream_pool[device].empty()) {
+            out = g_stream_pool[device].back(); g_stream_pool[device].pop_back();
+            return hipSuccess;
+        }
+    }
+    for (int i = 0; i < 4; ++i) {
+        const hipError_t e = hipStreamCreateWithFlags(&out.s[i], hipStreamNonBlocking);
+        if (e != hipSuccess) { for (int j = 0; j < i; ++j) hipStreamDestroy(out.s[j]); out = StreamSet{}; return e; }
+    }
+    return hipSuccess;
+}
+
+static void release_streams(int device, const StreamSet& set)
+{
+    if (!set.s[0]) return;
+    for (hipStream_t st : set.s) hipStreamSynchronize(st);
+    if (device < 0 || device >= 64) { for (hipStream_t st : set.s) hipStreamDestroy(st); return; }
+    std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+    g_stream_pool[device].push_back(set);
 }
 
 static int ceil_log2(int v) { int b = 0; while ((1 << b) < v) ++b; return b; }
@@ -324,23 +358,31 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     h->T = T;
 
     bool overlap = h->overlap && in.n >= h->overlap_min_points && h->stream == h->own_stream && !h->counting && !shard;
-    if (overlap && !h->bin_stream && create_bin_stream(h) != hipSuccess) {
-        h->bin_stream = nullptr; overlap = false; (void)hipGetLastError();
-    }
     { const int rcd = flush_deferred(h); if (rcd) return rcd; }
     // a shard bins into the WHOLE map (its records go to the strip owners); the frames carry the strip
     const int keep_row0 = h->row0, keep_row1 = h->row1;
     struct RestoreRows { gem_handle* h; int r0, r1; ~RestoreRows() { h->row0 = r0; h->row1 = r1; } } restore{h, keep_row0, keep_row1};
     if (shard) { h->row0 = 0; h->row1 = h->L; }
-    gem_handle::PassBuffers& pb = h->pb[overlap ? (h->pass++ & 1u) : 0u];
-    hipStream_t sbin = overlap ? h->bin_stream : h->stream;
+    // Consecutive overlapped passes sort on TWO binning streams in turn: the sort of a pass is a chain of six dependent kernels
+    // that keep the chip's VALUs busy less than half of the time, so the tail of one pass's chain runs next
+    // to the head of the next one's -- and next to the walk of the pass before, which alone has to follow the walk before it
+    // (C4 150 -> 134 us per batch, C5 400 -> 375).
+    const unsigned seq = overlap ? h->sort_pass++ : 0u;
+    const unsigned slot = overlap ? seq % (unsigned)h->sort_ring : 0u;
+    gem_handle::PassBuffers& pb = h->pb[slot];
+    hipStream_t sbin = overlap ? (((seq & 1u) && h->sort_streams > 1 && h->bin_stream2) ? h->bin_stream2 : h->bin_stream) : h->stream;
     if (overlap && h->main_reads_pb) {                   // see run_pipeline
         GEM_HIP(h, hipEventRecord(h->switch_done, h->stream));
         GEM_HIP(h, hipStreamWaitEvent(h->bin_stream, h->switch_done, 0));
+        if (h->bin_stream2) GEM_HIP(h, hipStreamWaitEvent(h->bin_stream2, h->switch_done, 0));
         h->main_reads_pb = false;
         for (auto& b : h->pb) b.fuse_recorded = false;
     }
     if (!overlap) h->main_reads_pb = true;
+    if (h->trace)
+        fprintf(stderr, "[gem] sorted pass: n=%lld sweeps=%d overlap=%d (knob %d, min %lld, own stream %d, counting %d, shard %d) slot=%u stream=%s\n",
+                (long long)in.n, in.n_sweeps, (int)overlap, (int)h->overlap, (long long)h->overlap_min_points, (int)(h->stream == h->own_stream),
+                (int)h->counting, (int)(shard != nullptr), slot, sbin == h->stream ? "main" : (sbin == h->bin_stream ? "bin" : "bin2"));
 
     const long long nc2max = (in.n + sh1.chunk - 1) / sh1.chunk;
     const size_t N = (size_t)in.n;
@@ -395,10 +437,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
         // binning stream is still sorting the pass before, instead of at the head of this pass's chain (the buffer's last
         // readers -- the pass before the previous one -- are done: fuse_done above)
         hipStream_t stab = sbin;
-        if (overlap) {
-            if (!h->tab_stream && hipStreamCreateWithFlags(&h->tab_stream, hipStreamNonBlocking) != hipSuccess) { h->tab_stream = nullptr; (void)hipGetLastError(); }
-            if (h->tab_stream) stab = h->tab_stream;
-        }
+        if (overlap && h->tab_stream) stab = h->tab_stream;
         GEM_HIP(h, hipMemcpyAsync(pb.tables.p, host, total, hipMemcpyHostToDevice, stab));
         GEM_HIP(h, hipEventRecord(pb.tables_done, stab)); pb.tables_recorded = true;
         if (stab != sbin) GEM_HIP(h, hipStreamWaitEvent(sbin, pb.tables_done, 0));
@@ -592,9 +631,6 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     // The cross-stream event pair costs ~3 us per pass (measured), so it only pays for big passes
     // (batches / aggregated clouds: C4 379 -> 313 us); single sweeps stay on one stream.
     bool overlap = h->overlap && in.n >= h->overlap_min_points && h->stream == h->own_stream && !h->counting && !h->dbg_on;
-    if (overlap && !h->bin_stream && create_bin_stream(h) != hipSuccess) {
-        h->bin_stream = nullptr; overlap = false; (void)hipGetLastError();
-    }
     // one launch per frame for a stream of single sweeps (k_frame): needs the other half of the double buffer
     const bool defer = h->defer && in.device_input && in.src == 0 && !batched && attr == 0 && ts == 4 && !overlap &&
                        !h->counting && !h->dbg_on;
@@ -607,6 +643,7 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
         // stream waits for everything enqueued on the handle's stream so far (one event at the switch, none per frame).
         GEM_HIP(h, hipEventRecord(h->switch_done, h->stream));
         GEM_HIP(h, hipStreamWaitEvent(h->bin_stream, h->switch_done, 0));
+        if (h->bin_stream2) GEM_HIP(h, hipStreamWaitEvent(h->bin_stream2, h->switch_done, 0));
         h->main_reads_pb = false;
         for (auto& b : h->pb) b.fuse_recorded = false;      // covered by the wait above
     }
@@ -777,13 +814,13 @@ int gem_create(const gem_map_config* cfg, gem_handle** out)
     h->ts = 0;                                  // 0: chosen per pass (run_pipeline)
 
     auto bail = [&](const char* what, hipError_t err) { int rc = fail(nullptr, GEM_ERR_HIP, what, err); gem_destroy(h); return rc; };
-    if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = acquire_streams(dev, h->streams)) != hipSuccess) return bail("hipStreamCreate", e);
+    h->own_stream = h->streams.s[0]; h->bin_stream = h->streams.s[1]; h->bin_stream2 = h->streams.s[2]; h->tab_stream = h->streams.s[3];
     h->stream = h->own_stream;
     if ((e = hipEventCreateWithFlags(&h->copy_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&h->switch_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-    // (the second stream, for the bin / fuse overlap of big passes, is created by the first pass that is big enough: ROCm maps
-    //  streams onto four hardware queues, and streams that share one serialise -- a handle that only ever fuses single sweeps
-    //  should not take a queue from its neighbours.  Measured: a batched C4 call 263 -> 345 us with a second handle alive.)
+    // (the handle's four streams come from the process-wide pool as a set, see acquire_streams: ROCm maps streams onto a few
+    //  hardware queues, and streams that share one serialise)
     for (auto& b : h->pb) {
         if ((e = hipEventCreateWithFlags(&b.bin_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&b.fuse_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
@@ -817,7 +854,8 @@ void gem_destroy(gem_handle* h)
     hipSetDevice(h->device);
     if (h->stream) { flush_deferred(h); hipStreamSynchronize(h->stream); }
     if (h->bin_stream) hipStreamSynchronize(h->bin_stream);
-    if (h->tab_stream) { hipStreamSynchronize(h->tab_stream); hipStreamDestroy(h->tab_stream); }
+    if (h->bin_stream2) hipStreamSynchronize(h->bin_stream2);
+    if (h->tab_stream) hipStreamSynchronize(h->tab_stream);
     if (h->comm) ncclCommDestroy(h->comm);
     fold_events(h);
     for (auto& ep : h->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
@@ -833,10 +871,9 @@ void gem_destroy(gem_handle* h)
         if (b.bin_done) hipEventDestroy(b.bin_done);
         if (b.fuse_done) hipEventDestroy(b.fuse_done);
     }
-    if (h->bin_stream) hipStreamDestroy(h->bin_stream);
     if (h->copy_done) hipEventDestroy(h->copy_done);
     if (h->switch_done) hipEventDestroy(h->switch_done);
-    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    release_streams(h->device, h->streams);            // back to the pool, as a set
     delete h;
 }
 
@@ -848,6 +885,7 @@ int gem_set_stream(gem_handle* h, void* hip_stream)
     { const int rcd = flush_deferred(h); if (rcd) return rcd; }
     GEM_HIP(h, hipStreamSynchronize(h->stream));
     if (h->bin_stream) GEM_HIP(h, hipStreamSynchronize(h->bin_stream));
+    if (h->bin_stream2) GEM_HIP(h, hipStreamSynchronize(h->bin_stream2));
     h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
     return GEM_OK;
 }
@@ -862,6 +900,7 @@ int gem_wait_event(gem_handle* h, void* hip_event)
     hipEvent_t ev = static_cast<hipEvent_t>(hip_event);
     GEM_HIP(h, hipStreamWaitEvent(h->stream, ev, 0));
     if (h->bin_stream) GEM_HIP(h, hipStreamWaitEvent(h->bin_stream, ev, 0));
+    if (h->bin_stream2) GEM_HIP(h, hipStreamWaitEvent(h->bin_stream2, ev, 0));
     // (a binning stream created later starts behind an event recorded on the handle's stream: see main_reads_pb)
     h->main_reads_pb = true;
     return GEM_OK;
@@ -1441,7 +1480,21 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "sort_path")          h->sort_path = value != 0;
     else if (k == "sort_min_points")    { h->sort_min_points = value; h->sort_min_points_batch = value; }
     else if (k == "walk_permute")       h->walk_permute = value != 0;
-    else if (k == "bin_priority")       h->bin_priority = value != 0;
+    else if (k == "trace")              h->trace = value != 0;
+    else if (k == "stream_roles") {
+        // experiment: permute the roles of the handle's four streams; the decimal digits of `value` name, for own / bin / bin2 /
+        // tab, which of the CURRENT (own, bin, bin2, tab) takes the role (e.g. 3210 reverses them)
+        if (h->stream != h->own_stream) return fail(h, GEM_ERR_INVALID, "stream_roles: caller-provided stream in use");
+        for (hipStream_t st : {h->own_stream, h->bin_stream, h->bin_stream2, h->tab_stream}) hipStreamSynchronize(st);
+        const hipStream_t cur[4] = {h->own_stream, h->bin_stream, h->bin_stream2, h->tab_stream};
+        const int d[4] = {(int)(value / 1000 % 10), (int)(value / 100 % 10), (int)(value / 10 % 10), (int)(value % 10)};
+        bool seen[4] = {false, false, false, false};
+        for (int i = 0; i < 4; ++i) { if (d[i] < 0 || d[i] > 3 || seen[d[i]]) return fail(h, GEM_ERR_INVALID, "stream_roles: not a permutation of 0123"); seen[d[i]] = true; }
+        h->own_stream = cur[d[0]]; h->bin_stream = cur[d[1]]; h->bin_stream2 = cur[d[2]]; h->tab_stream = cur[d[3]];
+        h->stream = h->own_stream;
+    }
+    else if (k == "sort_ring")          { if (value < 2 || value > 4) return fail(h, GEM_ERR_INVALID, "sort_ring: 2..4"); h->sort_ring = (int)value; }
+    else if (k == "sort_streams")       { if (value != 1 && value != 2) return fail(h, GEM_ERR_INVALID, "sort_streams: 1 or 2"); h->sort_streams = (int)value; }
     else if (k == "sort_passes")        { if (value != 0 && value != 2 && value != 3) return fail(h, GEM_ERR_INVALID, "sort_passes: 0, 2 or 3"); h->sort_passes = (int)value; }
     else return fail(h, GEM_ERR_INVALID, "gem_debug_set: unknown key");
     return GEM_OK;

@@ -111,7 +111,7 @@ __device__ __forceinline__ ChunkRange chunk_range(const int* __restrict__ sweep_
 // (256-thread workgroups whatever the chunk size: the projection needs ~100 VGPRs, and five light workgroups per CU hide its
 //  load latency better than one of 1024 threads)
 template <int SRC>
-__global__ __launch_bounds__(256) void k_sort_project(SortArgs a)
+__global__ __launch_bounds__(256, (SRC == 2 ? 4 : 1)) void k_sort_project(SortArgs a)
 {
     constexpr int NT = 256, CH = kSortChunk, K = CH / NT;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_sort[];

@@ -156,7 +156,7 @@ def main():
         pb = m.pack_batch(wl.frames, off, wl.var_updates)
         def f():
             m.add_batch(pb, cat)
-        wall, ub, uf = timed(m, f, max(args.reps // 5, 5))
+        wall, ub, uf = timed(m, f, max(args.reps, 20), warm=6)
         report("C4 batch of 32 sweeps + var updates", cat.shape[0], touched(m, f), 32, wl.length, wall, ub, uf)
         m.close()
 
@@ -168,7 +168,7 @@ def main():
         pb = m.pack_batch(wl.frames, off, None)
         def f():
             m.add_batch(pb, cat)
-        wall, ub, uf = timed(m, f, max(args.reps // 10, 3), warm=3)
+        wall, ub, uf = timed(m, f, max(args.reps // 2, 20), warm=6)
         report(f"C5 aggregated {cat.shape[0]} pts -> {wl.length}^2 (one GPU)", cat.shape[0], touched(m, f), 0, wl.length, wall, ub, uf)
         m.close()
 
