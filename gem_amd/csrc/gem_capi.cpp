@@ -84,7 +84,8 @@ struct gem_handle {
     hipEvent_t switch_done = nullptr;   // recorded on `stream` when a pass moves its binning to `bin_stream` after passes that did not
     bool main_reads_pb = false;         // work enqueued on `stream` since the last such switch reads the pass buffers
     bool overlap = true;
-    long long overlap_min_points = 1000000;
+    long long overlap_min_points = 1000000;        // tile pipeline: a cross-stream event pair costs 3 us, the second stream only pays for big passes
+    long long sort_overlap_min_points = 100000;    // sorted pipeline: its walk is a few long chains on a mostly idle chip; the next pass's sort fits beside it (depth image 120 -> 83 us)
     bool sort_path = true;              // passes of at least sort_min_points points run the sorted pipeline (gem_sort.hip)
     long long sort_min_points = 200000, sort_min_points_batch = 1000000;     // single cloud / batch of sweeps
     bool walk_permute = true;           // k_fuse_walk: blocks take the tile rows centre-first
@@ -357,7 +358,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     const int T = geo.T;
     h->T = T;
 
-    bool overlap = h->overlap && in.n >= h->overlap_min_points && h->stream == h->own_stream && !h->counting && !shard;
+    bool overlap = h->overlap && in.n >= std::min(h->overlap_min_points, h->sort_overlap_min_points) && h->stream == h->own_stream && !h->counting && !shard;
     { const int rcd = flush_deferred(h); if (rcd) return rcd; }
     // a shard bins into the WHOLE map (its records go to the strip owners); the frames carry the strip
     const int keep_row0 = h->row0, keep_row1 = h->row1;
@@ -381,7 +382,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     if (!overlap) h->main_reads_pb = true;
     if (h->trace)
         fprintf(stderr, "[gem] sorted pass: n=%lld sweeps=%d overlap=%d (knob %d, min %lld, own stream %d, counting %d, shard %d) slot=%u stream=%s\n",
-                (long long)in.n, in.n_sweeps, (int)overlap, (int)h->overlap, (long long)h->overlap_min_points, (int)(h->stream == h->own_stream),
+                (long long)in.n, in.n_sweeps, (int)overlap, (int)h->overlap, (long long)std::min(h->overlap_min_points, h->sort_overlap_min_points), (int)(h->stream == h->own_stream),
                 (int)h->counting, (int)(shard != nullptr), slot, sbin == h->stream ? "main" : (sbin == h->bin_stream ? "bin" : "bin2"));
 
     const long long nc2max = (in.n + sh1.chunk - 1) / sh1.chunk;
@@ -1476,7 +1477,7 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "dense_min")          h->dense_min = (unsigned)value;
     else if (k == "dbg_sweep")          h->dbg_sweep = (int)value;
     else if (k == "overlap")            h->overlap = value != 0;
-    else if (k == "overlap_min_points") h->overlap_min_points = value;
+    else if (k == "overlap_min_points") { h->overlap_min_points = value; h->sort_overlap_min_points = value; }
     else if (k == "sort_path")          h->sort_path = value != 0;
     else if (k == "sort_min_points")    { h->sort_min_points = value; h->sort_min_points_batch = value; }
     else if (k == "walk_permute")       h->walk_permute = value != 0;
