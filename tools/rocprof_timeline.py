@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel timeline of a rocprofv3 --kernel-trace run of tools/bench_configs.py: for every configuration (split at the long
-idle gaps between them), two passes from the middle of its timed loop: kernel, stream / queue, start relative to the pass's first kernel, duration.
+idle gaps between them), three passes of its timed loop: kernel, stream / queue, start relative to the pass's first kernel, duration.
 Shows what overlaps with what when the product runs its two streams.
 
     tools/rocprof_timeline.py TRACE_DIR > profiles/rNN_xxx_timeline.txt
@@ -33,17 +33,17 @@ def main():
         walks = [i for i, r in enumerate(sec) if r[2].startswith("gem::k_fuse_walk") or r[2].startswith("gem::k_fuse_list") or r[2].startswith("gem::k_frame")]
         if len(walks) < 3:
             continue
-        # two passes from the MIDDLE of the section (the steady timed loop; the section ends with the instrumented passes):
-        # from the first kernel after a fuse kernel's start to the end of the second fuse kernel after it
-        mid = len(walks) // 2
-        a, b = walks[mid - 2] + 1, walks[mid]
+        # three passes from the first QUARTER of the section (the steady timed loop; its second half are the instrumented passes,
+        # which do not overlap): from the first kernel after a fuse kernel's start to the end of the third fuse kernel after it
+        mid = max(len(walks) // 4, 3)
+        a, b = walks[mid - 3] + 1, walks[mid]
         part = sec[a:b + 1]
         t0 = part[0][0]
-        print(f"\n## section {si}: {len(sec)} dispatches; the last two passes (us relative to the first kernel shown)")
+        print(f"\n## section {si}: {len(sec)} dispatches; three passes of the timed loop (us relative to the first kernel shown)")
         print(f"{'start':>9s} {'dur':>8s} {'queue':>6s} {'grid':>9s} {'wg':>5s}  kernel")
         for s, e, k, q, g, w in part:
             print(f"{(s - t0) / 1e3:9.2f} {(e - s) / 1e3:8.2f} {q:>6s} {g:>9s} {w:>5s}  {k[:90]}")
-        print(f"# span {(part[-1][1] - t0) / 1e3:.1f} us for two passes")
+        print(f"# span {(part[-1][1] - t0) / 1e3:.1f} us for three passes")
 
 
 if __name__ == "__main__":
