@@ -17,7 +17,9 @@ extern "C" {
  *       16x16 tile above which the tile is counting-sorted), "dbg_sweep", "overlap" (0/1: binning of big passes on a
  *       second stream), "overlap_min_points", "sort_path" (0/1: the sorted pipeline for big passes), "sort_min_points",
  *       "sort_passes" (0 = by map size, 2, 3: counting-sort passes over the cell id), "walk_permute" (0/1),
- *       "sort_streams" (1, 2: binning streams consecutive overlapped passes of the sorted pipeline alternate between), "sort_ring" (2..4: the buffer sets they rotate through).  Returns GEM_ERR_INVALID for an unknown key or a value out of range. */
+ *       "sort_streams" (1, 2: binning streams consecutive overlapped passes of the sorted pipeline alternate between), "sort_ring" (2..4: the buffer sets they rotate through),
+ *       "trace" (0/1: one line on stderr per pass of the sorted pipeline), "stream_roles" (a permutation of 0123 as a decimal
+ *       number: which of the handle's current own / bin / bin2 / upload streams takes each role; tools/dbg/roles.py).  Returns GEM_ERR_INVALID for an unknown key or a value out of range. */
 int gem_debug_set(gem_handle* h, const char* key, long long value);
 
 /* per-tile cycle stamps of the last fuse launch ([tile][16] 64-bit counters); enable != 0 turns the stamps on for the
