@@ -405,7 +405,8 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     size_t o_seg[3] = {0, 0, 0}, o_next = 0;
     for (int i = 0; i < geo.n_passes; ++i) { o_seg[i] = o_next; o_next += (size_t)geo.dbins[i] * 16; }
     const size_t o_total = o_next, o_base = (o_total + 4 + 15) & ~(size_t)15;
-    if ((rc = ensure(h, pb.s_misc, o_base + ((size_t)geo.dbins[geo.n_passes - 1] + 1) * 4))) return rc;
+    const size_t o_segcnt = (o_base + ((size_t)geo.dbins[geo.n_passes - 1] + 1) * 4 + 15) & ~(size_t)15;
+    if ((rc = ensure(h, pb.s_misc, o_segcnt + (size_t)NC1 * 16))) return rc;
     // the walk of pass p-2 has read these buffers (host-side wait, see run_pipeline)
     if (overlap && pb.fuse_recorded) GEM_HIP(h, hipEventSynchronize(pb.fuse_done));
 
@@ -466,6 +467,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
         sa.segtot[i] = reinterpret_cast<uint32_t*>(misc + o_seg[i]);
     }
     sa.total = reinterpret_cast<uint32_t*>(misc + o_total); sa.bin_base = reinterpret_cast<uint32_t*>(misc + o_base);
+    sa.seg_cnt = reinterpret_cast<uint32_t*>(misc + o_segcnt);
     // arrays a: the projected records in input order, later the final order; arrays b: the order after pass 1
     sa.hv_a = static_cast<uint2*>(pb.s_hv2.p); sa.hv_b = static_cast<uint2*>(pb.s_hv1.p);
     sa.key_a = static_cast<uint32_t*>(pb.s_key2.p); sa.key_b = static_cast<uint32_t*>(pb.s_key1.p);
@@ -1337,7 +1339,7 @@ static int colorize_device(gem_handle* h, const gem_camera* cam, int n, float* d
     const size_t o_cnt1 = take(NC * sa.dbins[0] * 4), o_cnt2 = take(NC * bins_hi * 4 + 16);
     size_t o_seg[3] = {0, 0, 0};
     for (int i = 0; i < sa.n_passes; ++i) o_seg[i] = take((size_t)sa.dbins[i] * 16);
-    const size_t o_total = take(16), o_base = take(((size_t)sa.dbins[sa.n_passes - 1] + 1) * 4);
+    const size_t o_total = take(16), o_base = take(((size_t)sa.dbins[sa.n_passes - 1] + 1) * 4), o_segcnt = take(NC * 16);
     const size_t o_first = take((size_t)pixels * 4), o_pix = take(N * 4), o_link = take(N * 4);
     int rc;
     if ((rc = ensure(h, h->color, o))) return rc;
@@ -1351,6 +1353,7 @@ static int colorize_device(gem_handle* h, const gem_camera* cam, int n, float* d
         sa.segtot[i] = reinterpret_cast<uint32_t*>(d + o_seg[i]);
     }
     sa.total = reinterpret_cast<uint32_t*>(d + o_total); sa.bin_base = reinterpret_cast<uint32_t*>(d + o_base);
+    sa.seg_cnt = reinterpret_cast<uint32_t*>(d + o_segcnt);
     sa.hv_a = reinterpret_cast<uint2*>(d + o_hv2); sa.hv_b = reinterpret_cast<uint2*>(d + o_hv1);
     sa.key_a = reinterpret_cast<uint32_t*>(d + o_key2); sa.key_b = reinterpret_cast<uint32_t*>(d + o_key1);
     const LaunchEvents ev[9] = {};

@@ -112,6 +112,8 @@ struct SortArgs {
     int dshift[3], dbits[3], dbins[3]; // digit i = (id >> dshift[i]) & ((1 << dbits[i]) - 1), dbins[i] values
     int n_chunks1;                     // chunks of pass 1
     uint32_t *cnt[3], *segtot[3];      // per pass: [chunks][bins] per-chunk counts -> prefixes over the chunks of a segment; [4][bins] segment sums
+    uint32_t *seg_cnt;                 // [chunks of pass 1][4] records kept by each of k_sort_project's four waves: they are stored COMPACTED at the
+                                       // head of the wave's 1024-slot segment of the chunk (the rejected points leave no record)
     uint32_t *total;                   // [0] records kept by pass 1 (in the map, in the strip, accepted)
     uint32_t *bin_base;                // [bins of the last pass + 1] first record of every highest-digit bin in the final order (what k_fuse_walk searches in)
     uint2 *hv_a, *hv_b;                // {h, var}: a = input order, then after the even passes; b = after the odd passes (the passes ping-pong)
@@ -127,6 +129,7 @@ struct PassArgs {
     int n_chunks;                                // pass 1: chunks of the pass (pass 2 derives them from *n_dev)
     int bins, shift, digit_bits; uint32_t mask;
     const uint32_t* n_dev; long long n_host;     // number of items: on the device (pass 2) or known to the host (pass 1)
+    const uint32_t* seg_cnt;                     // pass 1: [chunks][4] records at the head of each 1024-slot segment (k_sort_project)
     const int* sweep_chunk0; const long long* sweep_first; int n_sweeps;   // pass 1 of a batched call: sweep-aligned chunks
     uint32_t* bin_base;                          // last pass: [bins + 1] published by workgroup 0
     unsigned long long* counters;

@@ -124,6 +124,12 @@ __global__ __launch_bounds__(256, (SRC == 2 ? 4 : 1)) void k_sort_project(SortAr
     // every constant after every store (measured: 105 us instead of 25 for the 32 sweeps of C4)
     const FrameConst fc = a.sweep_chunk0 ? a.frames[cr.sweep] : a.frame0;
     const long long base = cr.first + (long long)(tid >> 6) * (K * 64) + (tid & 63);
+    // The records of a wave's 1024 points are stored COMPACTED at the head of the wave's segment of the chunk, in input order: a
+    // point outside the map (or rejected) leaves nothing behind -- on a LiDAR batch that is three points in ten, which pass 1's
+    // scatter then neither reads nor ranks.  seg_cnt[chunk][wave] says how many there are.
+    const long long seg0 = cr.first + (long long)(tid >> 6) * (K * 64);
+    const uint64_t lt = lanemask_lt();
+    uint32_t kept = 0;                                                 // wave-uniform
     const uint32_t sweep_bits = (uint32_t)(cr.sweep + a.sweep_id0) << a.id_bits;   // (a shard of a multi-GPU batch numbers its sweeps globally)
     const uint32_t d0mask = (1u << a.dbits[0]) - 1u;
     __syncthreads();
@@ -137,15 +143,20 @@ __global__ __launch_bounds__(256, (SRC == 2 ? 4 : 1)) void k_sort_project(SortAr
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const long long i = base + (k0 + k) * 64;
-            if (i < cr.end) {
-                const Binned b = bin_one<SRC>(a, fc, SRC != 1 ? p[k] : make_float4(0.f, 0.f, 0.f, 0.f), i, (int)i + cr.orig0);
-                a.key_a[i] = b.valid ? (b.id | sweep_bits) : kKeyInvalid;
-                a.hv_a[i] = make_uint2(__float_as_uint(b.h), __float_as_uint(b.v));
-                if (a.src_a) a.src_a[i] = (uint32_t)i | (b.colour_ok ? 0x80000000u : 0u);   // source point; bit 31: R, G, B, intensity all non-zero
-                if (b.valid) atomicAdd(&hist[b.id & d0mask], 1u);
+            Binned b; b.valid = false;
+            if (i < cr.end) b = bin_one<SRC>(a, fc, SRC != 1 ? p[k] : make_float4(0.f, 0.f, 0.f, 0.f), i, (int)i + cr.orig0);
+            const uint64_t m = __ballot(b.valid);
+            if (b.valid) {
+                const long long at = seg0 + kept + (uint32_t)__popcll(m & lt);
+                a.key_a[at] = b.id | sweep_bits;
+                a.hv_a[at] = make_uint2(__float_as_uint(b.h), __float_as_uint(b.v));
+                if (a.src_a) a.src_a[at] = (uint32_t)i | (b.colour_ok ? 0x80000000u : 0u);  // source point; bit 31: R, G, B, intensity all non-zero
+                atomicAdd(&hist[b.id & d0mask], 1u);
             }
+            kept += (uint32_t)__popcll(m);
         }
     }
+    if ((tid & 63) == 0) a.seg_cnt[(size_t)chunk * 4 + (tid >> 6)] = kept;
     __syncthreads();
     for (int i = tid; i < a.dbins[0]; i += NT) a.cnt[0][(size_t)chunk * a.dbins[0] + i] = hist[i];
 }
@@ -306,13 +317,19 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void k_sort_scatter(PassAr
     for (int i = tid; i < NW * bins; i += NT) wcnt[i] = 0u;
     for (int i = tid; i < NW * 64; i += NT) wpms[i] = 0ull;
     const long long base = first + (long long)w * (K * 64) + lane;
+    // pass 1: the wave's 512 or 1024 positions lie in ONE 1024-slot segment of the chunk, whose first seg_cnt records are there
+    // (k_sort_project); the later passes read dense arrays
+    uint32_t seg_off = 0, seg_n = 0xffffffffu;
+    if (a.seg_cnt) { const uint32_t pos = (uint32_t)(w * (K * 64)); seg_off = pos & 1023u; seg_n = a.seg_cnt[(size_t)chunk * 4 + (pos >> 10)]; }
     uint2 hv[K]; uint32_t key[K], src[K], rk[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const long long i = base + k * 64, ic = i < end ? i : first;
+        const long long i = base + k * 64;
+        const bool there = i < end && seg_off + (uint32_t)(k * 64 + lane) < seg_n;
+        const long long ic = there ? i : first;
         key[k] = a.key_in[ic]; hv[k] = a.hv_in[ic];
         if (ATTR) src[k] = a.src_in[ic];
-        if (i >= end) key[k] = kKeyInvalid;
+        if (!there) key[k] = kKeyInvalid;
     }
     __syncthreads();
     // ---- 1. stable rank inside the wave's share, per-wave counts
@@ -825,6 +842,7 @@ hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, co
     p.cnt = a.cnt[0]; p.segtot = a.segtot[0]; p.n_chunks = a.n_chunks1; p.bins = a.dbins[0]; p.shift = a.dshift[0]; p.digit_bits = a.dbits[0];
     p.mask = (1u << a.dbits[0]) - 1u;
     p.n_dev = nullptr; p.n_host = a.n; p.sweep_chunk0 = a.sweep_chunk0; p.sweep_first = a.sweep_first; p.n_sweeps = a.n_sweeps;
+    p.seg_cnt = a.seg_cnt;
     const bool last0 = a.n_passes == 1;
     p.bin_base = last0 ? a.bin_base : nullptr; p.counters = last0 ? a.counters : nullptr;
     if ((e = launch_pass(st, sh[0], p, attr, a.n_chunks1, false, ev[2])) != hipSuccess) return e;
@@ -837,7 +855,7 @@ hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, co
         p.hv_out = from_b ? a.hv_a : a.hv_b; p.key_out = from_b ? a.key_a : a.key_b; p.src_out = from_b ? a.src_a : a.src_b;
         p.cnt = a.cnt[i]; p.segtot = a.segtot[i]; p.n_chunks = 0; p.bins = a.dbins[i]; p.shift = a.dshift[i]; p.digit_bits = a.dbits[i];
         p.mask = (1u << a.dbits[i]) - 1u;
-        p.n_dev = a.total; p.n_host = 0; p.sweep_chunk0 = nullptr; p.sweep_first = nullptr; p.n_sweeps = 1;
+        p.n_dev = a.total; p.n_host = 0; p.sweep_chunk0 = nullptr; p.sweep_first = nullptr; p.n_sweeps = 1; p.seg_cnt = nullptr;
         p.bin_base = last ? a.bin_base : nullptr; p.counters = last ? a.counters : nullptr;
         if ((e = launch_pass(st, sh[i], p, attr, grid, true, ev[3 * i])) != hipSuccess) return e;
         GEM_LAUNCH(k_sort_scan, dim3((a.dbins[i] + 63) / 64, kScanSegs), dim3(1024), 0, st, ev[3 * i + 1], a.cnt[i], a.segtot[i], a.dbins[i], 0,
