@@ -427,17 +427,6 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
     const uint32_t gf0 = load_gflag(0, 0);
     uint32_t gfn = 0;
     int prefetched = -1;                                                 // sweep whose first chunk sits in evn
-    // One sweep (the stream of single frames): the row's first chunk is requested AT ONCE, next to the stamps that say which of
-    // its groups are live and whether the tile is touched at all -- a whole 4 KB row per tile instead of its live 64-byte groups
-    // (6 MB per frame, nothing at 8 TB/s), and one dependent round trip less on the frame's critical path (stamps -> descriptor
-    // words -> records was three).  The stamps are applied when the words are unpacked.
-    bool evn_inb = false;
-    if constexpr (!BATCH) {
-        const int u0 = tid * UPT;
-        evn_inb = u0 < a.B_total;
-        evn = *reinterpret_cast<const RowWords*>(row_ptr(0) + (evn_inb ? u0 : 0));
-        prefetched = 0;
-    }
 
     // Batched call: the per-sweep tables are fetched once per block of 64 sweeps, one entry per lane, and read back with
     // v_readlane (a struct-of-pointers kernel argument carries no noalias information, so indexing them per sweep
@@ -466,8 +455,11 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
     }
     // descriptor words of the first touched sweep: in flight before the tile itself is read, so that the
     // (larger, strided) tile loads do not sit in front of them in the memory pipeline
-    if constexpr (!BATCH) {                                              // one sweep: requested above
-        evn_on = evn_inb && gf0 == epoch;
+    // (Requesting a single sweep's whole row at once, next to its stamps -- one dependent round trip less -- was measured:
+    //  k_frame 9.6 -> 9.4 us, but 2.8 MB more fetched per frame, the rows of the groups no point went to: not worth it.)
+    if constexpr (!BATCH) {                                              // one sweep: no branch around the load (see load_row)
+        prefetched = 0;
+        evn = load_row(0, a.B_total, 0, gf0, evn_on);
     } else if (MODE != 2 && smask != 0) {
         prefetched = __ffsll((unsigned long long)smask) - 1;
         evn = load_row(prefetched, units_of(prefetched), 0, prefetched == 0 ? gf0 : load_gflag(prefetched, 0), evn_on);
