@@ -456,7 +456,8 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
     // descriptor words of the first touched sweep: in flight before the tile itself is read, so that the
     // (larger, strided) tile loads do not sit in front of them in the memory pipeline
     // (Requesting a single sweep's whole row at once, next to its stamps -- one dependent round trip less -- was measured:
-    //  k_frame 9.6 -> 9.4 us, but 2.8 MB more fetched per frame, the rows of the groups no point went to: not worth it.)
+    //  no change beyond the box-to-box spread of k_frame, 9.3-9.6 us, and 2.8 MB more fetched per frame: the rows of the groups no
+    //  point went to.)
     if constexpr (!BATCH) {                                              // one sweep: no branch around the load (see load_row)
         prefetched = 0;
         evn = load_row(0, a.B_total, 0, gf0, evn_on);
