@@ -87,7 +87,7 @@ struct gem_handle {
     long long overlap_min_points = 1000000;        // tile pipeline: a cross-stream event pair costs 3 us, the second stream only pays for big passes
     long long sort_overlap_min_points = 100000;    // sorted pipeline: its walk is a few long chains on a mostly idle chip; the next pass's sort fits beside it (depth image 120 -> 83 us)
     bool sort_path = true;              // passes of at least sort_min_points points run the sorted pipeline (gem_sort.hip)
-    long long sort_min_points = 200000, sort_min_points_batch = 1000000;     // single cloud / batch of sweeps
+    long long sort_min_points = 200000, sort_min_points_batch = 600000;      // single cloud / batch of sweeps (tools/dbg/crossover.py)
     bool walk_permute = true;           // k_fuse_walk: blocks take the tile rows centre-first
     int  sort_passes = 0;               // 0 = by map size (two digits up to 2^20 cells, else three); 2 / 3 force it
     int dbg_sweep = 0;                  // debug stamps of the dense path: which sweep (GEM_DBG_SWEEP)
