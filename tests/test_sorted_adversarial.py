@@ -128,3 +128,36 @@ def test_big_batch_on_two_streams_then_small_passes(oracle_mod):
         for k in range(10):
             ref.add(wl.frames[k], wl.clouds[k])
         check(gpu, ref, f"round {rnd}")
+
+
+@pytest.mark.parametrize("period", [1, 2, 3, 5, 7, 31, 32, 33, 63, 64, 65])
+def test_cell_patterns_inside_a_wave_step(oracle_mod, period):
+    """The scatter ranks 64 consecutive records at a time; the lanes of a cell find each other through the LDS.  Clouds whose
+    points visit `period` cells cyclically (so a wave step holds every mix from 64 records of one cell to 64 different cells),
+    with every third-or-so point rejected by the height window (the records are compacted per wave before they are ranked) and
+    heights that make every swap inside a cell visible (the recurrence is order dependent)."""
+    import torch
+    L, res = 96, 0.1
+    rng = np.random.default_rng(100 + period)
+    n = 3 * 4096 + 777
+    k = np.arange(n)
+    cell = (k % period) if period > 1 else np.zeros(n, np.int64)
+    # the cells of the cycle lie on a line through several 32x32 tiles; the first digit of the id changes with every one
+    cx = 0.5 * res + res * ((cell * 7) % (L - 8) - (L - 8) // 2)
+    cy = 0.5 * res + res * ((cell * 3) % 11 - 5)
+    z = rng.normal(0.3, 0.4, n).astype(F32)
+    z[rng.random(n) < 0.3] = 50.0                            # outside the window: rejected
+    c = np.stack([cx, cy, z, np.ones(n)], 1).astype(F32)
+    f = frame(); f.lower, f.upper = -5.0, 5.0
+    for knobs in ({"sort_min_points": 1}, {"sort_min_points": 1, "sort_passes": 3}):
+        gpu, ref = ElevationMap(L, res, debug=knobs), oracle_mod.OracleMap(L, res)
+        d = torch.from_numpy(c).cuda()
+        for rep in range(2):
+            gpu.add(f, d); ref.add(f, c)
+            check(gpu, ref, f"period={period} rep={rep} {knobs}")
+        off = np.array([0, 1000, 1001, 5000, n])             # the same cloud as four sweeps with increments in between
+        vu = [1e-4, 0.0, 3e-5, 2e-4]
+        gpu.add_batch([f] * 4, d, off, vu)
+        for s in range(4):
+            ref.mapvar_update(vu[s]); ref.add(f, c[off[s]:off[s + 1]])
+        check(gpu, ref, f"period={period} batch {knobs}")
