@@ -341,7 +341,7 @@ SortGeometry sort_geometry(const gem_handle* h, int n_sweeps)
 
 // One pass through the sorted pipeline (gem_sort.hip): six sort kernels on the binning stream, k_fuse_walk on the handle's.
 constexpr size_t kShardHostBytes = 8192;
-struct ShardOpts { int sweep_id0; int nstrips; const int* strip_rows; };      // sort only: the walk happens on the strip owners
+struct ShardOpts { int sweep_id0; int nstrips; const int* strip_rows; bool bounds_stay_on_device; };   // sort only: the walk happens on the strip owners
 
 int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGeometry& geo, const ShardOpts* shard = nullptr)
 {
@@ -524,10 +524,16 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
         uint32_t* d_ids = static_cast<uint32_t*>(h->sh_dev.p), *d_bounds = d_ids + 16;
         GEM_HIP(h, hipMemcpyAsync(d_ids, host, sizeof(uint32_t) * (shard->nstrips + 1), hipMemcpyHostToDevice, h->stream));
         GEM_HIP(h, launch_strip_bounds(h->stream, final_b ? sa.key_b : sa.key_a, sa.total, geo.id_bits, d_ids, d_bounds, shard->nstrips + 1));
-        GEM_HIP(h, hipMemcpyAsync(host + 32, d_bounds, sizeof(uint32_t) * (shard->nstrips + 1), hipMemcpyDeviceToHost, h->stream));
-        GEM_HIP(h, hipStreamSynchronize(h->stream));
         sd.hv = final_b ? sa.hv_b : sa.hv_a; sd.key = final_b ? sa.key_b : sa.key_a;
         sd.nstrips = shard->nstrips;
+        if (shard->bounds_stay_on_device) {                  // gem_add_sharded_device all-gathers them from where they are: one host round trip per step, not two
+            for (int k = 0; k <= shard->nstrips; ++k) sd.bounds[k] = 0;
+            sd.valid = true;
+            h->stats.points_in = in.n;
+            return GEM_OK;
+        }
+        GEM_HIP(h, hipMemcpyAsync(host + 32, d_bounds, sizeof(uint32_t) * (shard->nstrips + 1), hipMemcpyDeviceToHost, h->stream));
+        GEM_HIP(h, hipStreamSynchronize(h->stream));
         for (int k = 0; k <= shard->nstrips; ++k) sd.bounds[k] = host[32 + k];
         sd.valid = true;
         h->stats.points_in = in.n;
@@ -1613,14 +1619,13 @@ static int shard_checks(gem_handle* h, int n_global_sweeps, SortGeometry* geo)
     return GEM_OK;
 }
 
-int gem_shard_sort_device(gem_handle* h, int n_local_sweeps, const gem_frame_params* params, const void* d_xyzi, const long long* offsets,
-                          int first_global_sweep, int n_global_sweeps, int nstrips, const int* strip_rows,
-                          uint32_t* out_bounds, const void** out_d_hv, const void** out_d_key)
+static int shard_sort_locked(gem_handle* h, int n_local_sweeps, const gem_frame_params* params, const void* d_xyzi, const long long* offsets,
+                             int first_global_sweep, int n_global_sweeps, int nstrips, const int* strip_rows,
+                             uint32_t* out_bounds, const void** out_d_hv, const void** out_d_key, bool bounds_stay_on_device)
 {
-    if (!h || n_local_sweeps < 0 || nstrips <= 0 || nstrips > kMaxRanks || !strip_rows || first_global_sweep < 0 ||
+    if (n_local_sweeps < 0 || nstrips <= 0 || nstrips > kMaxRanks || !strip_rows || first_global_sweep < 0 ||
         first_global_sweep + n_local_sweeps > n_global_sweeps || (n_local_sweeps > 0 && (!params || !offsets || !d_xyzi)))
-        return h ? fail(h, GEM_ERR_INVALID, "gem_shard_sort_device: bad argument") : GEM_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(h->mu);
+        return fail(h, GEM_ERR_INVALID, "gem_shard_sort_device: bad argument");
     hipSetDevice(h->device);
     for (int k = 0; k <= nstrips; ++k) {
         const bool ok = (strip_rows[k] % 32 == 0 || strip_rows[k] >= h->L) && strip_rows[k] >= 0 && (k == 0 || strip_rows[k] >= strip_rows[k - 1]);
@@ -1636,6 +1641,10 @@ int gem_shard_sort_device(gem_handle* h, int n_local_sweeps, const gem_frame_par
     if (n == 0) {                                        // an empty shard contributes nothing to any strip
         sd.valid = true; sd.hv = nullptr; sd.key = nullptr; sd.nstrips = nstrips;
         for (int k = 0; k <= nstrips; ++k) sd.bounds[k] = 0;
+        if (bounds_stay_on_device) {
+            if ((rc = ensure(h, h->sh_dev, 4096 + sizeof(float) * 512))) return rc;
+            GEM_HIP(h, hipMemsetAsync(static_cast<uint32_t*>(h->sh_dev.p) + 16, 0, 16 * sizeof(uint32_t), h->stream));
+        }
     } else {
         for (int s = 0; s < n_local_sweeps; ++s) if (offsets[s + 1] < offsets[s]) return fail(h, GEM_ERR_INVALID, "gem_shard_sort_device: offsets not monotone");
         PassInput in; in.src = 0; in.n_sweeps = n_local_sweeps; in.n = n; in.params = params; in.device_input = true;
@@ -1643,7 +1652,7 @@ int gem_shard_sort_device(gem_handle* h, int n_local_sweeps, const gem_frame_par
         for (int s = 0; s <= n_local_sweeps; ++s) off0[s] = offsets[s] - offsets[0];
         in.offsets = off0.data(); in.var_updates = nullptr;
         in.xyzi = static_cast<const float4*>(d_xyzi) + offsets[0];
-        ShardOpts so{first_global_sweep, nstrips, strip_rows};
+        ShardOpts so{first_global_sweep, nstrips, strip_rows, bounds_stay_on_device};
         if ((rc = run_sort_pipeline(h, in, 0, geo, &so))) return rc;
     }
     sd.n_global_sweeps = n_global_sweeps;
@@ -1651,6 +1660,16 @@ int gem_shard_sort_device(gem_handle* h, int n_local_sweeps, const gem_frame_par
     if (out_d_hv) *out_d_hv = sd.hv;
     if (out_d_key) *out_d_key = sd.key;
     return GEM_OK;
+}
+
+int gem_shard_sort_device(gem_handle* h, int n_local_sweeps, const gem_frame_params* params, const void* d_xyzi, const long long* offsets,
+                          int first_global_sweep, int n_global_sweeps, int nstrips, const int* strip_rows,
+                          uint32_t* out_bounds, const void** out_d_hv, const void** out_d_key)
+{
+    if (!h) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    return shard_sort_locked(h, n_local_sweeps, params, d_xyzi, offsets, first_global_sweep, n_global_sweeps, nstrips, strip_rows,
+                             out_bounds, out_d_hv, out_d_key, false);
 }
 
 static int shard_fuse_locked(gem_handle* h, int n_src, const void* const* d_hv, const void* const* d_key, const uint32_t* counts,
@@ -1713,28 +1732,26 @@ int gem_add_sharded_device(gem_handle* h, int n_local_sweeps, const gem_frame_pa
                            int first_global_sweep, int n_global_sweeps, const float* var_updates_global)
 {
     if (!h) return GEM_ERR_INVALID;
-    {
-        std::lock_guard<std::mutex> lk(h->mu);
-        if (!h->comm || !h->tile_strips) return fail(h, GEM_ERR_COMM, "gem_add_sharded_device: gem_comm_init_tiles not called");
-    }
-    const int W = h->nranks;
-    int rc = gem_shard_sort_device(h, n_local_sweeps, params, d_xyzi, offsets, first_global_sweep, n_global_sweeps, W, h->strip_row,
-                                   nullptr, nullptr, nullptr);
-    if (rc) return rc;
     std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->comm || !h->tile_strips) return fail(h, GEM_ERR_COMM, "gem_add_sharded_device: gem_comm_init_tiles not called");
+    const int W = h->nranks;
+    // the sort leaves this rank's strip boundaries on the device (k_strip_bounds' output, 16 words reserved) ...
+    int rc = shard_sort_locked(h, n_local_sweeps, params, d_xyzi, offsets, first_global_sweep, n_global_sweeps, W, h->strip_row,
+                               nullptr, nullptr, nullptr, true);
+    if (rc) return rc;
     hipSetDevice(h->device);
     gem_handle::Shard& sd = h->shard;
-    // every rank learns what it receives from whom: an all-gather of the strip boundaries (W + 1 words per rank)
+    // ... and every rank learns what it receives from whom -- and what it sends -- from ONE all-gather of them (W + 1 words per
+    // rank) and one host round trip
     uint32_t* host = static_cast<uint32_t*>(h->sh_host);
     if (!host) { GEM_HIP(h, hipHostMalloc(&h->sh_host, kShardHostBytes, hipHostMallocDefault)); host = static_cast<uint32_t*>(h->sh_host); }
     if ((rc = ensure(h, h->sh_dev, 4096 + sizeof(float) * 512))) return rc;
     uint32_t* d_mine = static_cast<uint32_t*>(h->sh_dev.p) + 16, *d_all = static_cast<uint32_t*>(h->sh_dev.p) + 64;   // [W][16]
-    for (int k = 0; k < 16; ++k) host[k] = k <= W ? sd.bounds[k] : 0u;
-    GEM_HIP(h, hipMemcpyAsync(d_mine, host, 16 * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
     ncclResult_t r = ncclAllGather(d_mine, d_all, 16, ncclUint32, h->comm, h->stream);
     if (r != ncclSuccess) return fail(h, GEM_ERR_COMM, ncclGetErrorString(r));
     GEM_HIP(h, hipMemcpyAsync(host + 64, d_all, (size_t)W * 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
     GEM_HIP(h, hipStreamSynchronize(h->stream));
+    for (int k = 0; k <= W; ++k) sd.bounds[k] = host[64 + h->rank * 16 + k];
     uint32_t cnt[kMaxRanks], off[kMaxRanks + 1];
     off[0] = 0;
     for (int s = 0; s < W; ++s) {
