@@ -15,10 +15,13 @@ CPU oracle replays the very sequence of sweeps the timed map has seen and the tw
 `roofline` describes the dominant kernel (dispatch time stamps on the stream it runs on, second loop), `batched_c4` the
 bandwidth-regime configuration (BASELINE configs[3]), `cpu_baseline` the oracle on this box's host cores.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): BASELINE configs[4], STRONG scaling -- the same 10^7-point
-aggregated cloud -> 2400 x 2400 map on N ranks per step: every rank projects / bins / sorts its N-th of the points, the sorted
-records go to the tile-row strip owners (RCCL send / recv), the owners fuse, and the fused strips are all-gathered over xGMI
-(gem_add_sharded_device + gem_allgather_layers).  value = 10^7 points / step time (max over ranks).
+N > 1 (one rank per GPU; launched by torch.distributed.run -- or by this script itself when WORLD_SIZE is not set: it re-executes
+under torch.distributed.run with N ranks, and exits non-zero when fewer than N devices are visible): BASELINE configs[4], STRONG
+scaling -- the same 10^7-point aggregated cloud -> 2400 x 2400 map on N ranks per step: every rank projects / bins / sorts its
+N-th of the points, the sorted records go to the tile-row strip owners (RCCL send / recv), the owners fuse, and the fused strips
+are all-gathered over xGMI (gem_add_sharded_device + gem_allgather_layers).  value = 10^7 points / step time (max over ranks).
+The same workload on ONE GPU (plain gem_add_batch_device) is in both kinds of line: `c5_one_gpu` at N = 1, and
+`one_gpu_us_per_step` / `speedup_vs_one_gpu` (measured by rank 0 in the same process) at N > 1.
 
 Prints ONE JSON line (rank 0).
 """
@@ -38,7 +41,8 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6300.0    # the same guide: 6.29 TB/s measured copy rate (SURVEY 8d asks for both fractions)
 N_DISTINCT = 8
 MIN_TIMED_S = 0.05
 
@@ -255,16 +259,133 @@ def batched_c4(emap_cls, dev, torch, reps: int = 20):
             "us_per_kernel": kern, "roofline": roof, "parity_checked": bool(ok)}
 
 
-# ---- N > 1: C5, strong scaling ------------------------------------------------------------------------------------------------
-def run_c5_distributed(args, torch, dist, world, rank, local_rank, dev):
-    from gem_amd import ElevationMap, synth
-    from gem_amd.tiling import shard_batch, tile_strip_rows
+def c5_cloud():
+    from gem_amd import synth
     wl = synth.config_c5()
     off = np.concatenate([[0], np.cumsum([c.shape[0] for c in wl.clouds])])
+    return wl, np.concatenate(wl.clouds), off
+
+
+def c5_one_gpu(emap_cls, dev, torch, reps: int = 12, wl=None, cat=None, off=None):
+    """BASELINE configs[4] on ONE GPU: the 10^7-point aggregated cloud -> 2400 x 2400 map with one plain gem_add_batch_device
+    call per step (what the N > 1 lines scale).  The first pass into the fresh map is compared with the committed digest."""
+    if wl is None:
+        wl, cat, off = c5_cloud()
+    d_cat = torch.from_numpy(cat).to(dev)
+    m = emap_cls(wl.length, wl.resolution, device=dev.index)
+    pb = m.pack_batch(wl.frames, off, None)
+    m.add_batch(pb, d_cat)
+    d = golden()["c5_full"]
+    ok = sha(m.layer("elevation")) == d["elevation"] and sha(m.layer("variance")) == d["variance"]
+    for _ in range(3):
+        m.add_batch(pb, d_cat)
+    m.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        m.add_batch(pb, d_cat)
+    m.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    m.set_counting(True); m.add_batch(pb, d_cat)
+    cells = m.stats()["cells_touched"]
+    m.close()
+    del d_cat
+    n = int(off[-1])
+    alg = 16.0 * n + 16.0 * cells
+    return {"workload": "C5: 10 M-point aggregated cloud (77 sweeps, no variance increments) -> 2400x2400 @ 0.05 m, one gem_add_batch_device call per step, ONE GPU",
+            "value": n / dt, "unit": "points/s", "us_per_step": dt * 1e6, "cells_touched": int(cells), "algorithmic_bytes": alg,
+            "achieved_GBps": alg / dt / 1e9, "frac_of_hbm_peak": alg / dt / 1e9 / HBM_PEAK_GBS, "frac_of_6300": alg / dt / 1e9 / HBM_ACHIEVABLE_GBS,
+            "parity_checked": bool(ok), "parity": "first pass into a fresh map == tests/golden/digests.json c5_full"}
+
+
+def c3_stream(emap_cls, dev, torch, reps: int = 40):
+    """BASELINE configs[2]: 640 x 480 depth image -> 400 x 400 @ 0.025 m, a stream of frames.  The cells under the camera hold
+    hundreds of points each and G_fuse's recurrence is sequential per cell (GPU:477-537), so a frame cannot take less than its
+    longest chain x the time of one step: `longest_chain` and `ns_per_chain_step` let a reader check that claim."""
+    from gem_amd import synth
+    d = golden()["c3"]
+    wl = synth.config_c3()
+    dc = torch.from_numpy(wl.clouds[0]).to(dev)
+    m = emap_cls(wl.length, wl.resolution, device=dev.index)
+    m.move(wl.map_position)
+    m.add(wl.frames[0], dc)
+    ok = sha(m.layer("elevation")) == d["elevation"] and sha(m.layer("variance")) == d["variance"]
+    c = wl.clouds[0]
+    pp = m.process_points(wl.frames[0], c[:, 0].copy(), c[:, 1].copy(), c[:, 2].copy())
+    idx = pp["index"]; idx = idx[idx >= 0]
+    per_cell = np.bincount(idx)
+    longest = int(per_cell.max())
+    for _ in range(5):
+        m.add(wl.frames[0], dc)
+    m.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        m.add(wl.frames[0], dc)
+    m.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    m.set_timing(True); m.stats(reset=True)
+    for _ in range(reps):
+        m.add(wl.frames[0], dc)
+    st = m.stats(); m.set_timing(False)
+    us_walk = 1e3 * st["ms_walk"] / max(st["launches_walk"], 1)
+    m.close()
+    n = c.shape[0]
+    cells = int((per_cell > 0).sum())
+    alg = 16.0 * n + 16.0 * cells
+    return {"workload": "C3: 640x480 depth image (307200 pts) -> 400x400 @ 0.025 m, one gem_add_device per frame, laser variance model",
+            "value": n / dt, "unit": "points/s", "us_per_frame": dt * 1e6, "cells_touched": cells, "mean_points_per_touched_cell": float(idx.size) / max(cells, 1),
+            "longest_chain": longest, "us_fuse_kernel": us_walk, "ns_per_chain_step": 1e3 * us_walk / max(longest, 1),
+            "algorithmic_bytes": alg, "achieved_GBps": alg / dt / 1e9, "frac_of_hbm_peak": alg / dt / 1e9 / HBM_PEAK_GBS,
+            "parity_checked": bool(ok), "parity": "first frame into a fresh map == tests/golden/digests.json c3"}
+
+
+def c2_variants(emap_cls, dev, torch, reps: int = 400):
+    """SURVEY 8d's other C2 figures: the sweep with the reference's sensor-frame reject filter ON (gpu_process.cu:393), and the
+    end-to-end rate when the boundary hands over HOST buffers (gem_add: pinned staging + H2D inside the call; never `value`)."""
+    from gem_amd import synth
+    d = golden()
+    out = {}
+    wl = synth.config_c2(reference_filter=True)
+    dc = torch.from_numpy(wl.clouds[0]).to(dev)
+    m = emap_cls(wl.length, wl.resolution, device=dev.index)
+    m.add(wl.frames[0], dc)
+    ok = sha(m.layer("elevation")) == d["c2_filter"]["elevation"] and sha(m.layer("variance")) == d["c2_filter"]["variance"]
+    for _ in range(20):
+        m.add(wl.frames[0], dc)
+    m.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps):
+        m.add(wl.frames[0], dc)
+    m.synchronize(); dt = (time.perf_counter() - t0) / reps
+    n = wl.clouds[0].shape[0]
+    alg = 16.0 * n + 16.0 * d["c2_filter"]["cells_touched"]
+    out["c2_reference_filter_on"] = {"workload": "C2 sweep, reject filter of gpu_process.cu:393 ON (55879 of 131072 points accepted)", "value": n / dt, "unit": "points/s",
+                                     "us_per_step": dt * 1e6, "achieved_GBps": alg / dt / 1e9, "parity_checked": bool(ok),
+                                     "parity": "first sweep into a fresh map == tests/golden/digests.json c2_filter"}
+    m.close()
+    wl = synth.config_c2()
+    m = emap_cls(wl.length, wl.resolution, device=dev.index)
+    host = wl.clouds[0]
+    m.add(wl.frames[0], host)
+    ok = sha(m.layer("elevation")) == d["c2"]["elevation"] and sha(m.layer("variance")) == d["c2"]["variance"]
+    for _ in range(10):
+        m.add(wl.frames[0], host)
+    m.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps // 4):
+        m.add(wl.frames[0], host)
+    m.synchronize(); dt = (time.perf_counter() - t0) / (reps // 4)
+    out["e2e_with_h2d"] = {"workload": "C2 sweep handed over as a HOST array (gem_add: staging copy + H2D + the same kernels)", "value": n / dt, "unit": "points/s",
+                           "us_per_step": dt * 1e6, "parity_checked": bool(ok), "parity": "first sweep into a fresh map == tests/golden/digests.json c2"}
+    m.close()
+    return out
+
+
+# ---- N > 1: C5, strong scaling ------------------------------------------------------------------------------------------------
+def run_c5_distributed(args, torch, dist, world, rank, local_rank, dev):
+    from gem_amd import ElevationMap
+    from gem_amd.tiling import shard_batch, tile_strip_rows
+    wl, cat, off = c5_cloud()
     n_total = int(off[-1])
     first, local = shard_batch(off, world, rank)
     # only this rank's share of the cloud has to be resident
-    cat = np.concatenate(wl.clouds)
     d_share = torch.from_numpy(cat[local[0]:local[-1]]).to(dev)
     emap = ElevationMap(wl.length, wl.resolution, device=local_rank)
     uid = [ElevationMap.comm_unique_id() if rank == 0 else None, ElevationMap.comm_unique_id() if rank == 0 else None]
@@ -309,11 +430,21 @@ def run_c5_distributed(args, torch, dist, world, rank, local_rank, dev):
     us_sort = 1e3 * sum(st["ms_sort"]) / reps; us_walk = 1e3 * st["ms_walk"] / reps
     us_step = 1e6 * elapsed / args.steps
     rows = tile_strip_rows(wl.length, world)
+    emap.close(); chk.close()
+    del d_share
+    barrier()
+    # the SAME workload on one GPU, by rank 0 in this process while the other ranks wait: what the speed-up is measured against
+    one = cpu = None
+    if rank == 0:
+        one = c5_one_gpu(ElevationMap, dev, torch, reps=max(6, min(args.steps, 20)), wl=wl, cat=cat, off=off)
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline_c5(wl, cat, off, args.cpu_seconds)
+    dist.barrier()
     out = None
     if rank == 0:
-        alg = 16.0 * n_total + 16.0 * 5_499_917        # the oracle's touched-cell count for this seed (tests/golden digests run)
+        alg = 16.0 * n_total + 16.0 * one["cells_touched"]
         out = {
-            "metric": "fused points/sec into 600x600 grid; achieved HBM GB/s vs roofline",
+            "metric": "fused points/sec into 2400x2400 grid (BASELINE configs[4]); achieved HBM GB/s vs roofline",
             "value": n_total * args.steps / elapsed, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -321,16 +452,57 @@ def run_c5_distributed(args, torch, dist, world, rank, local_rank, dev):
                                    "points sharded by index range over the ranks, sorted records routed to tile-row strip owners (RCCL send/recv), "
                                    "RCCL all-gather of the fused elevation + variance layers",
                        "points_per_step": n_total, "grid": "2400x2400@0.05m", "parallelism": f"shard{world}+strips{world}", "strip_rows": rows},
-            "phases_us_rank0": {"sort_kernels": us_sort, "k_fuse_walk": us_walk, "exchange_allgather_and_gaps": max(us_step - us_sort - us_walk, 0.0),
+            "one_gpu_us_per_step": one["us_per_step"], "speedup_vs_one_gpu": one["us_per_step"] / us_step, "c5_one_gpu": one,
+            "phases_us_rank0": {"sort_kernels": us_sort, "k_fuse_block": us_walk, "exchange_allgather_and_gaps": max(us_step - us_sort - us_walk, 0.0),
                                 "step": us_step},
             "roofline": {"bound": "hbm", "kernel": "pipeline (per rank)", "achieved": alg / world / (us_step * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": alg / world / (us_step * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                          "note": "SURVEY 8d algorithmic bytes of the whole cloud / ranks / step time; the all-gather adds 46 MB received per rank and step"},
-            "parity_checked": bool(okt.item() == 1),
-            "parity": "every rank's all-gathered map after one pass == tests/golden/digests.json c5_full (elevation, variance)",
+            "parity_checked": bool(okt.item() == 1 and one["parity_checked"]),
+            "parity": "every rank's all-gathered map after one pass == tests/golden/digests.json c5_full (elevation, variance); so is the one-GPU map",
         }
-    emap.close(); chk.close()
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
     return out
+
+
+def cpu_baseline_c5(wl, cat, off, budget_s: float):
+    """The all-core CPU oracle on the C5 cloud (one pass = 10^7 points; rank 0 only), checked against the committed digest."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import oracle
+    ncpu = os.cpu_count() or 1
+    t_begin = time.perf_counter()
+    best = None
+    for nt in sorted({min(ncpu, v) for v in (16, 32, 64)}):
+        m = oracle.OracleMap(wl.length, wl.resolution)
+        t0 = time.perf_counter(); m.add_batch_mt(wl.frames, cat, off, None, nt); dt = time.perf_counter() - t0
+        if best is None or dt < best[1]:
+            best = (nt, dt, m)
+        if time.perf_counter() - t_begin > budget_s:
+            break
+    nt, dt, m = best
+    d = golden()["c5_full"]
+    ok = sha(m.layer("elevation")) == d["elevation"] and sha(m.layer("variance")) == d["variance"]
+    return {"value": int(off[-1]) / dt, "unit": "points/s", "kind": "port", "cores": nt, "host_cores": ncpu, "cpu_model": cpu_model(),
+            "matches_committed_digest": bool(ok),
+            "sample": f"one pass of the whole C5 cloud (10^7 pts -> 2400x2400) by oracle/gem_oracle_mt.c gemo_add_batch_mt on {nt} threads ({dt:.2f} s), "
+                      f"the map compared with tests/golden/digests.json c5_full"}
+
+
+def self_launch(args) -> None:
+    """`python bench.py --gpus N` (N > 1) without a launcher around it: run the N ranks ourselves."""
+    import socket
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} HIP device(s) visible on this box; the N > 1 bench needs one device per rank "
+                         f"(set GEM_BENCH_FORCE_DIST=1 with --gpus 1 to exercise the distributed code path on one device)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    print("[bench] re-executing under torch.distributed.run: " + " ".join(cmd), file=sys.stderr, flush=True)
+    os.execv(sys.executable, cmd)
 
 
 _REAL_STDOUT = None
@@ -347,6 +519,10 @@ def emit(obj) -> None:
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                                    # does not return
     # Libraries underneath write to stdout on their own (RCCL prints a version banner at communicator creation, the compiled
     # reference printf's from its Init): everything but the JSON line goes to stderr.
     global _REAL_STDOUT
@@ -361,7 +537,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or bool(os.environ.get("GEM_BENCH_FORCE_DIST"))      # the env var exercises the N > 1 code path with one rank
-    if args.gpus != world and distributed:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -449,7 +625,7 @@ def main():
             traffic_note += (f"; kernel duration in that run {pm[2]:.2f} us vs {dom_us:.2f} us now" +
                              (" -- MORE THAN 25 % APART: the counters may describe an older kernel, re-run tools/profile_c2.sh" if stale else ""))
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                "frac": achieved / HBM_PEAK_GBS, "frac_of_6300": achieved / HBM_ACHIEVABLE_GBS, "traffic": traffic, "traffic_source": traffic_note,
                 "us_per_launch": {"k_frame": us_frame, "k_bin_wave": us_bin, "k_fuse_list": us_fuse},
                 "launches": {"k_frame": st["launches_frame"], "k_bin_wave": st["launches_bin"], "k_fuse_list": st["launches_fuse"]},
                 "algorithmic_bytes_per_launch": {"k_frame": alg_bin + alg_fuse, "k_bin_wave": alg_bin, "k_fuse_list": alg_fuse},
@@ -475,9 +651,13 @@ def main():
     failed = not ok_stream
     if not args.no_extras:
         out["batched_c4"] = batched_c4(ElevationMap, dev, torch)
-        out["parity_checked"] = bool(out["parity_checked"] and out["batched_c4"]["parity_checked"])
-        out["parity"] += "; C4 batch (twice into a fresh map) vs c4_32 / c4_32_twice"
-        failed = failed or not out["batched_c4"]["parity_checked"]
+        out["c5_one_gpu"] = c5_one_gpu(ElevationMap, dev, torch)
+        out["c3"] = c3_stream(ElevationMap, dev, torch)
+        out.update(c2_variants(ElevationMap, dev, torch))
+        extras = ("batched_c4", "c5_one_gpu", "c3", "c2_reference_filter_on", "e2e_with_h2d")
+        out["parity_checked"] = bool(out["parity_checked"] and all(out[k]["parity_checked"] for k in extras))
+        out["parity"] += "; C4 batch (twice into a fresh map) vs c4_32 / c4_32_twice; C5 on one GPU vs c5_full; C3 vs c3; C2 with the reference filter vs c2_filter; host-array C2 vs c2"
+        failed = failed or not out["parity_checked"]
     if not args.no_cpu_baseline:
         allc, one, lit = cpu_baseline(wl, n_timed_map, timed_layers, args.cpu_seconds)
         out["cpu_baseline"] = allc
