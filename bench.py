@@ -430,9 +430,9 @@ def run_c5_distributed(args, torch, dist, world, rank, local_rank, dev):
     us_sort = 1e3 * sum(st["ms_sort"]) / reps; us_walk = 1e3 * st["ms_walk"] / reps
     us_step = 1e6 * elapsed / args.steps
     rows = tile_strip_rows(wl.length, world)
+    barrier()
     emap.close(); chk.close()
     del d_share
-    barrier()
     # the SAME workload on one GPU, by rank 0 in this process while the other ranks wait: what the speed-up is measured against
     one = cpu = None
     if rank == 0:
