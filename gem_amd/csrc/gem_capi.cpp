@@ -89,7 +89,9 @@ struct gem_handle {
     bool sort_path = true;              // passes of at least sort_min_points points run the sorted pipeline (gem_sort.hip)
     long long sort_min_points = 200000, sort_min_points_batch = 600000;      // single cloud / batch of sweeps (tools/dbg/crossover.py)
     bool walk_permute = true;           // k_fuse_walk: blocks take the tile rows centre-first
-    int  sort_passes = 0;               // 0 = by map size (two digits up to 2^20 cells, else three); 2 / 3 force it
+    int  sort_passes = 0;               // 0 = by map size and form (sort_geometry); 1 / 2 / 3 force it
+    bool fast_laser = true;             // frames that qualify use the zero-rotation-variance form of the laser variance (fill_frame; debug knob)
+    int  sort_form = 0;                 // 0 = batches of sweeps BLOCK-sorted (k_fuse_block), single clouds CELL-sorted (k_fuse_walk); 1 / 2 force cell / block
     int dbg_sweep = 0;                  // debug stamps of the dense path: which sweep (GEM_DBG_SWEEP)
     bool track_lowest = false;          // also maintain map_lowest in the fuse kernels (gem_set_lowest_tracking, for gem_raytracing)
     unsigned dense_min = 2048;          // records of one sweep in one 16x16 tile above which the tile is counting-sorted (k_fuse_list, dense path)
@@ -180,6 +182,30 @@ void fill_frame(const gem_handle* h, const gem_frame_params* p, FrameConst& f)
     f.sx = h->start[0];  f.sy = h->start[1];
     f.L = h->L; f.res = h->res;
     f.row0 = h->row0; f.row1 = h->row1;
+    // kModelLaserFast (gem_device.hpp, height_variance): the variance's rotation term vanishes and its last addend is a constant
+    f.beam_a = (float)f.sp[1]; f.beam_c = (float)f.sp[2];
+    f.t2 = 0.f; f.fast_laser = 0;
+    if (p && f.model == GEM_MODEL_LASER && h->fast_laser) {
+        const float min_r = (float)f.sp[0], vn = min_r * min_r;
+        const float c0 = f.Js[0] * 0.0f, c1 = f.Js[1] * 0.0f, c2 = f.Js[2] * vn;     // b2 = dot3(Js0, 0, Js1, 0, Js2, vn), GPU:293-298
+        const float b2 = c0 + (c1 + c2);
+        const float t2 = b2 * f.Js[2];
+        auto small = [](float v, float bound) { return std::isfinite(v) && std::fabs(v) <= bound; };
+        bool ok = t2 > 0.f && std::isfinite(t2) && small(f.beam_a, 1e6f) && small(f.beam_c, 1e6f);
+        for (int i = 0; i < 9; ++i) ok = ok && f.Q[i] == 0.0f && small(f.C[i], 1e6f) && small(f.Bs[i], 1e6f);
+        for (int i = 0; i < 3; ++i) ok = ok && small(f.Js[i], 1e6f) && small(f.P[i], 1e6f);
+        // the frame bounds the points it accepts: rows of T orthonormal within 1 %, translation / window / map extent below 1e9
+        for (int i = 0; i < 3 && ok; ++i)
+            for (int j = i; j < 3; ++j) {
+                double d = 0.0;
+                for (int k = 0; k < 3; ++k) d += (double)f.T[4 * i + k] * (double)f.T[4 * j + k];
+                ok = ok && std::fabs(d - (i == j ? 1.0 : 0.0)) <= 0.01;
+            }
+        for (int i = 0; i < 3; ++i) ok = ok && small(f.T[4 * i + 3], 1e9f);
+        ok = ok && std::isfinite(f.lower) && std::isfinite(f.upper) && std::fabs(f.lower) <= 1e9 && std::fabs(f.upper) <= 1e9;
+        ok = ok && small(f.cx, 1e9f) && small(f.cy, 1e9f) && (double)f.L * (double)f.res <= 1e9;
+        if (ok) { f.t2 = t2; f.fast_laser = 1; }
+    }
 }
 
 hipEvent_t get_event(gem_handle* h)
@@ -217,6 +243,7 @@ void fold_events(gem_handle* h)
             else if (ep.kind == 9) { h->stats.ms_walk += ms; h->stats.launches_walk++; }
             else                   { h->stats.ms_sort[ep.kind - 3] += ms; if (ep.kind == 3) h->stats.launches_sort++; }
         }
+        else (void)hipGetLastError();      // (a pair that was never recorded: not an error of the next launch)
         h->pool.push_back(ep);
     }
     h->events.clear();
@@ -308,34 +335,47 @@ static void release_streams(int device, const StreamSet& set)
 
 static int ceil_log2(int v) { int b = 0; while ((1 << b) < v) ++b; return b; }
 
-// the key geometry of the sorted pipeline for this map, and whether a pass of `n_sweeps` sweeps fits the 32-bit record key
-struct SortGeometry { int tiles_per_row, T, id_bits, n_passes, dshift[3], dbits[3], dbins[3]; bool ok; };
-SortGeometry sort_geometry(const gem_handle* h, int n_sweeps)
+// The key geometry of the sorted pipelines for this map, and whether a pass of `n_sweeps` sweeps fits the 32-bit record key.
+// block_form: the digits cover the BLOCK id (id >> 8) only and k_fuse_block orders a block's records by cell itself; otherwise
+// they cover the whole id and k_fuse_walk streams every cell's run (gem_kernels.hpp).
+struct SortGeometry { int tiles_per_row, T, id_bits, n_passes, dshift[3], dbits[3], dbins[3]; bool block_form, ok; };
+SortGeometry sort_geometry(const gem_handle* h, int n_sweeps, bool block_form)
 {
     SortGeometry g{};
+    g.block_form = block_form;
     g.tiles_per_row = (h->L + 31) / 32;
     g.T = g.tiles_per_row * g.tiles_per_row;
     g.id_bits = 10 + std::max(1, ceil_log2(g.T));                 // id = tile << 10 | cell in tile
+    const int lo = block_form ? 8 : 0;                            // first bit the digits cover
+    const long long values = (((long long)g.T) << 10) >> lo;      // ids / block ids in use: 0 .. values - 1
     // Digits of about equal width, at most ten bits: the records of a (chunk, bin) leave k_sort_scatter as one run, and with
-    // thousands of bins a 4096-record chunk has one or two records per run -- no coalescing left (the 2400^2 map in two passes of
-    // 2048 / 2813 bins: 206 + 158 us; in three passes of 256 / 256 / 88 bins: see DESIGN.md).
-    g.n_passes = h->sort_passes ? h->sort_passes : (g.id_bits <= 20 ? 2 : 3);
-    int shift = 0;
+    // thousands of bins a 4096-record chunk has one or two records per run -- no coalescing left (cell-sorted, the 2400^2 map in
+    // two passes of 2048 / 2813 bins: 206 + 158 us; in three passes of 256 / 256 / 88 bins: see DESIGN.md).  Block ids are
+    // different: consecutive points of a scan fall into few blocks, the runs are long whatever the number of bins, and a map of
+    // up to kOnePassMaxBins blocks (600^2: 1444) is sorted by ONE pass.
+    if (h->sort_passes) g.n_passes = h->sort_passes;
+    else if (block_form) g.n_passes = values <= kOnePassMaxBins ? 1 : (g.id_bits - lo <= 20 ? 2 : 3);
+    else g.n_passes = g.id_bits <= 20 ? 2 : 3;
+    int shift = lo;
     for (int i = 0; i < g.n_passes; ++i) {
         const int left = g.n_passes - i;
         // (rounded down: the lowest digit sees the records in input order -- every bin in use, a run per bin and chunk -- and pays
-        //  for its bins; the higher digits see them sorted by the lower ones, longer runs.  600^2: 512 x 722 bins 28.7 + 26.4 us,
-        //  1024 x 361 37.7 + 21.4, 256 x 1444 27.6 + 38.8)
+        //  for its bins; the higher digits see them sorted by the lower ones, longer runs.  Cell-sorted 600^2: 512 x 722 bins
+        //  28.7 + 26.4 us, 1024 x 361 37.7 + 21.4, 256 x 1444 27.6 + 38.8)
         int bits = (g.id_bits - shift) / left;
-        if (i == 0) bits = std::max(bits, 8);                     // the 256 cells of a k_fuse_walk workgroup never straddle a bin of the last pass
+        if (i == 0 && !block_form) bits = std::max(bits, 8);      // the 256 cells of a k_fuse_walk workgroup never straddle a bin of the last pass
         if (i == g.n_passes - 1) bits = g.id_bits - shift;
+        bits = std::max(bits, 1);
         g.dshift[i] = shift; g.dbits[i] = bits;
         g.dbins[i] = i == g.n_passes - 1 ? (int)(((((long long)g.T) << 10) - 1) >> shift) + 1 : 1 << bits;
         shift += bits;
     }
     const long long max_sweeps = std::min<long long>(512, (1ll << (32 - g.id_bits)) - 1);     // the sweep field is never all ones
-    g.ok = g.id_bits <= 26 && n_sweeps <= max_sweeps && g.dshift[g.n_passes - 1] >= 8;
-    for (int i = 0; i < g.n_passes; ++i) g.ok = g.ok && g.dbins[i] <= kSortMaxBins && g.dbits[i] >= 1;
+    g.ok = g.id_bits <= 26 && n_sweeps <= max_sweeps && g.dshift[g.n_passes - 1] >= 8 && shift == g.id_bits;
+    for (int i = 0; i < g.n_passes; ++i) {
+        g.ok = g.ok && g.dbins[i] <= kSortMaxBins && g.dbits[i] >= 1;
+        g.ok = g.ok && sort_shape(g.dbins[i], true).lds <= 160 * 1024;                      // what launch_sort checks (a forced pass count may not fit)
+    }
     return g;
 }
 
@@ -406,7 +446,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     for (int i = 0; i < geo.n_passes; ++i) { o_seg[i] = o_next; o_next += (size_t)geo.dbins[i] * 16; }
     const size_t o_total = o_next, o_base = (o_total + 4 + 15) & ~(size_t)15;
     const size_t o_segcnt = (o_base + ((size_t)geo.dbins[geo.n_passes - 1] + 1) * 4 + 15) & ~(size_t)15;
-    if ((rc = ensure(h, pb.s_misc, o_segcnt + (size_t)NC1 * 16))) return rc;
+    if ((rc = ensure(h, pb.s_misc, o_segcnt + (size_t)NC1 * kSortSegsPerChunk * 4))) return rc;
     // the walk of pass p-2 has read these buffers (host-side wait, see run_pipeline)
     if (overlap && pb.fuse_recorded) GEM_HIP(h, hipEventSynchronize(pb.fuse_done));
 
@@ -483,6 +523,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     wa.center_tr = ((h->L / 2 + h->start[0]) % h->L) >> 5;
     wa.T = T; wa.tiles_per_row = geo.tiles_per_row; wa.L = h->L; wa.row0 = h->row0; wa.row1 = h->row1;
     wa.id_bits = geo.id_bits; wa.bin_shift = geo.dshift[geo.n_passes - 1]; wa.n_sweeps = in.n_sweeps;
+    wa.exact_bins = (geo.block_form && geo.n_passes == 1) ? 1 : 0;
     wa.mahal = h->cfg.mahalanobis_threshold; wa.var_floor = h->cfg.variance_floor;
     wa.dense = dense ? 1 : 0;
     wa.n_pending = h->n_pending;
@@ -497,16 +538,21 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     if (h->counting) GEM_HIP(h, hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
     {
         // (a third pass is accounted with the second: count / scan / scatter of the higher digits)
-        const bool three = geo.n_passes == 3;
-        Timed t0(h, 3), t1(h, 4), t2(h, 5), t3(h, 6), t4(h, 7), t5(h, 8), t6(h, three ? 6 : -1), t7(h, three ? 7 : -1), t8(h, three ? 8 : -1);
+        // (event pairs only for the kernels that are launched: the elapsed time of a pair that was never recorded is an error)
+        const bool two = geo.n_passes >= 2, three = geo.n_passes == 3;
+        Timed t0(h, 3), t1(h, 4), t2(h, 5), t3(h, two ? 6 : -1), t4(h, two ? 7 : -1), t5(h, two ? 8 : -1), t6(h, three ? 6 : -1), t7(h, three ? 7 : -1), t8(h, three ? 8 : -1);
         const LaunchEvents ev[9] = {t0.events(), t1.events(), t2.events(), t3.events(), t4.events(), t5.events(), t6.events(), t7.events(), t8.events()};
         // clouds whose frames all use the laser model (the reference's only GPU model, GPU:403-408) take the instantiation without
         // the camera models' double-precision code
         int src = in.src;
         if (src == 0) {
-            bool laser = true;
-            for (int s = 0; s < in.n_sweeps && laser; ++s) laser = in.params[s].sensor_model == GEM_MODEL_LASER;
-            if (laser) src = 2;
+            bool laser = true, fast = true;
+            for (int s = 0; s < in.n_sweeps && laser; ++s) {
+                laser = in.params[s].sensor_model == GEM_MODEL_LASER;
+                FrameConst fc; fill_frame(h, &in.params[s], fc);
+                fast = fast && fc.fast_laser != 0;
+            }
+            if (laser) src = fast ? 4 : 2;                       // 4: every frame's rotation variance is zero (height_variance, kModelLaserFast)
         }
         GEM_HIP(h, launch_sort(sbin, sa, src, with_src, ev));
     }
@@ -543,7 +589,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
         GEM_HIP(h, hipEventRecord(pb.bin_done, sbin));
         GEM_HIP(h, hipStreamWaitEvent(h->stream, pb.bin_done, 0));
     }
-    { Timed t(h, 9); GEM_HIP(h, launch_walk(h->stream, wa, attr, t.events())); }
+    { Timed t(h, 9); GEM_HIP(h, geo.block_form ? launch_block_walk(h->stream, wa, attr, t.events()) : launch_walk(h->stream, wa, attr, t.events())); }
     if (overlap) { GEM_HIP(h, hipEventRecord(pb.fuse_done, h->stream)); pb.fuse_recorded = true; }
     h->n_pending = 0;
     h->floor_dirty = false;
@@ -564,7 +610,13 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
         if (in0.src == 0 && in0.rgb) attr = 1;
         if (in0.src == 1 && in0.f_R && in0.f_G && in0.f_B && in0.f_I) attr = 2;
         if (h->track_lowest) attr |= 4;
-        const SortGeometry geo = sort_geometry(h, in0.n_sweeps);
+        // Batches of sweeps -- a few records per cell and sweep, every batch of a block's records spread over its cells -- take the
+        // block-sorted form (one counting-sort pass for the 600^2 map instead of two, no per-cell order in HBM at all); a single
+        // dense cloud (a depth image: a quarter of its points in one block, hundreds per cell, image row by image row) needs the
+        // whole chip to order it by cell: the cell-sorted form.
+        const bool block_form = h->sort_form == 2 || (h->sort_form == 0 && in0.n_sweeps > 1);
+        SortGeometry geo = sort_geometry(h, in0.n_sweeps, block_form);
+        if (!geo.ok) geo = sort_geometry(h, in0.n_sweeps, !block_form);
         if (geo.ok) return run_sort_pipeline(h, in0, attr, geo);
     }
     // A big single cloud becomes a batch of sweeps with one frame: every tile then only reads the descriptor
@@ -1338,14 +1390,14 @@ static int colorize_device(gem_handle* h, const gem_camera* cam, int n, float* d
         if (i > 0) bins_hi = std::max(bins_hi, sa.dbins[i]);
         shift += bits;
     }
-    const size_t N = (size_t)n, NC = (N + 4095) / 4096;
+    const size_t N = (size_t)n, NC = (N + kSortChunkRecords - 1) / kSortChunkRecords;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~(size_t)255; return at; };
     const size_t o_hv1 = take(N * 8 + 64), o_hv2 = take(N * 8 + 64), o_key1 = take(N * 4 + 64), o_key2 = take(N * 4 + 64);
     const size_t o_cnt1 = take(NC * sa.dbins[0] * 4), o_cnt2 = take(NC * bins_hi * 4 + 16);
     size_t o_seg[3] = {0, 0, 0};
     for (int i = 0; i < sa.n_passes; ++i) o_seg[i] = take((size_t)sa.dbins[i] * 16);
-    const size_t o_total = take(16), o_base = take(((size_t)sa.dbins[sa.n_passes - 1] + 1) * 4), o_segcnt = take(NC * 16);
+    const size_t o_total = take(16), o_base = take(((size_t)sa.dbins[sa.n_passes - 1] + 1) * 4), o_segcnt = take(NC * kSortSegsPerChunk * 4);
     const size_t o_first = take((size_t)pixels * 4), o_pix = take(N * 4), o_link = take(N * 4);
     int rc;
     if ((rc = ensure(h, h->color, o))) return rc;
@@ -1505,7 +1557,9 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     }
     else if (k == "sort_ring")          { if (value < 2 || value > 4) return fail(h, GEM_ERR_INVALID, "sort_ring: 2..4"); h->sort_ring = (int)value; }
     else if (k == "sort_streams")       { if (value != 1 && value != 2) return fail(h, GEM_ERR_INVALID, "sort_streams: 1 or 2"); h->sort_streams = (int)value; }
-    else if (k == "sort_passes")        { if (value != 0 && value != 2 && value != 3) return fail(h, GEM_ERR_INVALID, "sort_passes: 0, 2 or 3"); h->sort_passes = (int)value; }
+    else if (k == "sort_passes")        { if (value < 0 || value > 3) return fail(h, GEM_ERR_INVALID, "sort_passes: 0..3"); h->sort_passes = (int)value; }
+    else if (k == "fast_laser")         h->fast_laser = value != 0;
+    else if (k == "sort_form")          { if (value < 0 || value > 2) return fail(h, GEM_ERR_INVALID, "sort_form: 0 (by pass), 1 (cell-sorted), 2 (block-sorted)"); h->sort_form = (int)value; }
     else return fail(h, GEM_ERR_INVALID, "gem_debug_set: unknown key");
     return GEM_OK;
 }
@@ -1614,7 +1668,7 @@ int gem_allgather_layers(gem_handle* h, int with_attributes)
 static int shard_checks(gem_handle* h, int n_global_sweeps, SortGeometry* geo)
 {
     if (h->track_lowest) return fail(h, GEM_ERR_INVALID, "sharded path: lowest tracking is not supported (use the replicated path)");
-    *geo = sort_geometry(h, n_global_sweeps);
+    *geo = sort_geometry(h, n_global_sweeps, true);            // block-sorted: a strip's records are one contiguous range, a block's too
     if (!geo->ok) return fail(h, GEM_ERR_INVALID, "sharded path: map or batch too large for the record key");
     return GEM_OK;
 }
@@ -1711,7 +1765,7 @@ static int shard_fuse_locked(gem_handle* h, int n_src, const void* const* d_hv, 
         wa.var_updates = dv;
     }
     if (h->counting) GEM_HIP(h, hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
-    { Timed t(h, 9); GEM_HIP(h, launch_walk(h->stream, wa, 0, t.events())); }
+    { Timed t(h, 9); GEM_HIP(h, launch_block_walk(h->stream, wa, 0, t.events())); }
     h->n_pending = 0;
     h->floor_dirty = false;
     h->main_reads_pb = true;

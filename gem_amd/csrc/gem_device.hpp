@@ -41,7 +41,12 @@ struct FrameConst {
     float  res;
     // strip of storage rows owned by this device (multi-GPU tiling); whole map = [0, L)
     int    row0, row1;
+    // kModelLaserFast (see height_variance): the laser model's constants as floats and the point-independent term of the variance
+    float  beam_a, beam_c, t2;
+    int    fast_laser;       // 1: the frame qualifies for kModelLaserFast (fill_frame decides)
 };
+
+constexpr int kModelLaserFast = 4;   // template argument only: the laser model of a frame whose rotation variance is zero
 
 // Lidar -> image projection of the input colourisation (EMg.cpp:321-345: P_lidar2img = T.camera (3x4) * T.lidar (4x4), in
 // double), by value like FrameConst.
@@ -157,9 +162,24 @@ __device__ __forceinline__ void sensor_variances(const FrameConst& f, float x, f
 }
 
 // GPU:403-425
+// MODEL == kModelLaserFast: the reference hard-zeroes rotationVariance (SPB.cpp:202-204), and with Sigma_q = 0 the first term
+// Jq Sigma_q Jq^T -- q = C_SB^T p, S = skew(q) + B_r_BS_skew, Jq = P S, three dot products with Sigma_q's columns, one with Jq:
+// 45 of the projection's instructions -- is a sum of products with zero: +0 or -0 whenever Jq is finite.  The second term is
+// Js diag(vl, vl, vn) Js^T = ((Js0 vl) Js0 + (Js1 vl) Js1) + (Js2 vn) Js2 up to the signs of zeros, and its last addend t2 is a
+// constant of the frame (vn = min_r^2).  If t2 > 0 the sum is positive, a zero of either sign added to it changes nothing, and
+// the variance is exactly this expression.  fill_frame() checks what that needs: Sigma_q = 0, t2 > 0, finite constants, and a
+// frame that bounds the points it accepts (orthonormal rotation, finite height window: a point inside the map and the window
+// then has |p| < 1e10, so Jq is finite) -- every point that leaves a record gets the reference's variance bit for bit; a
+// frame that does not qualify takes the generic instantiation.
 template <int MODEL = -1>
 __device__ __forceinline__ float height_variance(const FrameConst& f, float x, float y, float z, int orig)
 {
+    if constexpr (MODEL == kModelLaserFast) {
+        const float d = sqrtf(dot3(x, x, y, y, z, z));                  // GPU:404
+        const float t = f.beam_c + f.beam_a * d;
+        const float vl = t * t;                                         // GPU:407
+        return ((f.Js[0] * vl) * f.Js[0] + (f.Js[1] * vl) * f.Js[1]) + f.t2;
+    }
     float vn, vl;
     sensor_variances<MODEL>(f, x, y, z, orig, vn, vl);
     const float q0 = dot3(f.C[0], x, f.C[1], y, f.C[2], z);

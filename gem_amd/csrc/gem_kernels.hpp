@@ -89,9 +89,16 @@ struct FuseArgs {
     unsigned long long* dbg;           // optional: [T][16] cycle-counter stamps of thread 0 (profiling aid)
 };
 
-// ---- the sorted pipeline of big passes (gem_sort.hip) ------------------------------------------------------------------------
+// ---- the sorted pipelines of big passes (gem_sort.hip) -----------------------------------------------------------------------
 // Record key, 32 bits:  id | sweep << id_bits,  id = tile << 10 | cell in its 32x32 tile  (id_bits = 10 + bits of the tile index).
-// The id is sorted by two or three stable counting-sort passes over digits of about equal width, lowest digit first.
+// A BLOCK is a quarter of a tile: eight rows of 32 cells, block id = id >> 8, cell in its block = id & 255.
+// Two forms (gem_capi.cpp picks one per pass, both give the same map):
+//   CELL-sorted : stable counting-sort passes over digits that cover the whole id, lowest digit first; every cell's records end
+//                 up as one contiguous run, k_fuse_walk streams the runs (single dense clouds: a depth image's cells hold hundreds
+//                 of points each, the whole chip has to take part in sorting them);
+//   BLOCK-sorted: the digits cover the block id only (ONE pass for maps of up to kOnePassMaxBins blocks); inside a block the
+//                 records stay in input order and k_fuse_block orders them by cell in LDS, a batch at a time (batches of sweeps,
+//                 aggregated clouds: a few records per cell and sweep).
 struct SortArgs {
     FrameConst frame0;                 // single-sweep call: the frame, by value
     const FrameConst* frames;          // [n_sweeps]    (batched call)
@@ -151,7 +158,9 @@ struct WalkArgs {
     const int* f_R; const int* f_G; const int* f_B; const float* f_I;
     unsigned long long* counters;      // optional: [1] += distinct touched cells (per sweep unless count_per_pass)
     int   count_per_pass;
-    // multi-GPU strip owner (gem_add_sharded_device): the sorted records received from every rank, walked in rank order
+    // k_fuse_block only:
+    int   exact_bins;                  // 1: the last pass's bins ARE the blocks (one-pass sort): bin_base gives a block's records without a search
+    // multi-GPU strip owner (gem_add_sharded_device): the block-sorted records received from every rank, taken in rank order
     int   n_src;                       // <= 1: the single source above (hv / key / src, searched through bin_base)
     const uint2* src_hv[kMaxRanks]; const uint32_t* src_key[kMaxRanks]; uint32_t src_n[kMaxRanks];
 };
@@ -160,8 +169,11 @@ struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };   // option
 struct SortShape { int nt, chunk; size_t lds; };
 SortShape  sort_shape(int bins, bool attr);   // workgroup shape of a pass with that many bins
 hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, const LaunchEvents ev[9]);   // project, scan, scatter | count, scan, scatter | (count, scan, scatter)
-hipError_t launch_walk(hipStream_t st, const WalkArgs& a, int flags, LaunchEvents ev);
+hipError_t launch_walk(hipStream_t st, const WalkArgs& a, int flags, LaunchEvents ev);                    // cell-sorted records
+hipError_t launch_block_walk(hipStream_t st, const WalkArgs& a, int flags, LaunchEvents ev);              // block-sorted records
+constexpr int kOnePassMaxBins = 2048;  // block-sorted: maps of up to this many blocks are sorted by ONE counting-sort pass
 hipError_t launch_strip_bounds(hipStream_t st, const uint32_t* keys, const uint32_t* n_records, int id_bits, const uint32_t* ids, uint32_t* out, int n);
+constexpr int kSortChunkRecords = 4096, kSortSegsPerChunk = 4;   // records per counting-sort chunk; 1024-point wave segments per pass-1 chunk (seg_cnt words)
 constexpr int kSortMaxBins = 8000;     // bins per pass the sorted pipeline handles (LDS of k_sort_scatter)
 
 hipError_t launch_project(hipStream_t st, const FrameConst& fc, int n, float* x, float* y, float* z, const int* orig,

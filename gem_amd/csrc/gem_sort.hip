@@ -40,7 +40,8 @@
 
 namespace gem {
 
-constexpr int kSortChunk = 4096;                 // records per chunk of every pass (its sorted copy is staged in LDS)
+constexpr int kSortChunk = kSortChunkRecords;    // records per chunk of every pass (its sorted copy is staged in LDS)
+static_assert(kSortChunk == kSortSegsPerChunk * 1024, "k_sort_project: four waves of 1024 points per chunk, one seg_cnt word each");
 constexpr uint32_t kKeyInvalid = 0xffffffffu;   // key of a rejected / outside point in the input-ordered record arrays
 
 // ------------------------------------------------------------------------------------------
@@ -48,7 +49,8 @@ constexpr uint32_t kKeyInvalid = 0xffffffffu;   // key of a rejected / outside p
 // ------------------------------------------------------------------------------------------
 struct Binned { bool valid; uint32_t id; float h, v; bool colour_ok; };
 
-// SRC: 0 = XYZI cloud, sensor model taken from the frame; 2 = XYZI cloud, every frame uses the laser model; 1 = Fuse()'s arrays;
+// SRC: 0 = XYZI cloud, sensor model taken from the frame; 2 = XYZI cloud, every frame uses the laser model; 4 = the same and every
+//      frame's rotation variance is zero (kModelLaserFast, gem_device.hpp); 1 = Fuse()'s arrays;
 //      3 = XYZI cloud binned by camera pixel (the input colourisation, k_color_* below)
 template <int SRC>
 __device__ __forceinline__ Binned bin_one(const SortArgs& a, const FrameConst& fc, const float4& p, long long i, int orig_fallback)
@@ -61,7 +63,8 @@ __device__ __forceinline__ Binned bin_one(const SortArgs& a, const FrameConst& f
     }
     int row, col; float h, v; bool colour_ok = false;
     if (SRC != 1) {
-        const Projected r = SRC == 2 ? project_point<0>(fc, p.x, p.y, p.z, 0)
+        const Projected r = SRC == 4 ? project_point<kModelLaserFast>(fc, p.x, p.y, p.z, 0)
+                          : SRC == 2 ? project_point<0>(fc, p.x, p.y, p.z, 0)
                                      : project_point<-1>(fc, p.x, p.y, p.z, a.orig ? a.orig[i] : orig_fallback);
         row = r.row; col = r.col; h = r.h; v = r.var;
         if (a.rgb) {
@@ -111,7 +114,7 @@ __device__ __forceinline__ ChunkRange chunk_range(const int* __restrict__ sweep_
 // (256-thread workgroups whatever the chunk size: the projection needs ~100 VGPRs, and five light workgroups per CU hide its
 //  load latency better than one of 1024 threads)
 template <int SRC>
-__global__ __launch_bounds__(256, (SRC == 2 ? 4 : 1)) void k_sort_project(SortArgs a)
+__global__ __launch_bounds__(256, (SRC == 4 ? 4 : (SRC == 2 ? 3 : 1))) void k_sort_project(SortArgs a)
 {
     constexpr int NT = 256, CH = kSortChunk, K = CH / NT;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_sort[];
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(256, (SRC == 2 ? 4 : 1)) void k_sort_project(SortAr
     const uint64_t lt = lanemask_lt();
     uint32_t kept = 0;                                                 // wave-uniform
     const uint32_t sweep_bits = (uint32_t)(cr.sweep + a.sweep_id0) << a.id_bits;   // (a shard of a multi-GPU batch numbers its sweeps globally)
-    const uint32_t d0mask = (1u << a.dbits[0]) - 1u;
+    const uint32_t d0mask = (1u << a.dbits[0]) - 1u, d0shift = (uint32_t)a.dshift[0];
     __syncthreads();
     // blocks of eight points: the loads of a block are in flight together, then each point is projected, stored and counted
     for (int k0 = 0; k0 < K; k0 += 8) {
@@ -146,17 +149,30 @@ __global__ __launch_bounds__(256, (SRC == 2 ? 4 : 1)) void k_sort_project(SortAr
             Binned b; b.valid = false;
             if (i < cr.end) b = bin_one<SRC>(a, fc, SRC != 1 ? p[k] : make_float4(0.f, 0.f, 0.f, 0.f), i, (int)i + cr.orig0);
             const uint64_t m = __ballot(b.valid);
+            const uint32_t bin = (b.id >> d0shift) & d0mask;
             if (b.valid) {
                 const long long at = seg0 + kept + (uint32_t)__popcll(m & lt);
                 a.key_a[at] = b.id | sweep_bits;
                 a.hv_a[at] = make_uint2(__float_as_uint(b.h), __float_as_uint(b.v));
                 if (a.src_a) a.src_a[at] = (uint32_t)i | (b.colour_ok ? 0x80000000u : 0u);  // source point; bit 31: R, G, B, intensity all non-zero
-                atomicAdd(&hist[b.id & d0mask], 1u);
             }
+            // Histogram.  Consecutive points of a scan fall into a few bins when the digit is a coarse one (the blocks of the
+            // block-sorted form): 64 lanes adding 1 to one LDS word take 64 turns, so the wave first counts the bins of its leading
+            // lanes by ballot -- one add per bin -- and the lanes still unmatched after three rounds add for themselves.
+            uint64_t rem = m;
+#pragma unroll 1
+            for (int it = 0; it < 3 && rem != 0 && d0shift != 0u; ++it) {   // wave-uniform
+                const int lead = __ffsll((unsigned long long)rem) - 1;
+                const uint32_t kb = (uint32_t)__builtin_amdgcn_readlane((int)bin, lead);
+                const uint64_t same = __ballot(b.valid && bin == kb) & rem;
+                if ((tid & 63) == lead) atomicAdd(&hist[kb], (uint32_t)__popcll(same));
+                rem &= ~same;
+            }
+            if ((rem >> (tid & 63)) & 1ull) atomicAdd(&hist[bin], 1u);
             kept += (uint32_t)__popcll(m);
         }
     }
-    if ((tid & 63) == 0) a.seg_cnt[(size_t)chunk * 4 + (tid >> 6)] = kept;
+    if ((tid & 63) == 0) a.seg_cnt[(size_t)chunk * kSortSegsPerChunk + (tid >> 6)] = kept;
     __syncthreads();
     for (int i = tid; i < a.dbins[0]; i += NT) a.cnt[0][(size_t)chunk * a.dbins[0] + i] = hist[i];
 }
@@ -234,31 +250,18 @@ __global__ __launch_bounds__(1024) void k_sort_scan(uint32_t* __restrict__ cnt, 
     }
 }
 
-// Stable rank of this lane's item among the items of the same bin that precede it in the wave's share of the chunk: the
-// wave's cursor of the bin (LDS, private to the wave: its LDS operations execute in order) carries the count from step to
-// step; inside a step the lanes of a bin find each other THROUGH THE LDS: every lane stores its number into the wave's slot of
-// its bin (whichever store lands last names the group), reads the name back, ORs its bit into the wave's 64-bit mask of that
-// name and reads the mask: the lanes of the same bin.  Five LDS instructions and a handful of VALU ones for any digit width --
-// matching the digits by one ballot per bit (wave_peers) costs six VALU instructions per bit, 60 of this kernel's 185 per
-// record with ten-bit digits, and this kernel is bound by VALU issue.
-__device__ __forceinline__ uint32_t wave_rank_step(bool valid, uint32_t bin, uint32_t* wcur, uint8_t* wslot, unsigned long long* wpm,
-                                                   uint64_t lt, unsigned long long mybit)
-{
-    const uint32_t lane = (uint32_t)lane_id();
-    // relaxed atomics, not plain accesses: the slot is read back to see ANOTHER lane's store (the compiler forwards this lane's own
-    // store to a plain load -- every lane then is its own group and the order inside a bin is left to the order in which the LDS
-    // happens to apply the lanes' cursor atomics), and the mask after the other lanes' ORs
-    if (valid) __hip_atomic_store(&wslot[bin], (uint8_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const uint32_t name = valid ? (uint32_t)__hip_atomic_load(&wslot[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : lane;
-    if (valid) atomicOr(&wpm[name], mybit);
-    const uint64_t peers = valid ? (uint64_t)__hip_atomic_load(&wpm[name], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
-    if (valid && name == lane) __hip_atomic_store(&wpm[name], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // for the next step (after every lane's read: in order)
-    const uint32_t rank = (uint32_t)__popcll(peers & lt);
-    uint32_t old = 0;
-    if (valid && rank == 0) old = atomicAdd(&wcur[bin], (uint32_t)__popcll(peers));
-    old = (uint32_t)__shfl((int)old, valid ? __ffsll((unsigned long long)peers) - 1 : (int)lane, 64);
-    return old + rank;
-}
+// Stable rank inside a wave's share of a chunk (k_sort_scatter, step 1).  The wave's cursor of a bin (LDS, private to the wave: a
+// wave's LDS operations execute in order) carries the count from step to step; inside a step the lanes of a bin have to find
+// each other.  Two ways:
+//   * THROUGH THE LDS (digits of scattered values: the low digits of the cell-sorted form): every lane stores its number into
+//     the wave's slot of its bin (whichever store lands last names the group), reads the name back, ORs its bit into the wave's
+//     64-bit mask of that name and reads the mask.  Five LDS instructions and a handful of VALU ones for any digit width --
+//     matching the digits by one ballot per bit (wave_peers) costs six VALU instructions per bit, and this kernel is bound by
+//     VALU issue.
+//   * BY BALLOT (COHERENT: the coarse digits of the block-sorted form, where the 64 consecutive records of a wave instruction
+//     fall into a handful of bins and 64 lanes hitting one LDS word would take 64 turns): one ballot per distinct bin, taken
+//     from the first lane still unmatched; a step with more than kFewBins distinct bins falls back to the LDS way.
+constexpr int kFewBins = 8;
 
 // words of LDS the ranking phase of k_sort_scatter needs: per wave a cursor per bin, a name byte per bin (+ 64), 64 masks
 __host__ __device__ constexpr size_t slot_words(int bins) { return (size_t)((bins + 3) / 4) + 16; }   // name bytes of the bins + 64 spare ones (lanes without a record)
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(NT) void k_sort_count(PassArgs a)
 // The chunk's records are ranked (stable), put into LDS in their sorted order and written out from there: consecutive threads
 // then write consecutive records of a bin -- runs of several records, 64-byte segments -- instead of 64 lanes writing 64
 // scattered 8-byte pieces (which cost 55 us for the 2.9 M records of C4 against 24 from LDS).
-template <int NT, bool ATTR>
+template <int NT, bool ATTR, bool COHERENT>
 __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void k_sort_scatter(PassArgs a)
 {
     constexpr int NW = NT / 64, CH = kSortChunk, K = CH / NT;
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void k_sort_scatter(PassAr
     // pass 1: the wave's 512 or 1024 positions lie in ONE 1024-slot segment of the chunk, whose first seg_cnt records are there
     // (k_sort_project); the later passes read dense arrays
     uint32_t seg_off = 0, seg_n = 0xffffffffu;
-    if (a.seg_cnt) { const uint32_t pos = (uint32_t)(w * (K * 64)); seg_off = pos & 1023u; seg_n = a.seg_cnt[(size_t)chunk * 4 + (pos >> 10)]; }
+    if (a.seg_cnt) { const uint32_t pos = (uint32_t)(w * (K * 64)); seg_off = pos & 1023u; seg_n = a.seg_cnt[(size_t)chunk * kSortSegsPerChunk + (pos >> 10)]; }
     uint2 hv[K]; uint32_t key[K], src[K], rk[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -344,17 +347,42 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void k_sort_scatter(PassAr
         // chunk instead of three per step.
         uint32_t bin[K], name[K]; uint64_t peers[K]; bool valid[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            valid[k] = key[k] != kKeyInvalid; bin[k] = (key[k] >> a.shift) & a.mask;
-            uint8_t* slot = wslot + (valid[k] ? bin[k] : spare);       // no branch: the eight round trips overlap
-            __hip_atomic_store(slot, (uint8_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            name[k] = (uint32_t)__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        for (int k = 0; k < K; ++k) { valid[k] = key[k] != kKeyInvalid; bin[k] = (key[k] >> a.shift) & a.mask; }
+        if constexpr (COHERENT) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            if (valid[k]) atomicOr(&wpm[name[k]], mybit);
-            peers[k] = valid[k] ? (uint64_t)__hip_atomic_load(&wpm[name[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
-            if (valid[k] && name[k] == (uint32_t)lane) __hip_atomic_store(&wpm[name[k]], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int k = 0; k < K; ++k) {
+                uint64_t rem = __ballot(valid[k]);
+                peers[k] = 0ull;
+#pragma unroll 1
+                for (int it = 0; it < kFewBins && rem != 0; ++it) {    // wave-uniform
+                    const uint32_t kb = (uint32_t)__builtin_amdgcn_readlane((int)bin[k], __ffsll((unsigned long long)rem) - 1);
+                    const bool mine = valid[k] && bin[k] == kb;
+                    const uint64_t same = __ballot(mine);
+                    peers[k] = mine ? same : peers[k];
+                    rem &= ~same;
+                }
+                if (rem != 0) {                                        // wave-uniform: many bins in this step, through the LDS
+                    uint8_t* slot = wslot + (valid[k] ? bin[k] : spare);
+                    __hip_atomic_store(slot, (uint8_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t nm = (uint32_t)__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (valid[k]) atomicOr(&wpm[nm], mybit);
+                    peers[k] = valid[k] ? (uint64_t)__hip_atomic_load(&wpm[nm], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+                    if (valid[k] && nm == (uint32_t)lane) __hip_atomic_store(&wpm[nm], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                uint8_t* slot = wslot + (valid[k] ? bin[k] : spare);   // no branch: the eight round trips overlap
+                __hip_atomic_store(slot, (uint8_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                name[k] = (uint32_t)__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (valid[k]) atomicOr(&wpm[name[k]], mybit);
+                peers[k] = valid[k] ? (uint64_t)__hip_atomic_load(&wpm[name[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+                if (valid[k] && name[k] == (uint32_t)lane) __hip_atomic_store(&wpm[name[k]], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -384,7 +412,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void k_sort_scatter(PassAr
         uint32_t ex = block_exclusive_scan<NT>(sum, scratch, &chunk_records);
         // the bin's records in the whole pass / in the chunk segments before this chunk's (k_sort_scan)
         const int nc = a.n_dev ? (int)((end + CH - 1) / CH) : a.n_chunks;
-        const int seg = chunk / scan_seg_chunks(nc);
+        const int seg = chunk / max(1, scan_seg_chunks(nc));                 // (nc = 0: pass 1 kept nothing, workgroup 0 only publishes the bases)
         auto bin_sums = [&](int b, uint32_t& before) -> uint32_t {
             uint32_t t = 0; before = 0;
 #pragma unroll
@@ -400,7 +428,8 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void k_sort_scatter(PassAr
                 const uint32_t c = lbase[b];
                 uint32_t before; const uint32_t tb = bin_sums(b, before);
                 lbase[b] = ex;
-                delta[b] = gex + before + a.cnt[(size_t)chunk * bins + b] - ex;   // bin base + earlier segments + earlier chunks - local position
+                const uint32_t earlier = first < end ? a.cnt[(size_t)chunk * bins + b] : 0u;   // (an empty pass has no count rows)
+                delta[b] = gex + before + earlier - ex;                // bin base + earlier segments + earlier chunks - local position
                 if (a.bin_base && chunk == 0) a.bin_base[b] = gex;
                 ex += c; gex += tb;
             }
@@ -489,14 +518,10 @@ __global__ __launch_bounds__(kWalkNT) void k_fuse_walk(WalkArgs a)
     if ((tr << 5) >= a.row1 || (tr << 5) + 32 <= a.row0) return;       // a tile row outside this device's strip
     const uint32_t idmask = (1u << a.id_bits) - 1u;
     const uint32_t id0 = ((uint32_t)tile << 10) | ((uint32_t)q4 << 8); // the cell ids of this workgroup: id0 .. id0 + 255
-    uint32_t run_lo = 0, run_hi = 0;
-    if (a.n_src <= 1) {
-        // one source (the device's own sort): the records of these cells lie inside the run of the last pass's bin that
-        // holds id0 (256 divides the bin width)
-        const uint32_t bin = id0 >> a.bin_shift;
-        run_lo = a.bin_base[bin]; run_hi = a.bin_base[bin + 1];
-        if (run_lo == run_hi && !a.dense) return;
-    }
+    // the records of these cells lie inside the run of the last pass's bin that holds id0 (256 divides the bin width)
+    const uint32_t bin0 = id0 >> a.bin_shift;
+    const uint32_t run_lo = a.bin_base[bin0], run_hi = a.bin_base[bin0 + 1];
+    if (run_lo == run_hi && !a.dense) return;
 
     // ---- the thread's OWN cell (cell tid of the workgroup): its map values are fetched now, coalesced, in flight behind the search
     const int L = a.L;
@@ -576,11 +601,10 @@ __global__ __launch_bounds__(kWalkNT) void k_fuse_walk(WalkArgs a)
     //      widely (a LiDAR ring crosses some cells of a row and misses the next: on C4 the lanes of a wave were busy half of the
     //      time, 0.51 = sum of the runs / 64 x the longest; a depth image 0.57).  So the workgroup's cells are handed out in
     //      descending order of their run length -- wave 0 takes the 64 longest, the last wave the empty ones: 0.80 on C4 -- by a
-    //      counting sort over the run lengths (exact below 64, eight steps per octave above).  Several sources (multi-GPU strip
-    //      owner): every thread keeps its own cell, the sources' runs are not known together.
+    //      counting sort over the run lengths (exact below 64, eight steps per octave above).
     uint32_t c = (uint32_t)tid;
     bool have = false;
-    if (a.n_src <= 1) {
+    {
         have = find_bounds(a.key, run_lo, run_hi);
         sh_e[tid] = e_t; sh_s[tid] = s_t;
         if constexpr (LOWEST) sh_l[tid] = l_t;
@@ -604,13 +628,13 @@ __global__ __launch_bounds__(kWalkNT) void k_fuse_walk(WalkArgs a)
     const int row = (tr << 5) + (q4 << 3) + (int)(c >> 5), col = (tc << 5) + (int)(c & 31u);
     const bool owned = row >= a.row0 && row < a.row1 && col < L;
     const size_t g = owned ? (size_t)row * L + col : 0;
-    const float e0 = a.n_src <= 1 ? sh_e[c] : e_t, s0 = a.n_src <= 1 ? sh_s[c] : s_t;
+    const float e0 = sh_e[c], s0 = sh_s[c];
     size_t lgeo = 0; float lw = 0.0f, lw0 = 0.0f;
     if constexpr (LOWEST) {
         int gr = row - a.start0, gc = col - a.start1;
         gr += gr < 0 ? L : 0; gc += gc < 0 ? L : 0;
         lgeo = owned ? (size_t)gr * L + gc : 0;
-        lw0 = lw = a.n_src <= 1 ? sh_l[c] : l_t;
+        lw0 = lw = sh_l[c];
     }
 
     float ce = e0, cs = s0;
@@ -698,12 +722,7 @@ __global__ __launch_bounds__(kWalkNT) void k_fuse_walk(WalkArgs a)
     // Mapvar_update increments queued before this pass, then the one of sweep 0 (GPU:540-547)
     for (int k = 0; k < a.n_pending; ++k) if (cs != kInitVariance) cs += a.pending[k];
     if constexpr (HAS_VU) { if (cs != kInitVariance) cs += vu[0]; u1 = vu[min(1u, last_sw)]; }
-    if (a.n_src <= 1) {
-        if (have) walk_run(a.key, a.hv, a.src);
-    } else {
-        for (int sidx = 0; sidx < a.n_src; ++sidx)                     // rank order = input order
-            if (find_bounds(a.src_key[sidx], 0u, a.src_n[sidx])) walk_run(a.src_key[sidx], a.src_hv[sidx], nullptr);
-    }
+    if (have) walk_run(a.key, a.hv, a.src);
     if (__ballot(n_total != 0) == 0 && !a.dense) return;               // nothing reached this wave's cells and nothing is pending
     if constexpr (HAS_VU) advance(last_sw);
     if (cs < a.var_floor) cs = a.var_floor;                            // GPU:533-534, on every cell
@@ -711,6 +730,283 @@ __global__ __launch_bounds__(kWalkNT) void k_fuse_walk(WalkArgs a)
     if (owned) {
         // only what changed goes back (a pass touches a fraction of the cells; whole-tile write-backs were most of the write
         // traffic of the tile kernels)
+        if (__float_as_uint(ce) != __float_as_uint(e0)) a.elevation[g] = ce;
+        if (__float_as_uint(cs) != __float_as_uint(s0)) a.variance[g] = cs;
+        if constexpr (LOWEST) { if (__float_as_uint(lw) != __float_as_uint(lw0)) a.lowest[lgeo] = lw; }
+        if constexpr (ATTR != 0) {
+            if (wlast != 0xffffffffu) {                                // colour / intensity of the last taken point with all four non-zero (GPU:487-494)
+                if (ATTR == 1) {
+                    const uint32_t cc = a.rgb[wlast];
+                    a.intensity[g] = a.xyzi[wlast].w;
+                    a.colorR[g] = (int)((cc >> 16) & 0xff); a.colorG[g] = (int)((cc >> 8) & 0xff); a.colorB[g] = (int)(cc & 0xff);
+                } else {
+                    a.intensity[g] = a.f_I[wlast];
+                    a.colorR[g] = a.f_R[wlast]; a.colorG[g] = a.f_G[wlast]; a.colorB[g] = a.f_B[wlast];
+                }
+            }
+        }
+    }
+    if (a.counters) {                                                  // distinct touched cells: per pass, or summed over the sweeps
+        const uint32_t mine = COUNT_SWEEPS ? sweeps_seen : (n_total ? 1u : 0u);
+        const uint32_t s = wave_inclusive_scan(mine);
+        if (lane == 63 && s) atomicAdd(&a.counters[1], (unsigned long long)s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_fuse_block : BLOCK-sorted records -- one workgroup per block of 256 cells (eight rows of a tile), one thread per cell
+// ------------------------------------------------------------------------------------------
+// The sort has brought the records of a block together and left them in INPUT ORDER.  The workgroup takes them a batch of B at a
+// time (coalesced loads), orders the batch by cell in LDS with a stable counting sort over the 256 cells -- wave w ranks the w-th
+// contiguous share; the lanes of a wave instruction that hold the same cell find each other through a 64-bit OR mask per (wave,
+// cell), a per-(wave, cell) cursor carries the count from step to step (a wave's LDS operations execute in order) -- and then
+// every thread runs ITS cell's records of the batch, in input order, through the reference's recurrence (fuse_step,
+// GPU:480-531), the sweeps' variance increments (GPU:540-547) and floors (GPU:533-534) replayed in between; the cell state stays
+// in registers from batch to batch.  The chains are read from LDS: 64 lanes reading 64 unrelated runs cost a few bank conflicts
+// instead of 64 cache lines per load (k_fuse_walk), and no kernel of the sort ever orders records by cell.
+// A batch takes as long as its longest chain, so a block of R records takes sum over its batches of (longest chain in the batch):
+// close to the longest chain of the block when every batch spreads over the block's cells (LiDAR sweeps), far above it when a
+// batch holds a few cells' records only (the rows of a depth image) -- such passes take the CELL-sorted form (k_fuse_walk).
+// Several sources (multi-GPU strip owner): the block's records of every source, in rank order = input order, form one sequence.
+constexpr int kBlkNT = 256;
+
+template <int B, bool KEYED, bool ATTR>
+__host__ __device__ constexpr size_t block_walk_lds()
+{
+    return (size_t)B * 8 + (KEYED ? (size_t)B * 2 : 0) + (ATTR ? (size_t)B * 4 : 0)                     // staged batch
+           + (size_t)4 * 320 * 4 + (size_t)4 * 320 * 8 + (size_t)4 * 256 * 4;                           // cursors, masks, bases
+}
+
+template <int FLAGS, int MODE, int B>
+__global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
+{
+    constexpr int ATTR = FLAGS & 3;
+    constexpr bool LOWEST = (FLAGS & 4) != 0;
+    constexpr bool HAS_VU = (MODE & 1) != 0, COUNT_SWEEPS = (MODE & 2) != 0, KEYED = HAS_VU || COUNT_SWEEPS;
+    constexpr int NT = kBlkNT, NW = NT / 64, K = B / NT;
+    static_assert(NW == 4 && K >= 1 && K <= 32 && B <= 65536, "batch geometry");
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_sort[];
+    uint2* st_hv = reinterpret_cast<uint2*>(lds_sort);                                  // [B]   the batch, ordered by cell
+    unsigned long long* wpm = reinterpret_cast<unsigned long long*>(st_hv + B);         // [NW][320] who shares my cell in this wave instruction
+    uint32_t* wcur = reinterpret_cast<uint32_t*>(wpm + NW * 320);                       // [NW][320] records of (wave, cell) so far
+    uint32_t* cbase = wcur + NW * 320;                                                  // [NW][256] where the run of (wave, cell) starts in the batch
+    uint32_t* st_src = cbase + NW * 256;                                                // [B] (ATTR)
+    uint16_t* st_sw = reinterpret_cast<uint16_t*>(st_src + (ATTR ? B : 0));             // [B] (KEYED) the record's sweep
+    __shared__ uint32_t scratch[16];
+    __shared__ float vu[HAS_VU ? kWalkMaxSweeps : 1];
+    __shared__ uint32_t seg_first[kMaxRanks], seg_off[kMaxRanks + 1];                  // per source: first record of the block; prefix of the counts
+    __shared__ unsigned long long seg_key[kMaxRanks], seg_hv[kMaxRanks];
+    const int tid = (int)threadIdx.x, lane = lane_id(), w = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // block -> 256 cells, tile rows centre-first when all workgroups are resident at once (see k_fuse_walk)
+    int tile, q4 = (int)(blockIdx.x & 3);
+    {
+        const int tpr = a.tiles_per_row, rnk = (int)(blockIdx.x >> 2);
+        if (a.walk_order) {
+            const int bi = rnk / tpr, bj = rnk - bi * tpr;
+            const int oi = (bi & 1) ? -((bi + 1) >> 1) : (bi >> 1);
+            int r = a.center_tr + oi; r = r < 0 ? r + tpr : (r >= tpr ? r - tpr : r);
+            tile = r * tpr + bj;
+        } else tile = rnk;
+    }
+    const int tr = tile / a.tiles_per_row, tc = tile - tr * a.tiles_per_row;
+    if ((tr << 5) >= a.row1 || (tr << 5) + 32 <= a.row0) return;       // a tile row outside this device's strip
+    const uint32_t idmask = (1u << a.id_bits) - 1u;
+    const uint32_t id0 = ((uint32_t)tile << 10) | ((uint32_t)q4 << 8); // the cell ids of this block: id0 .. id0 + 255
+    const int n_src = a.n_src <= 1 ? 1 : a.n_src;
+
+    // ---- the thread's cell: its map values are fetched now, coalesced, in flight behind the search
+    const int L = a.L;
+    const int row = (tr << 5) + (q4 << 3) + (tid >> 5), col = (tc << 5) + (tid & 31);
+    const bool owned = row >= a.row0 && row < a.row1 && col < L;
+    const size_t g = owned ? (size_t)row * L + col : 0;
+    const float e0 = a.elevation[g], s0 = a.variance[g];
+    size_t lgeo = 0; float lw = 0.0f, lw0 = 0.0f;
+    if constexpr (LOWEST) {                                            // map_lowest is indexed by the GEOGRAPHIC cell (GPU:430)
+        int gr = row - a.start0, gc = col - a.start1;
+        gr += gr < 0 ? L : 0; gc += gc < 0 ? L : 0;
+        lgeo = owned ? (size_t)gr * L + gc : 0;
+        lw0 = lw = a.lowest[lgeo];
+    }
+    if constexpr (HAS_VU) for (int i = tid; i < a.n_sweeps; i += NT) vu[i] = a.var_updates[i];
+
+    // ---- where the block's records are in every source.  One-pass sort: the last pass's bins are the blocks.  Otherwise a
+    //      32-ary search, both ends at once (lanes 0-31 look for the first record of the block, lanes 32-63 for the first one
+    //      behind it), inside the run of the last pass's bin (own sort) or over the whole source (records received from a rank);
+    //      the waves share the sources out.
+    auto search = [&](const uint32_t* __restrict__ keys, uint32_t lo, uint32_t hi, uint32_t& first, uint32_t& end) {
+        const uint32_t target = id0 + (uint32_t)(lane >> 5) * (uint32_t)NT, l5 = (uint32_t)lane & 31u;
+        while (__ballot(lo < hi) != 0) {                               // wave-uniform
+            const uint32_t n = hi - lo, s = (n + 32u) / 33u;           // probes lo + j s + s - 1, j = 0..31
+            const uint32_t pos = lo + l5 * s + s - 1u;
+            const bool probe = lo < hi && pos < hi;
+            const uint32_t id = probe ? (keys[pos] & idmask) : 0xffffffffu;
+            const uint64_t bl = __ballot(probe && id < target);
+            const uint32_t k = (uint32_t)__popc((uint32_t)(bl >> (lane & 32)));   // a prefix of the probes: the block ids are sorted
+            if (lo < hi) { const uint32_t nl = lo + k * s; if (k < 32u) hi = min(hi, nl + s - 1u); lo = nl; }
+        }
+        first = (uint32_t)__shfl((int)lo, 0, 64);
+        end = (uint32_t)__shfl((int)lo, 32, 64);
+    };
+    uint32_t first0 = 0;                                               // single source: the block's first record (block-uniform)
+    if (a.n_src <= 1) {
+        const uint32_t bin = id0 >> a.bin_shift;
+        uint32_t end = a.bin_base[bin + 1];
+        first0 = a.bin_base[bin];
+        if (first0 == end && !a.dense) return;
+        if (!a.exact_bins && first0 != end) search(a.key, first0, end, first0, end);
+        if (tid == 0) { seg_off[0] = 0u; seg_off[1] = end - first0; }
+    } else {
+        for (int s = w; s < n_src; s += NW) {                          // wave-uniform
+            uint32_t first = 0, end = 0;
+            if (a.src_n[s]) search(a.src_key[s], 0u, a.src_n[s], first, end);
+            if (lane == 0) {
+                seg_first[s] = first; cbase[s] = end - first;         // (cbase: free until the first batch)
+                seg_key[s] = (unsigned long long)(uintptr_t)a.src_key[s]; seg_hv[s] = (unsigned long long)(uintptr_t)a.src_hv[s];
+            }
+        }
+        __syncthreads();
+        if (tid == 0) { uint32_t o = 0; for (int s = 0; s < n_src; ++s) { seg_off[s] = o; o += cbase[s]; } seg_off[n_src] = o; }
+    }
+    for (int i = tid; i < NW * 320; i += NT) { wcur[i] = 0u; wpm[i] = 0ull; }
+    __syncthreads();
+    const uint32_t R = seg_off[n_src];                                 // records of this block, all sources
+    if (R == 0 && !a.dense) return;                                    // block-uniform
+
+    // record q of the block's sequence -> its source arrays and its place in them
+    auto locate = [&](uint32_t q, const uint32_t*& kp, const uint2*& hp) -> uint32_t {
+        if (n_src <= 1) { kp = a.key; hp = a.hv; return first0 + q; }
+        int s = 0;
+        while (s + 1 < n_src && q >= seg_off[s + 1]) ++s;
+        kp = reinterpret_cast<const uint32_t*>((uintptr_t)seg_key[s]); hp = reinterpret_cast<const uint2*>((uintptr_t)seg_hv[s]);
+        return seg_first[s] + (q - seg_off[s]);
+    };
+
+    float ce = e0, cs = s0;
+    uint32_t cur = 0;                                                  // "inside sweep cur, its increment applied"
+    // From sweep `cur` to sweep `to`: the floor that ends every Fuse (GPU:533-534), then the next sweep's increment; the increment
+    // of the lane's NEXT sweep is kept in a register so that the common one-sweep gap costs no LDS round trip (see k_fuse_walk).
+    const uint32_t last_sw = (uint32_t)(a.n_sweeps > 0 ? a.n_sweeps - 1 : 0);
+    float u1 = 0.0f;
+    auto advance = [&](uint32_t to) {
+        while (cur < to) {
+            if (cs < a.var_floor) cs = a.var_floor;
+            ++cur;
+            if (cs != kInitVariance) cs += u1;
+            u1 = vu[min(cur + 1u, last_sw)];
+        }
+    };
+    uint32_t wlast = 0xffffffffu, sweeps_seen = 0, last_sweep = 0xffffffffu, n_total = 0;
+    // Mapvar_update increments queued before this pass, then the one of sweep 0 (GPU:540-547)
+    for (int k = 0; k < a.n_pending; ++k) if (cs != kInitVariance) cs += a.pending[k];
+    if constexpr (HAS_VU) { if (cs != kInitVariance) cs += vu[0]; u1 = vu[min(1u, last_sw)]; }
+
+    const uint64_t lt = lanemask_lt();
+    const unsigned long long mybit = 1ull << lane;
+    unsigned long long* wpm_w = wpm + w * 320;
+    uint32_t* wcur_w = wcur + w * 320;
+    uint2 hv[K]; uint32_t key[K], src[K];
+    // the wave's share of a batch of nb records: `steps` wave instructions of 64 consecutive records
+    auto load_batch = [&](uint32_t P, uint32_t nb) {
+        const uint32_t steps = (nb + (uint32_t)NT - 1u) / (uint32_t)NT;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            key[k] = kKeyInvalid;
+            if ((uint32_t)k < steps) {                                 // block-uniform
+                const uint32_t j = ((uint32_t)w * steps + (uint32_t)k) * 64u + (uint32_t)lane;
+                const uint32_t* kp; const uint2* hp;
+                const uint32_t at = locate(P + min(j, nb - 1u), kp, hp);
+                const uint32_t kk = kp[at]; hv[k] = hp[at];
+                if (ATTR) src[k] = a.src[at];
+                key[k] = j < nb ? kk : kKeyInvalid;
+            }
+        }
+    };
+
+    uint32_t parity = 0;
+    if (R) load_batch(0u, min(R, (uint32_t)B));
+    for (uint32_t P = 0; P < R; P += (uint32_t)B) {                    // block-uniform
+        const uint32_t nb = min(R - P, (uint32_t)B), steps = (nb + (uint32_t)NT - 1u) / (uint32_t)NT;
+        // ---- 1. stable rank of every record among the records of its cell in the wave's share.  Phase by phase: a wave's LDS
+        //         operations execute in order, so the K steps' round trips overlap.
+        uint32_t rk[K]; uint64_t peers[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            peers[k] = 0ull;
+            if ((uint32_t)k < steps) {
+                const bool valid = key[k] != kKeyInvalid;
+                unsigned long long* m = wpm_w + (valid ? (key[k] & 255u) : 256u + (uint32_t)lane);   // no branch: a lane without a record has a slot of its own
+                __hip_atomic_fetch_or(m, mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                peers[k] = (uint64_t)__hip_atomic_load(m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(m, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);           // for the next step (every lane of the group: the same value)
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            rk[k] = 0u;
+            if ((uint32_t)k < steps) {
+                const bool valid = key[k] != kKeyInvalid;
+                uint32_t* cp = wcur_w + (valid ? (key[k] & 255u) : 256u + (uint32_t)lane);
+                const uint32_t rank = (uint32_t)__popcll(peers[k] & lt);
+                const uint32_t old = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // before the group's first lane adds the group
+                if (valid && rank == 0u) __hip_atomic_fetch_add(cp, (uint32_t)__popcll(peers[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                rk[k] = old + rank;
+            }
+        }
+        __syncthreads();
+        // ---- 2. per cell: the waves in order, the cell's place in the batch
+        const uint32_t n0 = wcur[0 * 320 + tid], n1 = wcur[1 * 320 + tid], n2 = wcur[2 * 320 + tid], n3 = wcur[3 * 320 + tid];
+        wcur[0 * 320 + tid] = 0u; wcur[1 * 320 + tid] = 0u; wcur[2 * 320 + tid] = 0u; wcur[3 * 320 + tid] = 0u;
+        const uint32_t n = n0 + n1 + n2 + n3;
+        uint32_t all;
+        const uint32_t first = block_exclusive_scan_alt<NT>(n, scratch, parity++, &all);
+        cbase[0 * 256 + tid] = first; cbase[1 * 256 + tid] = first + n0; cbase[2 * 256 + tid] = first + n0 + n1; cbase[3 * 256 + tid] = first + n0 + n1 + n2;
+        __syncthreads();
+        // ---- 3. the batch in LDS, ordered by cell
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if ((uint32_t)k < steps && key[k] != kKeyInvalid) {
+                const uint32_t at = cbase[w * 256 + (key[k] & 255u)] + rk[k];
+                st_hv[at] = hv[k];
+                if constexpr (KEYED) st_sw[at] = (uint16_t)(key[k] >> a.id_bits);
+                if constexpr (ATTR != 0) st_src[at] = src[k];
+            }
+        }
+        __syncthreads();
+        // the next batch's records: in flight behind the chains
+        if (P + (uint32_t)B < R) load_batch(P + (uint32_t)B, min(R - P - (uint32_t)B, (uint32_t)B));
+        // ---- 4. the thread's cell: its n records of this batch, in input order
+        n_total += n;
+        const uint32_t nmax = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_max(n), 63);
+        const uint32_t lastp = n ? first + n - 1u : 0u;
+        uint2 nx = st_hv[min(first, lastp)];
+        uint32_t nx_sw = 0, nx_src = 0;
+        if constexpr (KEYED) nx_sw = st_sw[min(first, lastp)];
+        if constexpr (ATTR != 0) nx_src = st_src[min(first, lastp)];
+        for (uint32_t i = 0; i < nmax; ++i) {                          // wave-uniform
+            const uint2 r = nx; const uint32_t sw = nx_sw, sr = nx_src;
+            const uint32_t pn = min(first + i + 1u, lastp);
+            nx = st_hv[pn];
+            if constexpr (KEYED) nx_sw = st_sw[pn];
+            if constexpr (ATTR != 0) nx_src = st_src[pn];
+            const bool live = i < n;
+            const float h = __uint_as_float(r.x), v = __uint_as_float(r.y);
+            if constexpr (HAS_VU) { if (live) advance(sw); }
+            if constexpr (COUNT_SWEEPS) { if (live && sw != last_sweep) { ++sweeps_seen; last_sweep = sw; } }
+            float e2 = ce, s2 = cs;
+            const bool taken = fuse_step(e2, s2, h, v, a.mahal, a.var_floor);
+            const bool fl = live && (!LOWEST || h != -1.0f);           // GPU:482 (only LOWEST passes carry such records)
+            ce = fl ? e2 : ce; cs = fl ? s2 : cs;
+            if constexpr (LOWEST) { const float l2 = lowest_step(lw, h, v); lw = live ? l2 : lw; }
+            if constexpr (ATTR != 0) { if (fl && taken && (sr & 0x80000000u)) wlast = sr & 0x7fffffffu; }
+        }
+        // (the next round's ranking touches the cursors and masks only; its stores into the stage come after two barriers)
+    }
+    if (__ballot(n_total != 0) == 0 && !a.dense) return;               // nothing reached this wave's cells and nothing is pending
+    if constexpr (HAS_VU) advance(last_sw);
+    if (cs < a.var_floor) cs = a.var_floor;                            // GPU:533-534, on every cell
+
+    if (owned) {                                                       // only what changed goes back
         if (__float_as_uint(ce) != __float_as_uint(e0)) a.elevation[g] = ce;
         if (__float_as_uint(cs) != __float_as_uint(s0)) a.variance[g] = cs;
         if constexpr (LOWEST) { if (__float_as_uint(lw) != __float_as_uint(lw0)) a.lowest[lgeo] = lw; }
@@ -801,30 +1097,36 @@ static hipError_t launch_project(hipStream_t st, const SortArgs& a, int src, Lau
     const size_t lds = (size_t)a.dbins[0] * 4;
     if (src == 0)      GEM_LAUNCH((k_sort_project<0>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
     else if (src == 2) GEM_LAUNCH((k_sort_project<2>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
+    else if (src == 4) GEM_LAUNCH((k_sort_project<4>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
     else if (src == 3) GEM_LAUNCH((k_sort_project<3>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
     else               GEM_LAUNCH((k_sort_project<1>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
     return hipGetLastError();
 }
 
-template <int NT>
-static hipError_t launch_pass_nt(hipStream_t st, const PassArgs& p, bool attr, int grid, bool count, size_t lds, LaunchEvents ev)
+template <int NT, bool ATTR, bool COHERENT>
+static hipError_t launch_scatter(hipStream_t st, const PassArgs& p, int grid, size_t lds, LaunchEvents ev)
 {
-    hipError_t e;
+    const hipError_t e = lds_opt_in((const void*)k_sort_scatter<NT, ATTR, COHERENT>, lds);
+    if (e != hipSuccess) return e;
+    GEM_LAUNCH((k_sort_scatter<NT, ATTR, COHERENT>), dim3(grid), dim3(NT), lds, st, ev, p);
+    return hipGetLastError();
+}
+
+template <int NT>
+static hipError_t launch_pass_nt(hipStream_t st, const PassArgs& p, bool attr, bool coherent, int grid, bool count, size_t lds, LaunchEvents ev)
+{
     if (count) {
         GEM_LAUNCH((k_sort_count<NT>), dim3(grid), dim3(NT), (size_t)p.bins * 4, st, ev, p);
         return hipGetLastError();
     }
-    const void* fn = attr ? (const void*)k_sort_scatter<NT, true> : (const void*)k_sort_scatter<NT, false>;
-    if ((e = lds_opt_in(fn, lds)) != hipSuccess) return e;
-    if (attr) GEM_LAUNCH((k_sort_scatter<NT, true>), dim3(grid), dim3(NT), lds, st, ev, p);
-    else      GEM_LAUNCH((k_sort_scatter<NT, false>), dim3(grid), dim3(NT), lds, st, ev, p);
-    return hipGetLastError();
+    if (attr) return coherent ? launch_scatter<NT, true, true>(st, p, grid, lds, ev) : launch_scatter<NT, true, false>(st, p, grid, lds, ev);
+    return coherent ? launch_scatter<NT, false, true>(st, p, grid, lds, ev) : launch_scatter<NT, false, false>(st, p, grid, lds, ev);
 }
 
-static hipError_t launch_pass(hipStream_t st, const SortShape& sh, const PassArgs& p, bool attr, int grid, bool count, LaunchEvents ev)
+static hipError_t launch_pass(hipStream_t st, const SortShape& sh, const PassArgs& p, bool attr, bool coherent, int grid, bool count, LaunchEvents ev)
 {
-    if (sh.nt == 512) return launch_pass_nt<512>(st, p, attr, grid, count, sh.lds, ev);
-    return launch_pass_nt<256>(st, p, attr, grid, count, sh.lds, ev);
+    if (sh.nt == 512) return launch_pass_nt<512>(st, p, attr, coherent, grid, count, sh.lds, ev);
+    return launch_pass_nt<256>(st, p, attr, coherent, grid, count, sh.lds, ev);
 }
 
 hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, const LaunchEvents ev[9])
@@ -845,7 +1147,8 @@ hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, co
     p.seg_cnt = a.seg_cnt;
     const bool last0 = a.n_passes == 1;
     p.bin_base = last0 ? a.bin_base : nullptr; p.counters = last0 ? a.counters : nullptr;
-    if ((e = launch_pass(st, sh[0], p, attr, a.n_chunks1, false, ev[2])) != hipSuccess) return e;
+    const bool coherent = a.dshift[0] >= 8;                          // block-sorted form: coarse digits, few bins per wave instruction
+    if ((e = launch_pass(st, sh[0], p, attr, coherent, a.n_chunks1, false, ev[2])) != hipSuccess) return e;
     // ---- the higher digits: count, scan, scatter on the records of the pass before (ping-pong between the arrays); the
     //      live chunks are known on the device only
     const int grid = std::max(1, (int)((a.n + kSortChunk - 1) / kSortChunk));
@@ -857,10 +1160,10 @@ hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, co
         p.mask = (1u << a.dbits[i]) - 1u;
         p.n_dev = a.total; p.n_host = 0; p.sweep_chunk0 = nullptr; p.sweep_first = nullptr; p.n_sweeps = 1; p.seg_cnt = nullptr;
         p.bin_base = last ? a.bin_base : nullptr; p.counters = last ? a.counters : nullptr;
-        if ((e = launch_pass(st, sh[i], p, attr, grid, true, ev[3 * i])) != hipSuccess) return e;
+        if ((e = launch_pass(st, sh[i], p, attr, coherent, grid, true, ev[3 * i])) != hipSuccess) return e;
         GEM_LAUNCH(k_sort_scan, dim3((a.dbins[i] + 63) / 64, kScanSegs), dim3(1024), 0, st, ev[3 * i + 1], a.cnt[i], a.segtot[i], a.dbins[i], 0,
                    (const uint32_t*)a.total, (uint32_t*)nullptr);
-        if ((e = launch_pass(st, sh[i], p, attr, grid, false, ev[3 * i + 2])) != hipSuccess) return e;
+        if ((e = launch_pass(st, sh[i], p, attr, coherent, grid, false, ev[3 * i + 2])) != hipSuccess) return e;
     }
     return hipSuccess;
 }
@@ -876,6 +1179,51 @@ static hipError_t launch_walk_f(hipStream_t st, const WalkArgs& a, int mode, Lau
     default: GEM_LAUNCH((k_fuse_walk<FLAGS, 3>), grid, block, 0, st, ev, a); break;
     }
     return hipGetLastError();
+}
+
+#ifndef GEM_BLK_BATCH
+#define GEM_BLK_BATCH 2048
+#endif
+constexpr int kBlkBatch = GEM_BLK_BATCH;          // records of a block staged in LDS per round
+
+template <int FLAGS, int MODE>
+static hipError_t launch_block_walk_fm(hipStream_t st, const WalkArgs& a, LaunchEvents ev)
+{
+    constexpr bool KEYED = (MODE & 3) != 0, ATTR = (FLAGS & 3) != 0;
+    const size_t lds = block_walk_lds<kBlkBatch, KEYED, ATTR>();
+    const void* fn = (const void*)k_fuse_block<FLAGS, MODE, kBlkBatch>;
+    const hipError_t e = lds_opt_in(fn, lds);
+    if (e != hipSuccess) return e;
+    GEM_LAUNCH((k_fuse_block<FLAGS, MODE, kBlkBatch>), dim3(a.T * 4), dim3(kBlkNT), lds, st, ev, a);
+    return hipGetLastError();
+}
+
+template <int FLAGS>
+static hipError_t launch_block_walk_f(hipStream_t st, const WalkArgs& a, int mode, LaunchEvents ev)
+{
+    switch (mode) {
+    case 0:  return launch_block_walk_fm<FLAGS, 0>(st, a, ev);
+    case 1:  return launch_block_walk_fm<FLAGS, 1>(st, a, ev);
+    case 2:  return launch_block_walk_fm<FLAGS, 2>(st, a, ev);
+    default: return launch_block_walk_fm<FLAGS, 3>(st, a, ev);
+    }
+}
+
+hipError_t launch_block_walk(hipStream_t st, const WalkArgs& a, int flags, LaunchEvents ev)
+{
+    if (a.T <= 0) return hipSuccess;
+    if (a.n_sweeps > kWalkMaxSweeps || a.n_src > kMaxRanks) return hipErrorInvalidValue;
+    if (a.n_src > 1 && flags != 0) return hipErrorInvalidValue;       // records received from other ranks carry no colours / lowest scan points
+    const int mode = (a.var_updates ? 1 : 0) | ((a.counters && !a.count_per_pass) ? 2 : 0);
+    switch (flags) {
+    case 0: return launch_block_walk_f<0>(st, a, mode, ev);
+    case 1: return launch_block_walk_f<1>(st, a, mode, ev);
+    case 2: return launch_block_walk_f<2>(st, a, mode, ev);
+    case 4: return launch_block_walk_f<4>(st, a, mode, ev);
+    case 5: return launch_block_walk_f<5>(st, a, mode, ev);
+    case 6: return launch_block_walk_f<6>(st, a, mode, ev);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_strip_bounds(hipStream_t st, const uint32_t* keys, const uint32_t* n_records, int id_bits, const uint32_t* ids, uint32_t* out, int n)

@@ -55,20 +55,29 @@ def ref_mod():
     return ref
 
 
+PIPELINES = {
+    "default": {},                                                                   # the library's own choice per pass
+    "cell": {"sort_min_points": 1, "sort_form": 1},                                  # cell-sorted (k_fuse_walk) for every pass, however small
+    "cell3": {"sort_min_points": 1, "sort_form": 1, "sort_passes": 3},               # ... with three counting-sort passes (maps beyond 2^20 cells)
+    "block": {"sort_min_points": 1, "sort_form": 2},                                 # block-sorted (k_fuse_block) for every pass
+    "block2": {"sort_min_points": 1, "sort_form": 2, "sort_passes": 2},              # ... with two passes: a block's records are found by search
+    "generic_laser": {"sort_min_points": 1, "fast_laser": 0},                        # the laser variance with its rotation term (frames that do not qualify for the short form)
+}
+
+
 def pytest_generate_tests(metafunc):
-    # every GPU test runs on both pipelines (see the `pipeline` fixture)
+    # every GPU test runs on every pipeline (see the `pipeline` fixture)
     if metafunc.definition.get_closest_marker("gpu") is not None:
         metafunc.fixturenames.append("pipeline")
-        metafunc.parametrize("pipeline", ["default", "sorted", "sorted3"], indirect=True)
+        metafunc.parametrize("pipeline", list(PIPELINES), indirect=True)
 
 
 @pytest.fixture
 def pipeline(request, monkeypatch):
-    """GPU tests run three times: with the library's own choice between the tile pipeline (k_frame / k_bin_wave + k_fuse_list)
-    and the sorted pipeline (gem_sort.hip), and with the sorted pipeline forced for every pass, however small -- once with the
-    pass count the map size calls for, once with three counting-sort passes (what only maps beyond 2^20 cells would take)."""
+    """GPU tests run once per entry of PIPELINES: with the library's own choice between the tile pipeline (k_frame / k_bin_wave +
+    k_fuse_list) and the two sorted forms (gem_sort.hip), and with each sorted form forced for every pass, however small, at
+    the pass counts only large maps would take."""
     from gem_amd import ElevationMap
     which = getattr(request, "param", "default")
-    knobs = {"default": {}, "sorted": {"sort_min_points": 1}, "sorted3": {"sort_min_points": 1, "sort_passes": 3}}[which]
-    monkeypatch.setattr(ElevationMap, "base_debug", knobs)
+    monkeypatch.setattr(ElevationMap, "base_debug", PIPELINES[which])
     return which
