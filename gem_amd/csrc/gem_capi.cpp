@@ -91,6 +91,7 @@ struct gem_handle {
     bool walk_permute = true;           // k_fuse_walk: blocks take the tile rows centre-first
     int  sort_passes = 0;               // 0 = by map size and form (sort_geometry); 1 / 2 / 3 force it
     bool fast_laser = true;             // frames that qualify use the zero-rotation-variance form of the laser variance (fill_frame; debug knob)
+    int  block_batch = 2048;            // k_fuse_block: records of a block staged in LDS per round (debug knob: 2048 / 4096)
     int  sort_form = 0;                 // 0 = batches of sweeps BLOCK-sorted (k_fuse_block), single clouds CELL-sorted (k_fuse_walk); 1 / 2 force cell / block
     int dbg_sweep = 0;                  // debug stamps of the dense path: which sweep (GEM_DBG_SWEEP)
     bool track_lowest = false;          // also maintain map_lowest in the fuse kernels (gem_set_lowest_tracking, for gem_raytracing)
@@ -125,6 +126,7 @@ struct gem_handle {
     Arena dbg;          // optional k_fuse phase stamps
     Arena color;        // gem_colorize: its own sort arrays and tables (never shared with a pass in flight on the binning stream)
     bool  dbg_on = false;
+    int   dbg_rows = 0;  // rows of `dbg` the last pass wrote, if it was a block-sorted one (else h->T rows)
     int fuse_variant = 12;
 };
 
@@ -589,7 +591,14 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
         GEM_HIP(h, hipEventRecord(pb.bin_done, sbin));
         GEM_HIP(h, hipStreamWaitEvent(h->stream, pb.bin_done, 0));
     }
-    { Timed t(h, 9); GEM_HIP(h, geo.block_form ? launch_block_walk(h->stream, wa, attr, t.events()) : launch_walk(h->stream, wa, attr, t.events())); }
+    h->dbg_rows = 0;
+    if (h->dbg_on && geo.block_form) {
+        if ((rc = ensure(h, h->dbg, (size_t)T * 4 * 16 * 8))) return rc;
+        GEM_HIP(h, hipMemsetAsync(h->dbg.p, 0, (size_t)T * 4 * 16 * 8, h->stream));
+        wa.dbg = static_cast<unsigned long long*>(h->dbg.p);
+        h->dbg_rows = T * 4;
+    }
+    { Timed t(h, 9); GEM_HIP(h, geo.block_form ? launch_block_walk(h->stream, wa, attr, h->block_batch, t.events()) : launch_walk(h->stream, wa, attr, t.events())); }
     if (overlap) { GEM_HIP(h, hipEventRecord(pb.fuse_done, h->stream)); pb.fuse_recorded = true; }
     h->n_pending = 0;
     h->floor_dirty = false;
@@ -1558,6 +1567,7 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "sort_ring")          { if (value < 2 || value > 4) return fail(h, GEM_ERR_INVALID, "sort_ring: 2..4"); h->sort_ring = (int)value; }
     else if (k == "sort_streams")       { if (value != 1 && value != 2) return fail(h, GEM_ERR_INVALID, "sort_streams: 1 or 2"); h->sort_streams = (int)value; }
     else if (k == "sort_passes")        { if (value < 0 || value > 3) return fail(h, GEM_ERR_INVALID, "sort_passes: 0..3"); h->sort_passes = (int)value; }
+    else if (k == "block_batch")        { if (value != 2048 && value != 4096) return fail(h, GEM_ERR_INVALID, "block_batch: 2048 or 4096"); h->block_batch = (int)value; }
     else if (k == "fast_laser")         h->fast_laser = value != 0;
     else if (k == "sort_form")          { if (value < 0 || value > 2) return fail(h, GEM_ERR_INVALID, "sort_form: 0 (by pass), 1 (cell-sorted), 2 (block-sorted)"); h->sort_form = (int)value; }
     else return fail(h, GEM_ERR_INVALID, "gem_debug_set: unknown key");
@@ -1574,7 +1584,8 @@ int gem_debug_fuse_stamps(gem_handle* h, int enable, unsigned long long* out, in
     h->dbg_on = enable != 0;
     if (out && h->dbg.p) {
         GEM_HIP(h, hipStreamSynchronize(h->stream));
-        const int n = max_tiles < h->T ? max_tiles : h->T;
+        const int rows = h->dbg_rows ? h->dbg_rows : h->T;
+        const int n = max_tiles < rows ? max_tiles : rows;
         GEM_HIP(h, hipMemcpy(out, h->dbg.p, (size_t)n * 16 * 8, hipMemcpyDeviceToHost));
         return n;
     }
@@ -1765,7 +1776,7 @@ static int shard_fuse_locked(gem_handle* h, int n_src, const void* const* d_hv, 
         wa.var_updates = dv;
     }
     if (h->counting) GEM_HIP(h, hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
-    { Timed t(h, 9); GEM_HIP(h, launch_block_walk(h->stream, wa, 0, t.events())); }
+    { Timed t(h, 9); GEM_HIP(h, launch_block_walk(h->stream, wa, 0, h->block_batch, t.events())); }
     h->n_pending = 0;
     h->floor_dirty = false;
     h->main_reads_pb = true;

@@ -156,19 +156,20 @@ __global__ __launch_bounds__(256, (SRC == 4 ? 4 : (SRC == 2 ? 3 : 1))) void k_so
                 a.hv_a[at] = make_uint2(__float_as_uint(b.h), __float_as_uint(b.v));
                 if (a.src_a) a.src_a[at] = (uint32_t)i | (b.colour_ok ? 0x80000000u : 0u);  // source point; bit 31: R, G, B, intensity all non-zero
             }
-            // Histogram.  Consecutive points of a scan fall into a few bins when the digit is a coarse one (the blocks of the
-            // block-sorted form): 64 lanes adding 1 to one LDS word take 64 turns, so the wave first counts the bins of its leading
-            // lanes by ballot -- one add per bin -- and the lanes still unmatched after three rounds add for themselves.
-            uint64_t rem = m;
-#pragma unroll 1
-            for (int it = 0; it < 3 && rem != 0 && d0shift != 0u; ++it) {   // wave-uniform
-                const int lead = __ffsll((unsigned long long)rem) - 1;
-                const uint32_t kb = (uint32_t)__builtin_amdgcn_readlane((int)bin, lead);
-                const uint64_t same = __ballot(b.valid && bin == kb) & rem;
-                if ((tid & 63) == lead) atomicAdd(&hist[kb], (uint32_t)__popcll(same));
-                rem &= ~same;
-            }
-            if ((rem >> (tid & 63)) & 1ull) atomicAdd(&hist[bin], 1u);
+            // Histogram.  With a coarse digit (the blocks of the block-sorted form) consecutive points of a scan share their bin, and
+            // 64 lanes adding 1 to one LDS word take 64 turns: a lane adds for its whole RUN of equal neighbours instead (the run's
+            // first lane, found with one DPP shift and one ballot; a bin that comes back later in the wave simply adds twice).
+            if (d0shift != 0u) {                                       // block-uniform
+                const uint32_t kb = b.valid ? bin : 0xffffffffu;
+                const uint32_t pv = wave_prev(kb);
+                const bool head = (tid & 63) == 0 || kb != pv;
+                const uint64_t heads = __ballot(head);
+                if (head && b.valid) {
+                    const uint64_t later = (tid & 63) == 63 ? 0ull : heads >> ((tid & 63) + 1);
+                    const uint32_t run = later ? (uint32_t)__ffsll((unsigned long long)later) : 64u - (uint32_t)(tid & 63);
+                    atomicAdd(&hist[bin], run);
+                }
+            } else if (b.valid) atomicAdd(&hist[bin], 1u);
             kept += (uint32_t)__popcll(m);
         }
     }
@@ -397,41 +398,41 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void k_sort_scatter(PassAr
     // ---- 2. per bin: the waves in order (exclusive prefix), the chunk's local base, the way from local to global positions
     {
         const int per = (bins + NT - 1) / NT, b0 = tid * per;
-        uint32_t sum = 0;
+        uint32_t* tbv = reinterpret_cast<uint32_t*>(wslots);          // [bins] records of the bin in the whole pass (the name slots are free now)
+        // the bin's records in the whole pass / in the chunk segments before this chunk's (k_sort_scan)
+        const int nc = a.n_dev ? (int)((end + CH - 1) / CH) : a.n_chunks;
+        const int seg = chunk / max(1, scan_seg_chunks(nc));                 // (nc = 0: pass 1 kept nothing, workgroup 0 only publishes the bases)
+        uint32_t sum = 0, gsum = 0;
         for (int j = 0; j < per; ++j) {
             const int b = b0 + j;
             if (b < bins) {
+                uint32_t sv[kScanSegs];
+#pragma unroll
+                for (int sg = 0; sg < kScanSegs; ++sg) sv[sg] = a.segtot[(size_t)sg * bins + b];
+                const uint32_t earlier = first < end ? a.cnt[(size_t)chunk * bins + b] : 0u;   // (an empty pass has no count rows)
                 uint32_t run = 0;
 #pragma unroll
                 for (int ww = 0; ww < NW; ++ww) { const uint32_t c = wcnt[ww * bins + b]; wcnt[ww * bins + b] = run; run += c; }
                 lbase[b] = run;                                        // the bin's records in this chunk, for now
                 sum += run;
+                uint32_t tb = 0, before = 0;
+#pragma unroll
+                for (int sg = 0; sg < kScanSegs; ++sg) { before += sg < seg ? sv[sg] : 0u; tb += sv[sg]; }
+                tbv[b] = tb; delta[b] = before + earlier;              // earlier segments + earlier chunks of this segment
+                gsum += tb;
             }
         }
         uint32_t chunk_records, all;
         uint32_t ex = block_exclusive_scan<NT>(sum, scratch, &chunk_records);
-        // the bin's records in the whole pass / in the chunk segments before this chunk's (k_sort_scan)
-        const int nc = a.n_dev ? (int)((end + CH - 1) / CH) : a.n_chunks;
-        const int seg = chunk / max(1, scan_seg_chunks(nc));                 // (nc = 0: pass 1 kept nothing, workgroup 0 only publishes the bases)
-        auto bin_sums = [&](int b, uint32_t& before) -> uint32_t {
-            uint32_t t = 0; before = 0;
-#pragma unroll
-            for (int sg = 0; sg < kScanSegs; ++sg) { const uint32_t v = a.segtot[(size_t)sg * bins + b]; before += sg < seg ? v : 0u; t += v; }
-            return t;
-        };
-        uint32_t gsum = 0;
-        for (int j = 0; j < per; ++j) if (b0 + j < bins) { uint32_t bf; gsum += bin_sums(b0 + j, bf); }
         uint32_t gex = block_exclusive_scan<NT>(gsum, scratch, &all);  // first record of the bin in the pass's output
         for (int j = 0; j < per; ++j) {
             const int b = b0 + j;
             if (b < bins) {
                 const uint32_t c = lbase[b];
-                uint32_t before; const uint32_t tb = bin_sums(b, before);
                 lbase[b] = ex;
-                const uint32_t earlier = first < end ? a.cnt[(size_t)chunk * bins + b] : 0u;   // (an empty pass has no count rows)
-                delta[b] = gex + before + earlier - ex;                // bin base + earlier segments + earlier chunks - local position
+                delta[b] = gex + delta[b] - ex;                        // bin base + earlier records of the bin - local position
                 if (a.bin_base && chunk == 0) a.bin_base[b] = gex;
-                ex += c; gex += tb;
+                ex += c; gex += tbv[b];
             }
         }
         if (tid == 0) {
@@ -814,6 +815,7 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
     const uint32_t idmask = (1u << a.id_bits) - 1u;
     const uint32_t id0 = ((uint32_t)tile << 10) | ((uint32_t)q4 << 8); // the cell ids of this block: id0 .. id0 + 255
     const int n_src = a.n_src <= 1 ? 1 : a.n_src;
+    if (a.dbg && tid == 0) a.dbg[(size_t)blockIdx.x * 16] = __builtin_readcyclecounter();
 
     // ---- the thread's cell: its map values are fetched now, coalesced, in flight behind the search
     const int L = a.L;
@@ -923,6 +925,15 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         }
     };
 
+    // profiling aid (gem_debug_fuse_stamps): cycle stamps of thread 0 -- start, set-up done, then the sums over the batches of
+    // {ranking + waiting for the slowest wave's chains, bases, placement, own chains}, end; records, batches, sum of wave 0's longest chains
+    unsigned long long* dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr;
+    unsigned long long t_prev = 0, acc_rank = 0, acc_base = 0, acc_place = 0, acc_walk = 0, acc_nmax = 0, n_batches = 0;
+    if (dbg && tid == 0) { t_prev = __builtin_readcyclecounter(); dbg[1] = t_prev; dbg[7] = R; }
+    auto lap = [&](unsigned long long& acc) {
+        if (dbg && tid == 0) { const unsigned long long t = __builtin_readcyclecounter(); acc += t - t_prev; t_prev = t; }
+    };
+
     uint32_t parity = 0;
     if (R) load_batch(0u, min(R, (uint32_t)B));
     for (uint32_t P = 0; P < R; P += (uint32_t)B) {                    // block-uniform
@@ -954,6 +965,7 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
             }
         }
         __syncthreads();
+        lap(acc_rank);
         // ---- 2. per cell: the waves in order, the cell's place in the batch
         const uint32_t n0 = wcur[0 * 320 + tid], n1 = wcur[1 * 320 + tid], n2 = wcur[2 * 320 + tid], n3 = wcur[3 * 320 + tid];
         wcur[0 * 320 + tid] = 0u; wcur[1 * 320 + tid] = 0u; wcur[2 * 320 + tid] = 0u; wcur[3 * 320 + tid] = 0u;
@@ -962,6 +974,7 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         const uint32_t first = block_exclusive_scan_alt<NT>(n, scratch, parity++, &all);
         cbase[0 * 256 + tid] = first; cbase[1 * 256 + tid] = first + n0; cbase[2 * 256 + tid] = first + n0 + n1; cbase[3 * 256 + tid] = first + n0 + n1 + n2;
         __syncthreads();
+        lap(acc_base);
         // ---- 3. the batch in LDS, ordered by cell
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -973,6 +986,7 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
             }
         }
         __syncthreads();
+        lap(acc_place);
         // the next batch's records: in flight behind the chains
         if (P + (uint32_t)B < R) load_batch(P + (uint32_t)B, min(R - P - (uint32_t)B, (uint32_t)B));
         // ---- 4. the thread's cell: its n records of this batch, in input order
@@ -1000,7 +1014,13 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
             if constexpr (LOWEST) { const float l2 = lowest_step(lw, h, v); lw = live ? l2 : lw; }
             if constexpr (ATTR != 0) { if (fl && taken && (sr & 0x80000000u)) wlast = sr & 0x7fffffffu; }
         }
+        lap(acc_walk);
+        acc_nmax += nmax; ++n_batches;
         // (the next round's ranking touches the cursors and masks only; its stores into the stage come after two barriers)
+    }
+    if (dbg && tid == 0) {
+        dbg[2] = acc_rank; dbg[3] = acc_base; dbg[4] = acc_place; dbg[5] = acc_walk; dbg[6] = __builtin_readcyclecounter();
+        dbg[8] = n_batches; dbg[9] = acc_nmax;
     }
     if (__ballot(n_total != 0) == 0 && !a.dense) return;               // nothing reached this wave's cells and nothing is pending
     if constexpr (HAS_VU) advance(last_sw);
@@ -1064,7 +1084,8 @@ SortShape sort_shape(int bins, bool attr)
 {
     SortShape s;
     const size_t stage = (size_t)(attr ? 4 : 3) * kSortChunk;
-    s.nt = rank_words(8, bins) <= stage + 2048 ? 512 : 256;           // eight waves while their ranking tables fit under the stage
+    // eight waves while two workgroups of them fit a CU's LDS (the ranking tables of 1444 bins x 8 waves exceed the stage: 74 KB)
+    s.nt = ((size_t)2 * bins + 16 + std::max(rank_words(8, bins), stage)) * 4 <= 80 * 1024 ? 512 : 256;
     s.chunk = kSortChunk;
     s.lds = ((size_t)2 * bins + 16 + std::max(rank_words(s.nt / 64, bins), stage)) * 4;
     return s;
@@ -1181,47 +1202,43 @@ static hipError_t launch_walk_f(hipStream_t st, const WalkArgs& a, int mode, Lau
     return hipGetLastError();
 }
 
-#ifndef GEM_BLK_BATCH
-#define GEM_BLK_BATCH 2048
-#endif
-constexpr int kBlkBatch = GEM_BLK_BATCH;          // records of a block staged in LDS per round
-
-template <int FLAGS, int MODE>
-static hipError_t launch_block_walk_fm(hipStream_t st, const WalkArgs& a, LaunchEvents ev)
+template <int FLAGS, int MODE, int B>
+static hipError_t launch_block_walk_fmb(hipStream_t st, const WalkArgs& a, LaunchEvents ev)
 {
     constexpr bool KEYED = (MODE & 3) != 0, ATTR = (FLAGS & 3) != 0;
-    const size_t lds = block_walk_lds<kBlkBatch, KEYED, ATTR>();
-    const void* fn = (const void*)k_fuse_block<FLAGS, MODE, kBlkBatch>;
-    const hipError_t e = lds_opt_in(fn, lds);
+    const size_t lds = block_walk_lds<B, KEYED, ATTR>();
+    const hipError_t e = lds_opt_in((const void*)k_fuse_block<FLAGS, MODE, B>, lds);
     if (e != hipSuccess) return e;
-    GEM_LAUNCH((k_fuse_block<FLAGS, MODE, kBlkBatch>), dim3(a.T * 4), dim3(kBlkNT), lds, st, ev, a);
+    GEM_LAUNCH((k_fuse_block<FLAGS, MODE, B>), dim3(a.T * 4), dim3(kBlkNT), lds, st, ev, a);
     return hipGetLastError();
 }
 
-template <int FLAGS>
+template <int FLAGS, int B>
 static hipError_t launch_block_walk_f(hipStream_t st, const WalkArgs& a, int mode, LaunchEvents ev)
 {
     switch (mode) {
-    case 0:  return launch_block_walk_fm<FLAGS, 0>(st, a, ev);
-    case 1:  return launch_block_walk_fm<FLAGS, 1>(st, a, ev);
-    case 2:  return launch_block_walk_fm<FLAGS, 2>(st, a, ev);
-    default: return launch_block_walk_fm<FLAGS, 3>(st, a, ev);
+    case 0:  return launch_block_walk_fmb<FLAGS, 0, B>(st, a, ev);
+    case 1:  return launch_block_walk_fmb<FLAGS, 1, B>(st, a, ev);
+    case 2:  return launch_block_walk_fmb<FLAGS, 2, B>(st, a, ev);
+    default: return launch_block_walk_fmb<FLAGS, 3, B>(st, a, ev);
     }
 }
 
-hipError_t launch_block_walk(hipStream_t st, const WalkArgs& a, int flags, LaunchEvents ev)
+// batch: records of a block staged in LDS per round (2048: three workgroups per CU; 4096, passes without colours / lowest scan
+// points only: two per CU, half as many rounds for the blocks under the sensor)
+hipError_t launch_block_walk(hipStream_t st, const WalkArgs& a, int flags, int batch, LaunchEvents ev)
 {
     if (a.T <= 0) return hipSuccess;
     if (a.n_sweeps > kWalkMaxSweeps || a.n_src > kMaxRanks) return hipErrorInvalidValue;
     if (a.n_src > 1 && flags != 0) return hipErrorInvalidValue;       // records received from other ranks carry no colours / lowest scan points
     const int mode = (a.var_updates ? 1 : 0) | ((a.counters && !a.count_per_pass) ? 2 : 0);
     switch (flags) {
-    case 0: return launch_block_walk_f<0>(st, a, mode, ev);
-    case 1: return launch_block_walk_f<1>(st, a, mode, ev);
-    case 2: return launch_block_walk_f<2>(st, a, mode, ev);
-    case 4: return launch_block_walk_f<4>(st, a, mode, ev);
-    case 5: return launch_block_walk_f<5>(st, a, mode, ev);
-    case 6: return launch_block_walk_f<6>(st, a, mode, ev);
+    case 0: return batch >= 4096 ? launch_block_walk_f<0, 4096>(st, a, mode, ev) : launch_block_walk_f<0, 2048>(st, a, mode, ev);
+    case 1: return launch_block_walk_f<1, 2048>(st, a, mode, ev);
+    case 2: return launch_block_walk_f<2, 2048>(st, a, mode, ev);
+    case 4: return launch_block_walk_f<4, 2048>(st, a, mode, ev);
+    case 5: return launch_block_walk_f<5, 2048>(st, a, mode, ev);
+    case 6: return launch_block_walk_f<6, 2048>(st, a, mode, ev);
     default: return hipErrorInvalidValue;
     }
 }
