@@ -91,6 +91,7 @@ struct gem_handle {
     bool walk_permute = true;           // k_fuse_walk: blocks take the tile rows centre-first
     int  sort_passes = 0;               // 0 = by map size and form (sort_geometry); 1 / 2 / 3 force it
     bool fast_laser = true;             // frames that qualify use the zero-rotation-variance form of the laser variance (fill_frame; debug knob)
+    bool block_order = true;            // k_fuse_block takes the blocks by record count (k_block_order; debug knob)
     int  block_batch = 2048;            // k_fuse_block: records of a block staged in LDS per round (debug knob: 2048 / 4096)
     int  sort_form = 0;                 // 0 = batches of sweeps BLOCK-sorted (k_fuse_block), single clouds CELL-sorted (k_fuse_walk); 1 / 2 force cell / block
     int dbg_sweep = 0;                  // debug stamps of the dense path: which sweep (GEM_DBG_SWEEP)
@@ -448,7 +449,8 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     for (int i = 0; i < geo.n_passes; ++i) { o_seg[i] = o_next; o_next += (size_t)geo.dbins[i] * 16; }
     const size_t o_total = o_next, o_base = (o_total + 4 + 15) & ~(size_t)15;
     const size_t o_segcnt = (o_base + ((size_t)geo.dbins[geo.n_passes - 1] + 1) * 4 + 15) & ~(size_t)15;
-    if ((rc = ensure(h, pb.s_misc, o_segcnt + (size_t)NC1 * kSortSegsPerChunk * 4))) return rc;
+    const size_t o_order = (o_segcnt + (size_t)NC1 * kSortSegsPerChunk * 4 + 15) & ~(size_t)15;       // workgroup -> block of k_fuse_block
+    if ((rc = ensure(h, pb.s_misc, o_order + (size_t)kOnePassMaxBins * 4))) return rc;
     // the walk of pass p-2 has read these buffers (host-side wait, see run_pipeline)
     if (overlap && pb.fuse_recorded) GEM_HIP(h, hipEventSynchronize(pb.fuse_done));
 
@@ -557,6 +559,12 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
             if (laser) src = fast ? 4 : 2;                       // 4: every frame's rotation variance is zero (height_variance, kModelLaserFast)
         }
         GEM_HIP(h, launch_sort(sbin, sa, src, with_src, ev));
+    }
+    if (wa.exact_bins && h->block_order && geo.dbins[0] == 4 * T) {
+        // the blocks by record count: what the scan already knows (segment sums of the one pass)
+        uint32_t* order = reinterpret_cast<uint32_t*>(misc + o_order);
+        GEM_HIP(h, launch_block_order(sbin, sa.segtot[0], geo.dbins[0], order));
+        wa.order = order;
     }
     if (shard) {
         // where the strips begin in the sorted records: one 32-ary search per boundary, then the only host round trip of the path
@@ -1567,6 +1575,7 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "sort_ring")          { if (value < 2 || value > 4) return fail(h, GEM_ERR_INVALID, "sort_ring: 2..4"); h->sort_ring = (int)value; }
     else if (k == "sort_streams")       { if (value != 1 && value != 2) return fail(h, GEM_ERR_INVALID, "sort_streams: 1 or 2"); h->sort_streams = (int)value; }
     else if (k == "sort_passes")        { if (value < 0 || value > 3) return fail(h, GEM_ERR_INVALID, "sort_passes: 0..3"); h->sort_passes = (int)value; }
+    else if (k == "block_order")        h->block_order = value != 0;
     else if (k == "block_batch")        { if (value != 2048 && value != 4096) return fail(h, GEM_ERR_INVALID, "block_batch: 2048 or 4096"); h->block_batch = (int)value; }
     else if (k == "fast_laser")         h->fast_laser = value != 0;
     else if (k == "sort_form")          { if (value < 0 || value > 2) return fail(h, GEM_ERR_INVALID, "sort_form: 0 (by pass), 1 (cell-sorted), 2 (block-sorted)"); h->sort_form = (int)value; }

@@ -476,6 +476,57 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void k_sort_scatter(PassAr
 }
 
 // ------------------------------------------------------------------------------------------
+// The sweeps' variance increments between the records of a cell (both walks).  Between two records of sweeps s < t the cell lives
+// through t - s times {the floor that ends a Fuse (GPU:533-534); the next sweep's Mapvar_update (GPU:540-547)} -- a serial chain
+// of rounded additions, so it is replayed step by step.  The lanes of a wave stand at unrelated sweeps and the increments come
+// from LDS: a loop that fetches one increment per round exposes an LDS round trip per sweep to every lane of the wave (that
+// loop was 60 % of the walks' time on a batch of 32 sweeps).  Here every lane keeps the increments of its NEXT FOUR sweeps in
+// registers, refilled behind the record's fusion step: gaps of up to four sweeps -- nearly all of them -- cost four VALU
+// instructions per sweep and no wait.  vu[] is padded with 8 words.
+// ------------------------------------------------------------------------------------------
+struct SweepReplay {
+    float w0, w1, w2, w3;          // increments of sweeps cur + 1 .. cur + 4
+    uint32_t cur;                  // "inside sweep cur, its increment applied"
+
+    __device__ __forceinline__ void refill(const float* vu) { w0 = vu[cur + 1u]; w1 = vu[cur + 2u]; w2 = vu[cur + 3u]; w3 = vu[cur + 4u]; }
+    __device__ __forceinline__ void one(float& cs, float u, float var_floor)
+    {
+        if (cs < var_floor) cs = var_floor;
+        ++cur;
+        if (cs != kInitVariance) cs += u;
+    }
+    // this lane: to sweep `to` (>= cur; lanes that stay pass cur)
+    __device__ __forceinline__ void advance(float& cs, uint32_t to, const float* vu, float var_floor)
+    {
+        if (__ballot(cur < to) == 0) return;                           // wave-uniform
+        if (cur < to) one(cs, w0, var_floor);
+        if (__ballot(cur < to) != 0) {
+            if (cur < to) one(cs, w1, var_floor);
+            if (__ballot(cur < to) != 0) {
+                if (cur < to) one(cs, w2, var_floor);
+                if (__ballot(cur < to) != 0) {
+                    if (cur < to) one(cs, w3, var_floor);
+                    while (__ballot(cur < to) != 0) { if (cur < to) one(cs, vu[cur + 1u], var_floor); }   // a gap of five or more sweeps
+                }
+            }
+        }
+        refill(vu);
+    }
+    // every lane to the last sweep: the sweep index runs wave-uniform from the wave's earliest lane, four increments per round trip
+    __device__ __forceinline__ void finish(float& cs, uint32_t last_sw, const float* vu, float var_floor)
+    {
+        const uint32_t behind = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_max(0xffffu - cur), 63);
+        for (uint32_t s = 0xffffu - behind + 1u; s <= last_sw; s += 4u) {   // wave-uniform
+            const float u0 = vu[s], u1 = vu[s + 1u], u2 = vu[s + 2u], u3 = vu[s + 3u];
+            if (cur < s && s <= last_sw) one(cs, u0, var_floor);
+            if (cur < s + 1u && s + 1u <= last_sw) one(cs, u1, var_floor);
+            if (cur < s + 2u && s + 2u <= last_sw) one(cs, u2, var_floor);
+            if (cur < s + 3u && s + 3u <= last_sw) one(cs, u3, var_floor);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
 // k_fuse_walk : one wave per 64 consecutive cells (two rows of a 32x32 tile), one lane per cell
 // ------------------------------------------------------------------------------------------
 // FLAGS: bits 0-1 = ATTR (0 none, 1 colours from the cloud, 2 colours from gem_fuse's arrays), bit 2 = LOWEST (also maintain
@@ -496,7 +547,7 @@ __global__ __launch_bounds__(kWalkNT) void k_fuse_walk(WalkArgs a)
     __shared__ uint32_t cstart[NT], cend[NT], hist[128];
     __shared__ float sh_e[NT], sh_s[NT], sh_l[LOWEST ? NT : 1];
     __shared__ uint16_t perm[NT];
-    __shared__ float vu[HAS_VU ? kWalkMaxSweeps : 1];
+    __shared__ float vu[HAS_VU ? kWalkMaxSweeps + 8 : 1];
     const int tid = (int)threadIdx.x, lane = lane_id(), w = tid >> 6;
     // Block -> 256 cells (a quarter of a tile), CENTRE ROWS FIRST: the map is robot-centric, the cells under the sensor carry
     // chains a hundred times longer than the rim's, and a wave takes as long as its longest chain -- so the tile rows start in
@@ -536,7 +587,7 @@ __global__ __launch_bounds__(kWalkNT) void k_fuse_walk(WalkArgs a)
         gr += gr < 0 ? L : 0; gc += gc < 0 ? L : 0;
         l_t = a.lowest[owned_t ? (size_t)gr * L + gc : 0];
     }
-    if constexpr (HAS_VU) for (int i = tid; i < a.n_sweeps; i += NT) vu[i] = a.var_updates[i];
+    if constexpr (HAS_VU) for (int i = tid; i < kWalkMaxSweeps + 8; i += NT) vu[i] = i < a.n_sweeps ? a.var_updates[i] : 0.0f;
 
     // ---- where the cells of this workgroup begin and end in one SOURCE of records sorted by cell id (keys[lo0, hi0) may hold
     //      them): cstart / cend in LDS; false if the source has nothing for these cells.  Block-uniform.
@@ -639,22 +690,13 @@ __global__ __launch_bounds__(kWalkNT) void k_fuse_walk(WalkArgs a)
     }
 
     float ce = e0, cs = s0;
-    uint32_t cur = 0;                                                  // "inside sweep cur, its increment applied"
     // From sweep `cur` to sweep `to`: the floor that ends every Fuse (GPU:533-534), then the next sweep's increment.  The lanes of
     // a wave stand at unrelated sweeps, so this loop runs as long as the lane with the widest gap needs; the increment of the
     // lane's NEXT sweep is kept in a register (fetched behind the previous use), so that the common one-sweep gap costs no LDS
     // round trip.  (Tried: the first two sweeps of a gap as straight-line predicated code -- every record then pays for them,
     // 69 -> 144 us on C4.)
     const uint32_t last_sw = (uint32_t)(a.n_sweeps > 0 ? a.n_sweeps - 1 : 0);
-    float u1 = 0.0f;
-    auto advance = [&](uint32_t to) {
-        while (cur < to) {
-            if (cs < a.var_floor) cs = a.var_floor;
-            ++cur;
-            if (cs != kInitVariance) cs += u1;
-            u1 = vu[min(cur + 1u, last_sw)];
-        }
-    };
+    SweepReplay rp; rp.cur = 0u; rp.w0 = rp.w1 = rp.w2 = rp.w3 = 0.0f;
     uint32_t wlast = 0xffffffffu, sweeps_seen = 0, last_sweep = 0xffffffffu, n_total = 0;
 
     // ---- the run of cell c in one source (its boundaries are in LDS)
@@ -687,7 +729,7 @@ __global__ __launch_bounds__(kWalkNT) void k_fuse_walk(WalkArgs a)
             const float h = __uint_as_float(hb), v = __uint_as_float(vb);
             if constexpr (KEYED) {
                 const uint32_t sw = cur_k >> a.id_bits;
-                if constexpr (HAS_VU) { if (live) advance(sw); }
+                if constexpr (HAS_VU) rp.advance(cs, live ? sw : rp.cur, vu, a.var_floor);
                 if constexpr (COUNT_SWEEPS) { if (live && sw != last_sweep) { ++sweeps_seen; last_sweep = sw; } }
             }
             float e2 = ce, s2 = cs;
@@ -722,10 +764,10 @@ __global__ __launch_bounds__(kWalkNT) void k_fuse_walk(WalkArgs a)
     __syncthreads();                                                   // vu is in LDS
     // Mapvar_update increments queued before this pass, then the one of sweep 0 (GPU:540-547)
     for (int k = 0; k < a.n_pending; ++k) if (cs != kInitVariance) cs += a.pending[k];
-    if constexpr (HAS_VU) { if (cs != kInitVariance) cs += vu[0]; u1 = vu[min(1u, last_sw)]; }
+    if constexpr (HAS_VU) { if (cs != kInitVariance) cs += vu[0]; rp.refill(vu); }
     if (have) walk_run(a.key, a.hv, a.src);
     if (__ballot(n_total != 0) == 0 && !a.dense) return;               // nothing reached this wave's cells and nothing is pending
-    if constexpr (HAS_VU) advance(last_sw);
+    if constexpr (HAS_VU) rp.finish(cs, last_sw, vu, a.var_floor);
     if (cs < a.var_floor) cs = a.var_floor;                            // GPU:533-534, on every cell
 
     if (owned) {
@@ -794,14 +836,16 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
     uint32_t* st_src = cbase + NW * 256;                                                // [B] (ATTR)
     uint16_t* st_sw = reinterpret_cast<uint16_t*>(st_src + (ATTR ? B : 0));             // [B] (KEYED) the record's sweep
     __shared__ uint32_t scratch[16];
-    __shared__ float vu[HAS_VU ? kWalkMaxSweeps : 1];
+    __shared__ float vu[HAS_VU ? kWalkMaxSweeps + 8 : 1];
     __shared__ uint32_t seg_first[kMaxRanks], seg_off[kMaxRanks + 1];                  // per source: first record of the block; prefix of the counts
     __shared__ unsigned long long seg_key[kMaxRanks], seg_hv[kMaxRanks];
     const int tid = (int)threadIdx.x, lane = lane_id(), w = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // block -> 256 cells, tile rows centre-first when all workgroups are resident at once (see k_fuse_walk)
+    // workgroup -> block of 256 cells: by record count (k_block_order) when the sort knows it, else tile rows centre-first when all
+    // workgroups are resident at once (see k_fuse_walk), else memory order
     int tile, q4 = (int)(blockIdx.x & 3);
-    {
+    if (a.order) { const uint32_t blk = a.order[blockIdx.x]; tile = (int)(blk >> 2); q4 = (int)(blk & 3u); }
+    else {
         const int tpr = a.tiles_per_row, rnk = (int)(blockIdx.x >> 2);
         if (a.walk_order) {
             const int bi = rnk / tpr, bj = rnk - bi * tpr;
@@ -830,7 +874,7 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         lgeo = owned ? (size_t)gr * L + gc : 0;
         lw0 = lw = a.lowest[lgeo];
     }
-    if constexpr (HAS_VU) for (int i = tid; i < a.n_sweeps; i += NT) vu[i] = a.var_updates[i];
+    if constexpr (HAS_VU) for (int i = tid; i < kWalkMaxSweeps + 8; i += NT) vu[i] = i < a.n_sweeps ? a.var_updates[i] : 0.0f;
 
     // ---- where the block's records are in every source.  One-pass sort: the last pass's bins are the blocks.  Otherwise a
     //      32-ary search, both ends at once (lanes 0-31 look for the first record of the block, lanes 32-63 for the first one
@@ -875,52 +919,53 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
     const uint32_t R = seg_off[n_src];                                 // records of this block, all sources
     if (R == 0 && !a.dense) return;                                    // block-uniform
 
-    // record q of the block's sequence -> its source arrays and its place in them
-    auto locate = [&](uint32_t q, const uint32_t*& kp, const uint2*& hp) -> uint32_t {
-        if (n_src <= 1) { kp = a.key; hp = a.hv; return first0 + q; }
+    // record q of the block's sequence -> its source arrays (global memory: the pointers kept in LDS are cast back to that address
+    // space, a generic pointer would make every load a FLAT one that also counts as an LDS operation) and its place in them
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(1))) uint32_t* gkey_t;
+    typedef const __attribute__((address_space(1))) uint2* ghv_t;
+#else
+    typedef const uint32_t* gkey_t;                                    // (the host pass only parses the kernel)
+    typedef const uint2* ghv_t;
+#endif
+    auto locate = [&](uint32_t q, gkey_t& kp, ghv_t& hp) -> uint32_t {
+        if (n_src <= 1) { kp = (gkey_t)a.key; hp = (ghv_t)a.hv; return first0 + q; }
         int s = 0;
         while (s + 1 < n_src && q >= seg_off[s + 1]) ++s;
-        kp = reinterpret_cast<const uint32_t*>((uintptr_t)seg_key[s]); hp = reinterpret_cast<const uint2*>((uintptr_t)seg_hv[s]);
+        kp = (gkey_t)(uintptr_t)seg_key[s]; hp = (ghv_t)(uintptr_t)seg_hv[s];
         return seg_first[s] + (q - seg_off[s]);
     };
 
     float ce = e0, cs = s0;
-    uint32_t cur = 0;                                                  // "inside sweep cur, its increment applied"
     // From sweep `cur` to sweep `to`: the floor that ends every Fuse (GPU:533-534), then the next sweep's increment; the increment
     // of the lane's NEXT sweep is kept in a register so that the common one-sweep gap costs no LDS round trip (see k_fuse_walk).
     const uint32_t last_sw = (uint32_t)(a.n_sweeps > 0 ? a.n_sweeps - 1 : 0);
-    float u1 = 0.0f;
-    auto advance = [&](uint32_t to) {
-        while (cur < to) {
-            if (cs < a.var_floor) cs = a.var_floor;
-            ++cur;
-            if (cs != kInitVariance) cs += u1;
-            u1 = vu[min(cur + 1u, last_sw)];
-        }
-    };
+    SweepReplay rp; rp.cur = 0u; rp.w0 = rp.w1 = rp.w2 = rp.w3 = 0.0f;
     uint32_t wlast = 0xffffffffu, sweeps_seen = 0, last_sweep = 0xffffffffu, n_total = 0;
     // Mapvar_update increments queued before this pass, then the one of sweep 0 (GPU:540-547)
     for (int k = 0; k < a.n_pending; ++k) if (cs != kInitVariance) cs += a.pending[k];
-    if constexpr (HAS_VU) { if (cs != kInitVariance) cs += vu[0]; u1 = vu[min(1u, last_sw)]; }
+    if constexpr (HAS_VU) { if (cs != kInitVariance) cs += vu[0]; rp.refill(vu); }
 
     const uint64_t lt = lanemask_lt();
     const unsigned long long mybit = 1ull << lane;
     unsigned long long* wpm_w = wpm + w * 320;
     uint32_t* wcur_w = wcur + w * 320;
     uint2 hv[K]; uint32_t key[K], src[K];
-    // the wave's share of a batch of nb records: `steps` wave instructions of 64 consecutive records
+    // The wave's share of a batch of nb records: `steps` wave instructions of 64 consecutive records.  load_batch only ISSUES the
+    // loads (clamped addresses, nothing looks at the values): the next batch's records are in flight behind the chains of this one.
+    auto in_batch = [&](int k, uint32_t steps, uint32_t nb) -> bool {
+        return (uint32_t)k < steps && ((uint32_t)w * steps + (uint32_t)k) * 64u + (uint32_t)lane < nb;
+    };
     auto load_batch = [&](uint32_t P, uint32_t nb) {
         const uint32_t steps = (nb + (uint32_t)NT - 1u) / (uint32_t)NT;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            key[k] = kKeyInvalid;
             if ((uint32_t)k < steps) {                                 // block-uniform
                 const uint32_t j = ((uint32_t)w * steps + (uint32_t)k) * 64u + (uint32_t)lane;
-                const uint32_t* kp; const uint2* hp;
+                gkey_t kp; ghv_t hp;
                 const uint32_t at = locate(P + min(j, nb - 1u), kp, hp);
-                const uint32_t kk = kp[at]; hv[k] = hp[at];
-                if (ATTR) src[k] = a.src[at];
-                key[k] = j < nb ? kk : kKeyInvalid;
+                key[k] = kp[at]; hv[k] = hp[at];
+                if (ATTR) src[k] = ((gkey_t)a.src)[at];
             }
         }
     };
@@ -945,7 +990,7 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         for (int k = 0; k < K; ++k) {
             peers[k] = 0ull;
             if ((uint32_t)k < steps) {
-                const bool valid = key[k] != kKeyInvalid;
+                const bool valid = in_batch(k, steps, nb);
                 unsigned long long* m = wpm_w + (valid ? (key[k] & 255u) : 256u + (uint32_t)lane);   // no branch: a lane without a record has a slot of its own
                 __hip_atomic_fetch_or(m, mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 peers[k] = (uint64_t)__hip_atomic_load(m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -956,7 +1001,7 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         for (int k = 0; k < K; ++k) {
             rk[k] = 0u;
             if ((uint32_t)k < steps) {
-                const bool valid = key[k] != kKeyInvalid;
+                const bool valid = in_batch(k, steps, nb);
                 uint32_t* cp = wcur_w + (valid ? (key[k] & 255u) : 256u + (uint32_t)lane);
                 const uint32_t rank = (uint32_t)__popcll(peers[k] & lt);
                 const uint32_t old = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // before the group's first lane adds the group
@@ -978,7 +1023,7 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         // ---- 3. the batch in LDS, ordered by cell
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            if ((uint32_t)k < steps && key[k] != kKeyInvalid) {
+            if (in_batch(k, steps, nb)) {
                 const uint32_t at = cbase[w * 256 + (key[k] & 255u)] + rk[k];
                 st_hv[at] = hv[k];
                 if constexpr (KEYED) st_sw[at] = (uint16_t)(key[k] >> a.id_bits);
@@ -1005,7 +1050,7 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
             if constexpr (ATTR != 0) nx_src = st_src[pn];
             const bool live = i < n;
             const float h = __uint_as_float(r.x), v = __uint_as_float(r.y);
-            if constexpr (HAS_VU) { if (live) advance(sw); }
+            if constexpr (HAS_VU) rp.advance(cs, live ? sw : rp.cur, vu, a.var_floor);
             if constexpr (COUNT_SWEEPS) { if (live && sw != last_sweep) { ++sweeps_seen; last_sweep = sw; } }
             float e2 = ce, s2 = cs;
             const bool taken = fuse_step(e2, s2, h, v, a.mahal, a.var_floor);
@@ -1023,7 +1068,7 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         dbg[8] = n_batches; dbg[9] = acc_nmax;
     }
     if (__ballot(n_total != 0) == 0 && !a.dense) return;               // nothing reached this wave's cells and nothing is pending
-    if constexpr (HAS_VU) advance(last_sw);
+    if constexpr (HAS_VU) rp.finish(cs, last_sw, vu, a.var_floor);
     if (cs < a.var_floor) cs = a.var_floor;                            // GPU:533-534, on every cell
 
     if (owned) {                                                       // only what changed goes back
@@ -1047,6 +1092,53 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         const uint32_t mine = COUNT_SWEEPS ? sweeps_seen : (n_total ? 1u : 0u);
         const uint32_t s = wave_inclusive_scan(mine);
         if (lane == 63 && s) atomicAdd(&a.counters[1], (unsigned long long)s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_block_order : in which order k_fuse_block's workgroups take the blocks (one-pass block-sorted form: the bins are the blocks)
+// ------------------------------------------------------------------------------------------
+// The blocks under the sensor hold ten to thirty times the records of the average block, and a chain step is VALU work: three
+// heavy workgroups resident on one CU share its four SIMDs and run at a third of the speed, while CUs that drew light blocks idle
+// (C4: the walk took as long as the CUs with three 15 000-record blocks, 184 000 cycles; the mean block takes 49 000).  So the
+// blocks are sorted by their record count (a counting sort over count / 32; the counts are the scan's segment sums, known before
+// the scatter runs) and dealt out so that workgroups 3 q, 3 q + 1, 3 q + 2 take the q-th block of the heavy, the middle and the
+// light third: whether the dispatcher fills one CU after the other or goes round them, a CU's resident workgroups are one of
+// each kind, and the heaviest blocks start first.
+constexpr int kOrderNT = 1024, kOrderKeys = 2048;
+
+__global__ __launch_bounds__(kOrderNT) void k_block_order(const uint32_t* __restrict__ segtot, int bins, uint32_t* __restrict__ order)
+{
+    __shared__ uint32_t hist[kOrderKeys], sorted[kOnePassMaxBins], scratch[16];
+    const int tid = (int)threadIdx.x;
+    for (int i = tid; i < kOrderKeys; i += kOrderNT) hist[i] = 0u;
+    __syncthreads();
+    uint32_t key[2], rank[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int b = tid + j * kOrderNT;
+        key[j] = 0u; rank[j] = 0u;
+        if (b < bins) {
+            uint32_t r = 0;
+#pragma unroll
+            for (int sg = 0; sg < kScanSegs; ++sg) r += segtot[(size_t)sg * bins + b];
+            key[j] = (uint32_t)(kOrderKeys - 1) - min(r >> 5, (uint32_t)(kOrderKeys - 1));      // heaviest first
+            rank[j] = atomicAdd(&hist[key[j]], 1u);
+        }
+    }
+    __syncthreads();
+    const uint32_t h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
+    uint32_t all;
+    const uint32_t ex = block_exclusive_scan<kOrderNT>(h0 + h1, scratch, &all);
+    hist[2 * tid] = ex; hist[2 * tid + 1] = ex + h0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int b = tid + j * kOrderNT; if (b < bins) sorted[hist[key[j]] + rank[j]] = (uint32_t)b; }
+    __syncthreads();
+    const int n0 = (bins + 2) / 3, n1 = (bins + 1) / 3;               // sizes of the heavy and the middle third
+    for (int r = tid; r < bins; r += kOrderNT) {
+        const int c = r % 3, q = r / 3;
+        order[r] = sorted[c == 0 ? q : (c == 1 ? n0 + q : n0 + n1 + q)];
     }
 }
 
@@ -1222,6 +1314,13 @@ static hipError_t launch_block_walk_f(hipStream_t st, const WalkArgs& a, int mod
     case 2:  return launch_block_walk_fmb<FLAGS, 2, B>(st, a, ev);
     default: return launch_block_walk_fmb<FLAGS, 3, B>(st, a, ev);
     }
+}
+
+hipError_t launch_block_order(hipStream_t st, const uint32_t* segtot, int bins, uint32_t* order)
+{
+    if (bins <= 0 || bins > kOnePassMaxBins) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_block_order, dim3(1), dim3(kOrderNT), 0, st, segtot, bins, order);
+    return hipGetLastError();
 }
 
 // batch: records of a block staged in LDS per round (2048: three workgroups per CU; 4096, passes without colours / lowest scan

@@ -18,12 +18,12 @@ dbg = {"sort_form": 2}
 for a in sys.argv[1:]:
     if a.startswith("--debug="):
         dbg.update({k: int(v) for k, v in (kv.split("=") for kv in a[8:].split(","))})
-wl = synth.config_c4(n_sweeps=32) if which == "c4" else synth.config_c5()
+wl = synth.config_c4(n_sweeps=32) if which in ("c4", "c4nv") else synth.config_c5()
 cat = torch.from_numpy(np.concatenate(wl.clouds)).cuda()
 off = np.concatenate([[0], np.cumsum([c.shape[0] for c in wl.clouds])])
 m = ElevationMap(wl.length, wl.resolution, debug=dbg)
 lib = _lib.load()
-pb = m.pack_batch(wl.frames, off, wl.var_updates if which == "c4" else None)
+pb = m.pack_batch(wl.frames, off, wl.var_updates if which == "c4" else None)      # c4nv: the same sweeps without variance increments
 for _ in range(3):
     m.add_batch(pb, cat)
 m.synchronize()
