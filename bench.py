@@ -238,24 +238,28 @@ def batched_c4(emap_cls, dev, torch, reps: int = 20):
     kern = {}
     if st["launches_walk"]:
         ls = max(st["launches_sort"], 1)
-        kern = {nm: 1e3 * v / ls for nm, v in zip(names, st["ms_sort"])}
-        kern["k_fuse_walk"] = 1e3 * st["ms_walk"] / st["launches_walk"]
-        # bytes each kernel moves by construction (records of 12 B: {h, var} + key; M = records kept of N points)
-        moved = {"k_sort_project": 16.0 * n + 12.0 * n, "k_sort_scatter": 12.0 * n + 12.0 * records, "k_sort_count": 4.0 * records,
-                 "k_sort_scatter(2)": 24.0 * records, "k_fuse_walk": 12.0 * records + 4.0 * records + 16.0 * L2}
-        dom = max(("k_sort_project", "k_sort_scatter", "k_sort_scatter(2)", "k_fuse_walk"), key=lambda k: kern[k])
+        kern = {nm: 1e3 * v / ls for nm, v in zip(names, st["ms_sort"]) if v > 0}
+        # one counting-sort pass = the block-sorted form (k_fuse_block orders a block's records by cell in LDS); two = cell-sorted (k_fuse_walk)
+        one_pass = "k_sort_scatter(2)" not in kern
+        walk = "k_fuse_block" if one_pass else "k_fuse_walk"
+        kern[walk] = 1e3 * st["ms_walk"] / st["launches_walk"]
+        # bytes each kernel moves by construction (records of 12 B: {h, var} + key; `records` of the n points are kept)
+        moved = {"k_sort_project": 16.0 * n + 12.0 * records, "k_sort_scatter": 24.0 * records, "k_sort_count": 4.0 * records,
+                 "k_sort_scatter(2)": 24.0 * records, walk: 12.0 * records + (0.0 if one_pass else 4.0 * records) + 16.0 * L2}
+        dom = max((k for k in ("k_sort_project", "k_sort_scatter", "k_sort_scatter(2)", walk) if k in kern), key=lambda k: kern[k])
         roof = {"bound": "hbm", "kernel": dom, "us_per_launch": kern[dom], "bytes_moved_by_construction": moved[dom],
                 "achieved": moved[dom] / (kern[dom] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": moved[dom] / (kern[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                "note": "per-kernel figure on the bytes that kernel reads + writes; the pipeline-level figures are frac_of_hbm_peak "
-                        "(SURVEY 8d algorithmic bytes) and frac_of_hbm_peak_must_move above"}
+                "pipeline_bytes_by_construction": sum(moved[k] for k in kern if k in moved),
+                "note": "per-kernel figure on the bytes that kernel reads + writes, its duration taken while the passes overlap as in the timed loop; "
+                        "the pipeline-level figures are frac_of_hbm_peak (SURVEY 8d algorithmic bytes) and frac_of_hbm_peak_must_move above"}
     else:
         kern = {"k_bin_wave": 1e3 * st["ms_bin"] / max(st["launches_bin"], 1), "k_fuse_list": 1e3 * st["ms_fuse"] / max(st["launches_fuse"], 1)}
         roof = None
     return {"workload": "C4: 32 consecutive 131072-pt sweeps + Mapvar_update before each, one batched call, 600x600 map",
             "value": n / dt, "unit": "points/s", "us_per_batch": dt * 1e6, "records_kept": int(records), "cells_touched": int(cells),
             "algorithmic_bytes": alg, "achieved_GBps": alg / dt / 1e9, "frac_of_hbm_peak": alg / dt / 1e9 / HBM_PEAK_GBS,
-            "must_move_bytes": must_move, "frac_of_hbm_peak_must_move": must_move / dt / 1e9 / HBM_PEAK_GBS,
+            "frac_of_6300": alg / dt / 1e9 / HBM_ACHIEVABLE_GBS, "must_move_bytes": must_move, "frac_of_hbm_peak_must_move": must_move / dt / 1e9 / HBM_PEAK_GBS,
             "us_per_kernel": kern, "roofline": roof, "parity_checked": bool(ok)}
 
 

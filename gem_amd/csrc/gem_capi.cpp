@@ -72,7 +72,9 @@ struct gem_handle {
     unsigned pass = 0, sort_pass = 0;
     int sort_streams = 2;               // binning streams the overlapped passes of the sorted pipeline alternate between (debug knob)
     bool trace = false;                 // debug knob: one line on stderr per pass of the sorted pipeline (which streams / buffers it took)
-    int sort_ring = 2;                  // buffer sets they rotate through (debug knob; 2..4: measured equal on C4, two best on C5)
+    int sort_ring = 3;                  // buffer sets they rotate through (debug knob, 2..4).  The sort of pass p may start once the walk of pass p - ring has
+                                        // read its buffers: with two sets that wait -- a host round trip and then the whole sort chain -- sat between consecutive walks
+                                        // (C4 block-sorted: 120 us per batch with two sets, 104 with three, 109 with four)
     // A stream of single device-resident sweeps runs as ONE launch per frame: k_frame fuses the previous
     // frame's records next to the binning of the new cloud.  The fuse of the newest frame is therefore
     // deferred until the next gem_add_device -- or until anything observes or modifies the map.
@@ -91,8 +93,7 @@ struct gem_handle {
     bool walk_permute = true;           // k_fuse_walk: blocks take the tile rows centre-first
     int  sort_passes = 0;               // 0 = by map size and form (sort_geometry); 1 / 2 / 3 force it
     bool fast_laser = true;             // frames that qualify use the zero-rotation-variance form of the laser variance (fill_frame; debug knob)
-    bool block_order = true;            // k_fuse_block takes the blocks by record count (k_block_order; debug knob)
-    int  block_batch = 2048;            // k_fuse_block: records of a block staged in LDS per round (debug knob: 2048 / 4096)
+    bool lane_sort = true;              // k_fuse_block: cells to threads by record count (debug knob)
     int  sort_form = 0;                 // 0 = batches of sweeps BLOCK-sorted (k_fuse_block), single clouds CELL-sorted (k_fuse_walk); 1 / 2 force cell / block
     int dbg_sweep = 0;                  // debug stamps of the dense path: which sweep (GEM_DBG_SWEEP)
     bool track_lowest = false;          // also maintain map_lowest in the fuse kernels (gem_set_lowest_tracking, for gem_raytracing)
@@ -449,8 +450,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     for (int i = 0; i < geo.n_passes; ++i) { o_seg[i] = o_next; o_next += (size_t)geo.dbins[i] * 16; }
     const size_t o_total = o_next, o_base = (o_total + 4 + 15) & ~(size_t)15;
     const size_t o_segcnt = (o_base + ((size_t)geo.dbins[geo.n_passes - 1] + 1) * 4 + 15) & ~(size_t)15;
-    const size_t o_order = (o_segcnt + (size_t)NC1 * kSortSegsPerChunk * 4 + 15) & ~(size_t)15;       // workgroup -> block of k_fuse_block
-    if ((rc = ensure(h, pb.s_misc, o_order + (size_t)kOnePassMaxBins * 4))) return rc;
+    if ((rc = ensure(h, pb.s_misc, o_segcnt + (size_t)NC1 * kSortSegsPerChunk * 4))) return rc;
     // the walk of pass p-2 has read these buffers (host-side wait, see run_pipeline)
     if (overlap && pb.fuse_recorded) GEM_HIP(h, hipEventSynchronize(pb.fuse_done));
 
@@ -528,6 +528,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     wa.T = T; wa.tiles_per_row = geo.tiles_per_row; wa.L = h->L; wa.row0 = h->row0; wa.row1 = h->row1;
     wa.id_bits = geo.id_bits; wa.bin_shift = geo.dshift[geo.n_passes - 1]; wa.n_sweeps = in.n_sweeps;
     wa.exact_bins = (geo.block_form && geo.n_passes == 1) ? 1 : 0;
+    wa.lane_sort = h->lane_sort ? 1 : 0;
     wa.mahal = h->cfg.mahalanobis_threshold; wa.var_floor = h->cfg.variance_floor;
     wa.dense = dense ? 1 : 0;
     wa.n_pending = h->n_pending;
@@ -559,12 +560,6 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
             if (laser) src = fast ? 4 : 2;                       // 4: every frame's rotation variance is zero (height_variance, kModelLaserFast)
         }
         GEM_HIP(h, launch_sort(sbin, sa, src, with_src, ev));
-    }
-    if (wa.exact_bins && h->block_order && geo.dbins[0] == 4 * T) {
-        // the blocks by record count: what the scan already knows (segment sums of the one pass)
-        uint32_t* order = reinterpret_cast<uint32_t*>(misc + o_order);
-        GEM_HIP(h, launch_block_order(sbin, sa.segtot[0], geo.dbins[0], order));
-        wa.order = order;
     }
     if (shard) {
         // where the strips begin in the sorted records: one 32-ary search per boundary, then the only host round trip of the path
@@ -606,7 +601,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
         wa.dbg = static_cast<unsigned long long*>(h->dbg.p);
         h->dbg_rows = T * 4;
     }
-    { Timed t(h, 9); GEM_HIP(h, geo.block_form ? launch_block_walk(h->stream, wa, attr, h->block_batch, t.events()) : launch_walk(h->stream, wa, attr, t.events())); }
+    { Timed t(h, 9); GEM_HIP(h, geo.block_form ? launch_block_walk(h->stream, wa, attr, t.events()) : launch_walk(h->stream, wa, attr, t.events())); }
     if (overlap) { GEM_HIP(h, hipEventRecord(pb.fuse_done, h->stream)); pb.fuse_recorded = true; }
     h->n_pending = 0;
     h->floor_dirty = false;
@@ -631,7 +626,10 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
         // block-sorted form (one counting-sort pass for the 600^2 map instead of two, no per-cell order in HBM at all); a single
         // dense cloud (a depth image: a quarter of its points in one block, hundreds per cell, image row by image row) needs the
         // whole chip to order it by cell: the cell-sorted form.
-        const bool block_form = h->sort_form == 2 || (h->sort_form == 0 && in0.n_sweeps > 1);
+        // (Maps of more than kOnePassMaxBins blocks would need two passes over the block id and a search per block: their batches
+        //  stay cell-sorted -- C5, 2400^2: 341 us cell-sorted in three passes, 353 block-sorted in two.)
+        const long long blocks = 4ll * ((h->L + 31) / 32) * ((h->L + 31) / 32);
+        const bool block_form = h->sort_form == 2 || (h->sort_form == 0 && in0.n_sweeps > 1 && blocks <= kOnePassMaxBins);
         SortGeometry geo = sort_geometry(h, in0.n_sweeps, block_form);
         if (!geo.ok) geo = sort_geometry(h, in0.n_sweeps, !block_form);
         if (geo.ok) return run_sort_pipeline(h, in0, attr, geo);
@@ -1575,8 +1573,7 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "sort_ring")          { if (value < 2 || value > 4) return fail(h, GEM_ERR_INVALID, "sort_ring: 2..4"); h->sort_ring = (int)value; }
     else if (k == "sort_streams")       { if (value != 1 && value != 2) return fail(h, GEM_ERR_INVALID, "sort_streams: 1 or 2"); h->sort_streams = (int)value; }
     else if (k == "sort_passes")        { if (value < 0 || value > 3) return fail(h, GEM_ERR_INVALID, "sort_passes: 0..3"); h->sort_passes = (int)value; }
-    else if (k == "block_order")        h->block_order = value != 0;
-    else if (k == "block_batch")        { if (value != 2048 && value != 4096) return fail(h, GEM_ERR_INVALID, "block_batch: 2048 or 4096"); h->block_batch = (int)value; }
+    else if (k == "lane_sort")          h->lane_sort = value != 0;
     else if (k == "fast_laser")         h->fast_laser = value != 0;
     else if (k == "sort_form")          { if (value < 0 || value > 2) return fail(h, GEM_ERR_INVALID, "sort_form: 0 (by pass), 1 (cell-sorted), 2 (block-sorted)"); h->sort_form = (int)value; }
     else return fail(h, GEM_ERR_INVALID, "gem_debug_set: unknown key");
@@ -1772,6 +1769,7 @@ static int shard_fuse_locked(gem_handle* h, int n_src, const void* const* d_hv, 
     wa.counters = h->counting ? h->d_counters : nullptr;
     wa.count_per_pass = 0;
     wa.walk_order = (h->walk_permute && 4ll * geo.T <= 4096) ? 1 : 0;
+    wa.lane_sort = h->lane_sort ? 1 : 0;
     wa.center_tr = ((h->L / 2 + h->start[0]) % h->L) >> 5;
     if (var_updates_global) {
         if (n_global_sweeps > 512) return fail(h, GEM_ERR_INVALID, "sharded path: more than 512 sweeps");
@@ -1785,7 +1783,7 @@ static int shard_fuse_locked(gem_handle* h, int n_src, const void* const* d_hv, 
         wa.var_updates = dv;
     }
     if (h->counting) GEM_HIP(h, hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
-    { Timed t(h, 9); GEM_HIP(h, launch_block_walk(h->stream, wa, 0, h->block_batch, t.events())); }
+    { Timed t(h, 9); GEM_HIP(h, launch_block_walk(h->stream, wa, 0, t.events())); }
     h->n_pending = 0;
     h->floor_dirty = false;
     h->main_reads_pb = true;

@@ -159,8 +159,8 @@ struct WalkArgs {
     unsigned long long* counters;      // optional: [1] += distinct touched cells (per sweep unless count_per_pass)
     int   count_per_pass;
     // k_fuse_block only:
-    const uint32_t* order;             // optional: [4 T] workgroup -> block (k_block_order), else by position
     unsigned long long* dbg;           // optional: [blocks][16] cycle stamps of thread 0 (profiling aid, gem_debug_fuse_stamps)
+    int   lane_sort;                   // 1: the block's cells are handed to the threads in descending order of their record count in the first batch
     int   exact_bins;                  // 1: the last pass's bins ARE the blocks (one-pass sort): bin_base gives a block's records without a search
     // multi-GPU strip owner (gem_add_sharded_device): the block-sorted records received from every rank, taken in rank order
     int   n_src;                       // <= 1: the single source above (hv / key / src, searched through bin_base)
@@ -172,8 +172,7 @@ struct SortShape { int nt, chunk; size_t lds; };
 SortShape  sort_shape(int bins, bool attr);   // workgroup shape of a pass with that many bins
 hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, const LaunchEvents ev[9]);   // project, scan, scatter | count, scan, scatter | (count, scan, scatter)
 hipError_t launch_walk(hipStream_t st, const WalkArgs& a, int flags, LaunchEvents ev);                    // cell-sorted records
-hipError_t launch_block_walk(hipStream_t st, const WalkArgs& a, int flags, int batch, LaunchEvents ev);   // block-sorted records; batch = records staged in LDS per round (2048 / 4096)
-hipError_t launch_block_order(hipStream_t st, const uint32_t* segtot, int bins, uint32_t* order);   // one-pass block-sorted form: workgroup -> block, by record count
+hipError_t launch_block_walk(hipStream_t st, const WalkArgs& a, int flags, LaunchEvents ev);              // block-sorted records
 constexpr int kOnePassMaxBins = 2048;  // block-sorted: maps of up to this many blocks are sorted by ONE counting-sort pass
 hipError_t launch_strip_bounds(hipStream_t st, const uint32_t* keys, const uint32_t* n_records, int id_bits, const uint32_t* ids, uint32_t* out, int n);
 constexpr int kSortChunkRecords = 4096, kSortSegsPerChunk = 4;   // records per counting-sort chunk; 1024-point wave segments per pass-1 chunk (seg_cnt words)

@@ -835,17 +835,20 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
     uint32_t* cbase = wcur + NW * 320;                                                  // [NW][256] where the run of (wave, cell) starts in the batch
     uint32_t* st_src = cbase + NW * 256;                                                // [B] (ATTR)
     uint16_t* st_sw = reinterpret_cast<uint16_t*>(st_src + (ATTR ? B : 0));             // [B] (KEYED) the record's sweep
-    __shared__ uint32_t scratch[16];
+    __shared__ uint32_t scratch[16], ccnt[NT], phist[128];
+    __shared__ uint16_t perm[NT];
+    __shared__ float sh_e[NT], sh_s[NT], sh_l[LOWEST ? NT : 1];
     __shared__ float vu[HAS_VU ? kWalkMaxSweeps + 8 : 1];
     __shared__ uint32_t seg_first[kMaxRanks], seg_off[kMaxRanks + 1];                  // per source: first record of the block; prefix of the counts
     __shared__ unsigned long long seg_key[kMaxRanks], seg_hv[kMaxRanks];
     const int tid = (int)threadIdx.x, lane = lane_id(), w = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // workgroup -> block of 256 cells: by record count (k_block_order) when the sort knows it, else tile rows centre-first when all
-    // workgroups are resident at once (see k_fuse_walk), else memory order
+    // workgroup -> block of 256 cells: tile rows centre-first when all workgroups are resident at once (see k_fuse_walk), else memory
+    // order.  (Tried: the blocks sorted by record count on the device and dealt out heavy / middle / light to consecutive
+    // workgroups, so that no CU holds three blocks of the sensor's neighbourhood at once -- a kernel more, no gain: the walk ends
+    // with the chains of its heaviest block whatever runs beside it.)
     int tile, q4 = (int)(blockIdx.x & 3);
-    if (a.order) { const uint32_t blk = a.order[blockIdx.x]; tile = (int)(blk >> 2); q4 = (int)(blk & 3u); }
-    else {
+    {
         const int tpr = a.tiles_per_row, rnk = (int)(blockIdx.x >> 2);
         if (a.walk_order) {
             const int bi = rnk / tpr, bj = rnk - bi * tpr;
@@ -861,19 +864,20 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
     const int n_src = a.n_src <= 1 ? 1 : a.n_src;
     if (a.dbg && tid == 0) a.dbg[(size_t)blockIdx.x * 16] = __builtin_readcyclecounter();
 
-    // ---- the thread's cell: its map values are fetched now, coalesced, in flight behind the search
+    // ---- cell tid of the block: its map values are fetched now, coalesced, in flight behind the search; which cell the thread
+    //      WALKS is decided after the first batch (below)
     const int L = a.L;
-    const int row = (tr << 5) + (q4 << 3) + (tid >> 5), col = (tc << 5) + (tid & 31);
-    const bool owned = row >= a.row0 && row < a.row1 && col < L;
-    const size_t g = owned ? (size_t)row * L + col : 0;
-    const float e0 = a.elevation[g], s0 = a.variance[g];
-    size_t lgeo = 0; float lw = 0.0f, lw0 = 0.0f;
+    const int row_t = (tr << 5) + (q4 << 3) + (tid >> 5), col_t = (tc << 5) + (tid & 31);
+    const bool owned_t = row_t >= a.row0 && row_t < a.row1 && col_t < L;
+    const size_t g_t = owned_t ? (size_t)row_t * L + col_t : 0;
+    sh_e[tid] = a.elevation[g_t]; sh_s[tid] = a.variance[g_t];
     if constexpr (LOWEST) {                                            // map_lowest is indexed by the GEOGRAPHIC cell (GPU:430)
-        int gr = row - a.start0, gc = col - a.start1;
+        int gr = row_t - a.start0, gc = col_t - a.start1;
         gr += gr < 0 ? L : 0; gc += gc < 0 ? L : 0;
-        lgeo = owned ? (size_t)gr * L + gc : 0;
-        lw0 = lw = a.lowest[lgeo];
+        sh_l[tid] = a.lowest[owned_t ? (size_t)gr * L + gc : 0];
     }
+    if (tid < 128) phist[tid] = 0u;
+    perm[tid] = (uint16_t)tid;
     if constexpr (HAS_VU) for (int i = tid; i < kWalkMaxSweeps + 8; i += NT) vu[i] = i < a.n_sweeps ? a.var_updates[i] : 0.0f;
 
     // ---- where the block's records are in every source.  One-pass sort: the last pass's bins are the blocks.  Otherwise a
@@ -936,15 +940,35 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         return seg_first[s] + (q - seg_off[s]);
     };
 
-    float ce = e0, cs = s0;
-    // From sweep `cur` to sweep `to`: the floor that ends every Fuse (GPU:533-534), then the next sweep's increment; the increment
-    // of the lane's NEXT sweep is kept in a register so that the common one-sweep gap costs no LDS round trip (see k_fuse_walk).
+    // ---- the cell this thread walks, and its state.  A wave lasts as long as its longest chain and the chains of 64 neighbouring
+    //      cells differ widely (a LiDAR ring crosses some cells of a row and misses the next), so after the first batch the block's
+    //      cells are handed out in descending order of their record count in that batch -- wave 0 takes the 64 busiest cells, the
+    //      last wave the empty ones -- by a counting sort over the counts (exact below 64, eight steps per octave above).  The
+    //      assignment then stays: the state lives in registers from batch to batch.
+    uint32_t c = (uint32_t)tid;
+    int row = 0, col = 0; bool owned = false; size_t g = 0, lgeo = 0;
+    float e0 = 0.0f, s0 = 0.0f, lw = 0.0f, lw0 = 0.0f, ce = 0.0f, cs = 0.0f;
     const uint32_t last_sw = (uint32_t)(a.n_sweeps > 0 ? a.n_sweeps - 1 : 0);
     SweepReplay rp; rp.cur = 0u; rp.w0 = rp.w1 = rp.w2 = rp.w3 = 0.0f;
     uint32_t wlast = 0xffffffffu, sweeps_seen = 0, last_sweep = 0xffffffffu, n_total = 0;
-    // Mapvar_update increments queued before this pass, then the one of sweep 0 (GPU:540-547)
-    for (int k = 0; k < a.n_pending; ++k) if (cs != kInitVariance) cs += a.pending[k];
-    if constexpr (HAS_VU) { if (cs != kInitVariance) cs += vu[0]; rp.refill(vu); }
+    auto take_cell = [&]() {                                           // (sh_e / sh_s / perm are final: behind a barrier)
+        c = perm[tid];
+        row = (tr << 5) + (q4 << 3) + (int)(c >> 5); col = (tc << 5) + (int)(c & 31u);
+        owned = row >= a.row0 && row < a.row1 && col < L;
+        g = owned ? (size_t)row * L + col : 0;
+        e0 = sh_e[c]; s0 = sh_s[c];
+        if constexpr (LOWEST) {
+            int gr = row - a.start0, gc = col - a.start1;
+            gr += gr < 0 ? L : 0; gc += gc < 0 ? L : 0;
+            lgeo = owned ? (size_t)gr * L + gc : 0;
+            lw0 = lw = sh_l[c];
+        }
+        ce = e0; cs = s0;
+        // Mapvar_update increments queued before this pass, then the one of sweep 0 (GPU:540-547)
+        for (int k = 0; k < a.n_pending; ++k) if (cs != kInitVariance) cs += a.pending[k];
+        if constexpr (HAS_VU) { if (cs != kInitVariance) cs += vu[0]; rp.refill(vu); }
+    };
+    if (R == 0) take_cell();                                           // (a dense pass over a block without records: every thread keeps cell tid)
 
     const uint64_t lt = lanemask_lt();
     const unsigned long long mybit = 1ull << lane;
@@ -1018,6 +1042,20 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         uint32_t all;
         const uint32_t first = block_exclusive_scan_alt<NT>(n, scratch, parity++, &all);
         cbase[0 * 256 + tid] = first; cbase[1 * 256 + tid] = first + n0; cbase[2 * 256 + tid] = first + n0 + n1; cbase[3 * 256 + tid] = first + n0 + n1 + n2;
+        ccnt[tid] = n;
+        if (P == 0u && a.lane_sort) {                                  // block-uniform: who walks which cell (see above)
+            uint32_t bin = n;
+            if (n >= 64u) { const uint32_t lg = 31u - (uint32_t)__clz((int)n); bin = 64u + min(63u, (lg - 6u) * 8u + ((n >> (lg - 3u)) & 7u)); }
+            const uint32_t rank = atomicAdd(&phist[bin], 1u);
+            __syncthreads();
+            if (w == 0) {                                              // phist[b] -> cells with more records than bin b's
+                const uint32_t v1 = phist[127 - 2 * lane], v0 = phist[126 - 2 * lane];
+                const uint32_t incl = wave_inclusive_scan(v1 + v0), excl = incl - (v1 + v0);
+                phist[127 - 2 * lane] = excl; phist[126 - 2 * lane] = excl + v1;
+            }
+            __syncthreads();
+            perm[phist[bin] + rank] = (uint16_t)tid;
+        }
         __syncthreads();
         lap(acc_base);
         // ---- 3. the batch in LDS, ordered by cell
@@ -1034,21 +1072,23 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         lap(acc_place);
         // the next batch's records: in flight behind the chains
         if (P + (uint32_t)B < R) load_batch(P + (uint32_t)B, min(R - P - (uint32_t)B, (uint32_t)B));
-        // ---- 4. the thread's cell: its n records of this batch, in input order
-        n_total += n;
-        const uint32_t nmax = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_max(n), 63);
-        const uint32_t lastp = n ? first + n - 1u : 0u;
-        uint2 nx = st_hv[min(first, lastp)];
+        // ---- 4. the thread's cell: its records of this batch, in input order
+        if (P == 0u) take_cell();
+        const uint32_t cn = ccnt[c], cf = cbase[c];
+        n_total += cn;
+        const uint32_t nmax = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_max(cn), 63);
+        const uint32_t lastp = cn ? cf + cn - 1u : 0u;
+        uint2 nx = st_hv[min(cf, lastp)];
         uint32_t nx_sw = 0, nx_src = 0;
-        if constexpr (KEYED) nx_sw = st_sw[min(first, lastp)];
-        if constexpr (ATTR != 0) nx_src = st_src[min(first, lastp)];
+        if constexpr (KEYED) nx_sw = st_sw[min(cf, lastp)];
+        if constexpr (ATTR != 0) nx_src = st_src[min(cf, lastp)];
         for (uint32_t i = 0; i < nmax; ++i) {                          // wave-uniform
             const uint2 r = nx; const uint32_t sw = nx_sw, sr = nx_src;
-            const uint32_t pn = min(first + i + 1u, lastp);
+            const uint32_t pn = min(cf + i + 1u, lastp);
             nx = st_hv[pn];
             if constexpr (KEYED) nx_sw = st_sw[pn];
             if constexpr (ATTR != 0) nx_src = st_src[pn];
-            const bool live = i < n;
+            const bool live = i < cn;
             const float h = __uint_as_float(r.x), v = __uint_as_float(r.y);
             if constexpr (HAS_VU) rp.advance(cs, live ? sw : rp.cur, vu, a.var_floor);
             if constexpr (COUNT_SWEEPS) { if (live && sw != last_sweep) { ++sweeps_seen; last_sweep = sw; } }
@@ -1092,53 +1132,6 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         const uint32_t mine = COUNT_SWEEPS ? sweeps_seen : (n_total ? 1u : 0u);
         const uint32_t s = wave_inclusive_scan(mine);
         if (lane == 63 && s) atomicAdd(&a.counters[1], (unsigned long long)s);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_block_order : in which order k_fuse_block's workgroups take the blocks (one-pass block-sorted form: the bins are the blocks)
-// ------------------------------------------------------------------------------------------
-// The blocks under the sensor hold ten to thirty times the records of the average block, and a chain step is VALU work: three
-// heavy workgroups resident on one CU share its four SIMDs and run at a third of the speed, while CUs that drew light blocks idle
-// (C4: the walk took as long as the CUs with three 15 000-record blocks, 184 000 cycles; the mean block takes 49 000).  So the
-// blocks are sorted by their record count (a counting sort over count / 32; the counts are the scan's segment sums, known before
-// the scatter runs) and dealt out so that workgroups 3 q, 3 q + 1, 3 q + 2 take the q-th block of the heavy, the middle and the
-// light third: whether the dispatcher fills one CU after the other or goes round them, a CU's resident workgroups are one of
-// each kind, and the heaviest blocks start first.
-constexpr int kOrderNT = 1024, kOrderKeys = 2048;
-
-__global__ __launch_bounds__(kOrderNT) void k_block_order(const uint32_t* __restrict__ segtot, int bins, uint32_t* __restrict__ order)
-{
-    __shared__ uint32_t hist[kOrderKeys], sorted[kOnePassMaxBins], scratch[16];
-    const int tid = (int)threadIdx.x;
-    for (int i = tid; i < kOrderKeys; i += kOrderNT) hist[i] = 0u;
-    __syncthreads();
-    uint32_t key[2], rank[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int b = tid + j * kOrderNT;
-        key[j] = 0u; rank[j] = 0u;
-        if (b < bins) {
-            uint32_t r = 0;
-#pragma unroll
-            for (int sg = 0; sg < kScanSegs; ++sg) r += segtot[(size_t)sg * bins + b];
-            key[j] = (uint32_t)(kOrderKeys - 1) - min(r >> 5, (uint32_t)(kOrderKeys - 1));      // heaviest first
-            rank[j] = atomicAdd(&hist[key[j]], 1u);
-        }
-    }
-    __syncthreads();
-    const uint32_t h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
-    uint32_t all;
-    const uint32_t ex = block_exclusive_scan<kOrderNT>(h0 + h1, scratch, &all);
-    hist[2 * tid] = ex; hist[2 * tid + 1] = ex + h0;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 2; ++j) { const int b = tid + j * kOrderNT; if (b < bins) sorted[hist[key[j]] + rank[j]] = (uint32_t)b; }
-    __syncthreads();
-    const int n0 = (bins + 2) / 3, n1 = (bins + 1) / 3;               // sizes of the heavy and the middle third
-    for (int r = tid; r < bins; r += kOrderNT) {
-        const int c = r % 3, q = r / 3;
-        order[r] = sorted[c == 0 ? q : (c == 1 ? n0 + q : n0 + n1 + q)];
     }
 }
 
@@ -1305,39 +1298,33 @@ static hipError_t launch_block_walk_fmb(hipStream_t st, const WalkArgs& a, Launc
     return hipGetLastError();
 }
 
-template <int FLAGS, int B>
+constexpr int kBlkBatch = 2048;   // records of a block staged in LDS per round: three workgroups per CU (4096: two per CU, half the rounds
+                                  // for the blocks under the sensor -- whose chains stay as long; C4 104 -> 116 us per batch)
+
+template <int FLAGS>
 static hipError_t launch_block_walk_f(hipStream_t st, const WalkArgs& a, int mode, LaunchEvents ev)
 {
     switch (mode) {
-    case 0:  return launch_block_walk_fmb<FLAGS, 0, B>(st, a, ev);
-    case 1:  return launch_block_walk_fmb<FLAGS, 1, B>(st, a, ev);
-    case 2:  return launch_block_walk_fmb<FLAGS, 2, B>(st, a, ev);
-    default: return launch_block_walk_fmb<FLAGS, 3, B>(st, a, ev);
+    case 0:  return launch_block_walk_fmb<FLAGS, 0, kBlkBatch>(st, a, ev);
+    case 1:  return launch_block_walk_fmb<FLAGS, 1, kBlkBatch>(st, a, ev);
+    case 2:  return launch_block_walk_fmb<FLAGS, 2, kBlkBatch>(st, a, ev);
+    default: return launch_block_walk_fmb<FLAGS, 3, kBlkBatch>(st, a, ev);
     }
 }
 
-hipError_t launch_block_order(hipStream_t st, const uint32_t* segtot, int bins, uint32_t* order)
-{
-    if (bins <= 0 || bins > kOnePassMaxBins) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_block_order, dim3(1), dim3(kOrderNT), 0, st, segtot, bins, order);
-    return hipGetLastError();
-}
-
-// batch: records of a block staged in LDS per round (2048: three workgroups per CU; 4096, passes without colours / lowest scan
-// points only: two per CU, half as many rounds for the blocks under the sensor)
-hipError_t launch_block_walk(hipStream_t st, const WalkArgs& a, int flags, int batch, LaunchEvents ev)
+hipError_t launch_block_walk(hipStream_t st, const WalkArgs& a, int flags, LaunchEvents ev)
 {
     if (a.T <= 0) return hipSuccess;
     if (a.n_sweeps > kWalkMaxSweeps || a.n_src > kMaxRanks) return hipErrorInvalidValue;
     if (a.n_src > 1 && flags != 0) return hipErrorInvalidValue;       // records received from other ranks carry no colours / lowest scan points
     const int mode = (a.var_updates ? 1 : 0) | ((a.counters && !a.count_per_pass) ? 2 : 0);
     switch (flags) {
-    case 0: return batch >= 4096 ? launch_block_walk_f<0, 4096>(st, a, mode, ev) : launch_block_walk_f<0, 2048>(st, a, mode, ev);
-    case 1: return launch_block_walk_f<1, 2048>(st, a, mode, ev);
-    case 2: return launch_block_walk_f<2, 2048>(st, a, mode, ev);
-    case 4: return launch_block_walk_f<4, 2048>(st, a, mode, ev);
-    case 5: return launch_block_walk_f<5, 2048>(st, a, mode, ev);
-    case 6: return launch_block_walk_f<6, 2048>(st, a, mode, ev);
+    case 0: return launch_block_walk_f<0>(st, a, mode, ev);
+    case 1: return launch_block_walk_f<1>(st, a, mode, ev);
+    case 2: return launch_block_walk_f<2>(st, a, mode, ev);
+    case 4: return launch_block_walk_f<4>(st, a, mode, ev);
+    case 5: return launch_block_walk_f<5>(st, a, mode, ev);
+    case 6: return launch_block_walk_f<6>(st, a, mode, ev);
     default: return hipErrorInvalidValue;
     }
 }
