@@ -385,10 +385,11 @@ def c2_variants(emap_cls, dev, torch, reps: int = 400):
 # ---- N > 1: C5, strong scaling ------------------------------------------------------------------------------------------------
 def run_c5_distributed(args, torch, dist, world, rank, local_rank, dev):
     from gem_amd import ElevationMap
-    from gem_amd.tiling import shard_batch, tile_strip_rows
+    from gem_amd.tiling import first_point_in_sweep, shard_batch, tile_strip_rows
     wl, cat, off = c5_cloud()
     n_total = int(off[-1])
     first, local = shard_batch(off, world, rank)
+    fp = first_point_in_sweep(off, first, local)
     # only this rank's share of the cloud has to be resident
     d_share = torch.from_numpy(cat[local[0]:local[-1]]).to(dev)
     emap = ElevationMap(wl.length, wl.resolution, device=local_rank)
@@ -398,7 +399,7 @@ def run_c5_distributed(args, torch, dist, world, rank, local_rank, dev):
     pb = emap.pack_batch([wl.frames[first + i] for i in range(len(local) - 1)], [v - local[0] for v in local], None)
 
     def step():
-        emap.add_sharded(pb, d_share, first, len(wl.frames), None)
+        emap.add_sharded(pb, d_share, first, len(wl.frames), None, fp)
         emap.allgather_layers(False)
 
     def barrier():
@@ -420,7 +421,7 @@ def run_c5_distributed(args, torch, dist, world, rank, local_rank, dev):
     # what every rank holds after the all-gather is the whole map: check it against the committed digest of ONE pass
     chk = ElevationMap(wl.length, wl.resolution, device=local_rank)
     chk.comm_init_tiles(uid[1], world, rank)
-    chk.add_sharded(pb, d_share, first, len(wl.frames), None)
+    chk.add_sharded(pb, d_share, first, len(wl.frames), None, fp)
     chk.allgather_layers(False)
     d = golden()["c5_full"]
     ok = sha(chk.layer("elevation")) == d["elevation"] and sha(chk.layer("variance")) == d["variance"]

@@ -85,10 +85,11 @@ SIGNATURES = {
     "gem_show": (c_int, [c_void_p, c_double, c_double, POINTER(c_double), c_void_p, c_void_p, c_void_p, POINTER(c_int), c_void_p]),
     "gem_comm_init_tiles": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "gem_get_strip": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
-    "gem_add_sharded_device": (c_int, [c_void_p, c_int, POINTER(FrameParams), c_void_p, POINTER(c_longlong), c_int, c_int, POINTER(c_float)]),
-    "gem_shard_sort_device": (c_int, [c_void_p, c_int, POINTER(FrameParams), c_void_p, POINTER(c_longlong), c_int, c_int, c_int, POINTER(c_int),
-                                      POINTER(c_uint32), POINTER(c_void_p), POINTER(c_void_p)]),
-    "gem_shard_fuse_device": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_uint32), c_int, POINTER(c_float)]),
+    "gem_add_sharded_device": (c_int, [c_void_p, c_int, POINTER(FrameParams), c_void_p, POINTER(c_longlong), c_int, c_int, c_int, POINTER(c_float)]),
+    "gem_shard_sort_device": (c_int, [c_void_p, c_int, POINTER(FrameParams), c_void_p, POINTER(c_longlong), c_int, c_int, c_int, c_int, POINTER(c_int),
+                                      POINTER(c_uint32), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
+    "gem_shard_fuse_device": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_uint32), POINTER(c_void_p), POINTER(c_uint32),
+                                      c_int, POINTER(c_float)]),
 }
 # include/gem_hip_debug.h (tuning knobs / profiling aids, not part of the drop-in surface)
 DEBUG_SIGNATURES = {

@@ -510,31 +510,36 @@ class ElevationMap:
         return int(r0.value), int(r1.value)
 
     # -- multi-GPU with the points sharded (SURVEY 8e stage B) --------------------------------------------------------------
-    def add_sharded(self, pb: "PackedBatch", xyzi_device, first_global_sweep: int, n_global_sweeps: int, var_updates_global=None) -> None:
-        """This rank's contiguous share of a batch (local sweeps of `pb`, numbered first_global_sweep.. globally): sort, RCCL
-        exchange of the sorted records to the strip owners, walk in rank order (gem_add_sharded_device)."""
+    def add_sharded(self, pb: "PackedBatch", xyzi_device, first_global_sweep: int, n_global_sweeps: int, var_updates_global=None,
+                    first_point_in_sweep: int = 0) -> None:
+        """This rank's contiguous share of a batch (local sweeps of `pb`, numbered first_global_sweep.. globally; its first point is
+        point first_point_in_sweep of its sweep): sort, RCCL exchange of the sorted records to the strip owners, walk in rank order
+        (gem_add_sharded_device)."""
         vu = None if var_updates_global is None else (C.c_float * n_global_sweeps)(*[float(v) for v in var_updates_global])
         ptr = C.c_void_p(xyzi_device.data_ptr()) if pb.n else None
         self._check(self._lib.gem_add_sharded_device(self._h, pb.n, pb.frames, ptr, pb.offsets, int(first_global_sweep),
-                                                     int(n_global_sweeps), vu), "gem_add_sharded_device")
+                                                     int(n_global_sweeps), int(first_point_in_sweep), vu), "gem_add_sharded_device")
 
-    def shard_sort(self, pb: "PackedBatch", xyzi_device, first_global_sweep: int, n_global_sweeps: int, strip_rows):
-        """First half: returns (bounds [nstrips + 1], device pointer of the sorted {h, var} records, of their keys)."""
+    def shard_sort(self, pb: "PackedBatch", xyzi_device, first_global_sweep: int, n_global_sweeps: int, strip_rows, first_point_in_sweep: int = 0,
+                   with_ranges: bool = False):
+        """First half: returns (bounds [nstrips + 1], device pointer of the sorted {h, var} records, of their keys[, of the block ranges])."""
         ns = len(strip_rows) - 1
         rows = (C.c_int * (ns + 1))(*[int(v) for v in strip_rows])
         bounds = (C.c_uint32 * (ns + 1))()
-        phv, pkey = C.c_void_p(), C.c_void_p()
+        phv, pkey, prng = C.c_void_p(), C.c_void_p(), C.c_void_p()
         ptr = C.c_void_p(xyzi_device.data_ptr()) if pb.n else None
         self._check(self._lib.gem_shard_sort_device(self._h, pb.n, pb.frames, ptr, pb.offsets, int(first_global_sweep), int(n_global_sweeps),
-                                                    ns, rows, bounds, C.byref(phv), C.byref(pkey)), "gem_shard_sort_device")
-        return np.array(bounds[:], np.int64), phv.value or 0, pkey.value or 0
+                                                    int(first_point_in_sweep), ns, rows, bounds, C.byref(phv), C.byref(pkey), C.byref(prng)),
+                    "gem_shard_sort_device")
+        out = (np.array(bounds[:], np.int64), phv.value or 0, pkey.value or 0)
+        return out + (prng.value or 0,) if with_ranges else out
 
-    def shard_sort_tensors(self, pb, xyzi_device, first_global_sweep, n_global_sweeps, strip_rows):
+    def shard_sort_tensors(self, pb, xyzi_device, first_global_sweep, n_global_sweeps, strip_rows, first_point_in_sweep: int = 0):
         """shard_sort with the sorted records as torch tensors aliasing the handle's arenas ([M, 2] int32 {h, var} bits, [M] int32
         keys); they stay valid until the next pass of this handle."""
         import torch
         from .tiling import _DeviceArray
-        bounds, phv, pkey = self.shard_sort(pb, xyzi_device, first_global_sweep, n_global_sweeps, strip_rows)
+        bounds, phv, pkey = self.shard_sort(pb, xyzi_device, first_global_sweep, n_global_sweeps, strip_rows, first_point_in_sweep)
         m = int(bounds[-1])
         if m == 0:
             dev = xyzi_device.device
@@ -550,14 +555,17 @@ class ElevationMap:
         self.shard_fuse([t.data_ptr() if t.numel() else 0 for t in hv_list], [t.data_ptr() if t.numel() else 0 for t in key_list],
                         [int(t.shape[0]) for t in key_list], n_global_sweeps, var_updates_global)
 
-    def shard_fuse(self, hv_ptrs, key_ptrs, counts, n_global_sweeps: int, var_updates_global=None) -> None:
-        """Second half: walk this handle's strip through the sources (device pointers + record counts) in the order given."""
+    def shard_fuse(self, hv_ptrs, key_ptrs, counts, n_global_sweeps: int, var_updates_global=None, range_ptrs=None, bases=None) -> None:
+        """Second half: walk this handle's strip through the sources (device pointers + record counts) in the order given; with
+        range_ptrs / bases the sources' own block ranges replace the search (gem_hip.h)."""
         n = len(counts)
         a_hv = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in hv_ptrs])
         a_key = (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in key_ptrs])
         a_cnt = (C.c_uint32 * n)(*[int(c) for c in counts])
+        a_rng = None if range_ptrs is None else (C.c_void_p * n)(*[C.c_void_p(int(p)) for p in range_ptrs])
+        a_base = None if bases is None else (C.c_uint32 * n)(*[int(b) for b in bases])
         vu = None if var_updates_global is None else (C.c_float * n_global_sweeps)(*[float(v) for v in var_updates_global])
-        self._check(self._lib.gem_shard_fuse_device(self._h, n, a_hv, a_key, a_cnt, int(n_global_sweeps), vu), "gem_shard_fuse_device")
+        self._check(self._lib.gem_shard_fuse_device(self._h, n, a_hv, a_key, a_cnt, a_rng, a_base, int(n_global_sweeps), vu), "gem_shard_fuse_device")
 
 
 class RobotMotionMapUpdater:

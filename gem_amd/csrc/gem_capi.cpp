@@ -60,6 +60,7 @@ struct gem_handle {
     struct PassBuffers {
         Arena rec, srt, seg, flag, gflag;   // records, descriptor table, touched stamps per (tile, sweep) and per (sweep, tile, 32 units)
         Arena s_hv1, s_hv2, s_key1, s_key2, s_src1, s_src2, s_cnt1, s_cnt2, s_misc;   // the sorted pipeline of big passes (gem_sort.hip)
+        Arena s_ranges, s_shard;       // multi-GPU shard: every block's range in the sorted records; strip ids [16] | strip bounds [16]
         Arena tables;                  // batched-call tables (frames, sweep_unit0, sweep_first, var_updates)
         void* host_tables = nullptr;   // their pinned staging copy: the upload is asynchronous, `tables_done` guards its reuse
         size_t host_cap = 0;
@@ -119,10 +120,19 @@ struct gem_handle {
     struct Shard {
         bool valid = false;
         const uint2* hv = nullptr; const uint32_t* key = nullptr;     // this device's sorted records
+        const uint2* ranges = nullptr;                                 // [4 T] where every block's records are in them (k_block_ranges)
         uint32_t bounds[kMaxRanks + 1] = {0};                          // first record of every strip in them
+        const uint32_t* d_bounds = nullptr;                            // ... on the device (16 words)
         int nstrips = 0, n_global_sweeps = 0;
+        int slot = -1;                                                 // pass-buffer set the sort ran in on a binning stream (its bin_done / fuse_done events), -1: on the handle's stream
     } shard;
-    Arena sh_dev, sh_recv_hv, sh_recv_key;  // ids / bounds / gathered bounds / variance increments; records received from the other ranks
+    Arena sh_dev, sh_recv_hv, sh_recv_key, sh_recv_rng, sh_ranges;  // ids / bounds / gathered bounds / variance increments; records and block ranges received from the other ranks; own block ranges
+    // RCCL traffic (record exchange, all-gather of the fused strips) runs on a stream of its own, in the same order on every rank: the
+    // all-gather of step p -- from a PUBLISHED COPY of this rank's strip -- then overlaps the sort of step p + 1 on the handle's stream
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_sorted = nullptr, ev_exchanged = nullptr, ev_walked = nullptr, ev_published = nullptr, ev_gathered = nullptr;
+    bool gather_pending = false, walk_recorded = false;
+    Arena published;                        // copy of this rank's strip of the gathered layers
     void* sh_host = nullptr;            // pinned staging of the small tables (kShardHostBytes)
 
     Arena dbg;          // optional k_fuse phase stamps
@@ -154,6 +164,7 @@ int ensure(gem_handle* h, Arena& a, size_t bytes)
     if (h->bin_stream) GEM_HIP(h, hipStreamSynchronize(h->bin_stream));
     if (h->bin_stream2) GEM_HIP(h, hipStreamSynchronize(h->bin_stream2));
     if (h->tab_stream) GEM_HIP(h, hipStreamSynchronize(h->tab_stream));
+    if (h->comm_stream) GEM_HIP(h, hipStreamSynchronize(h->comm_stream));
     if (a.p) GEM_HIP(h, hipFree(a.p));
     a.p = nullptr; a.cap = 0;
     size_t want = bytes + bytes / 4 + 4096;
@@ -265,9 +276,20 @@ int flush_deferred(gem_handle* h)
 }
 
 // standalone dense pass: queued Mapvar_update increments (+ optionally the variance floor)
+// an all-gather of the fused strips still in flight on the communication stream writes the other ranks' strips: whatever
+// observes or modifies the whole map on the handle's stream comes after it
+int wait_gather(gem_handle* h)
+{
+    if (!h->gather_pending) return GEM_OK;
+    GEM_HIP(h, hipStreamWaitEvent(h->stream, h->ev_gathered, 0));
+    h->gather_pending = false;
+    return GEM_OK;
+}
+
 int flush_pending(gem_handle* h, bool with_floor)
 {
     { const int rc = flush_deferred(h); if (rc) return rc; }
+    { const int rc = wait_gather(h); if (rc) return rc; }
     if (h->n_pending == 0 && !with_floor) return GEM_OK;
     GEM_HIP(h, launch_dense_variance(h->stream, h->layers.variance, h->cells, h->n_pending, h->pending, with_floor ? 1 : 0,
                                      h->cfg.variance_floor));
@@ -291,6 +313,7 @@ struct PassInput {
     const gem_frame_params* params = nullptr;      // [n_sweeps] (src 0)
     const long long* offsets = nullptr;            // [n_sweeps+1] (batched)
     const float* var_updates = nullptr;            // [n_sweeps]  (batched, host)
+    const int* sweep_orig0 = nullptr;              // [n_sweeps]  (batched, host, optional) index inside its sweep of each sweep's first point here
     const float4* xyzi = nullptr; const uint32_t* rgb = nullptr; const int* orig = nullptr;
     const int* f_index = nullptr; const float* f_height = nullptr; const float* f_var = nullptr;
     const int* f_R = nullptr; const int* f_G = nullptr; const int* f_B = nullptr; const float* f_I = nullptr;
@@ -402,7 +425,8 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     const int T = geo.T;
     h->T = T;
 
-    bool overlap = h->overlap && in.n >= std::min(h->overlap_min_points, h->sort_overlap_min_points) && h->stream == h->own_stream && !h->counting && !shard;
+    bool overlap = h->overlap && in.n >= std::min(h->overlap_min_points, h->sort_overlap_min_points) && h->stream == h->own_stream && !h->counting &&
+                   (!shard || shard->bounds_stay_on_device);          // (the halves' sort returns its strip boundaries to the host: nothing to overlap)
     { const int rcd = flush_deferred(h); if (rcd) return rcd; }
     // a shard bins into the WHOLE map (its records go to the strip owners); the frames carry the strip
     const int keep_row0 = h->row0, keep_row1 = h->row1;
@@ -462,7 +486,8 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
         const size_t o_chunk0 = o_frames + sizeof(FrameConst) * in.n_sweeps;
         const size_t o_first = (o_chunk0 + sizeof(int) * (in.n_sweeps + 1) + 15) & ~(size_t)15;
         const size_t o_var = o_first + sizeof(long long) * (in.n_sweeps + 1);
-        const size_t total = o_var + sizeof(float) * in.n_sweeps;
+        const size_t o_orig = o_var + sizeof(float) * in.n_sweeps;
+        const size_t total = o_orig + sizeof(int) * in.n_sweeps;
         if ((rc = ensure(h, pb.tables, total))) return rc;
         if (total > pb.host_cap) {
             if (pb.tables_recorded) GEM_HIP(h, hipEventSynchronize(pb.tables_done));
@@ -479,6 +504,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
         memcpy(host + o_chunk0, chunk0.data(), sizeof(int) * (in.n_sweeps + 1));
         memcpy(host + o_first, in.offsets, sizeof(long long) * (in.n_sweeps + 1));
         if (in.var_updates) memcpy(host + o_var, in.var_updates, sizeof(float) * in.n_sweeps);
+        if (in.sweep_orig0) memcpy(host + o_orig, in.sweep_orig0, sizeof(int) * in.n_sweeps);
         // on a stream of its own when the passes overlap: the upload (a 5 us blit + two kernel boundaries) then runs while the
         // binning stream is still sorting the pass before, instead of at the head of this pass's chain (the buffer's last
         // readers -- the pass before the previous one -- are done: fuse_done above)
@@ -491,10 +517,11 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
         sa.frames = reinterpret_cast<const FrameConst*>(d + o_frames);
         sa.sweep_chunk0 = reinterpret_cast<const int*>(d + o_chunk0);
         sa.sweep_first = reinterpret_cast<const long long*>(d + o_first);
-        sa.sweep_orig0 = nullptr;
+        sa.sweep_orig0 = in.sweep_orig0 ? reinterpret_cast<const int*>(d + o_orig) : nullptr;
         wa.var_updates = in.var_updates ? reinterpret_cast<const float*>(d + o_var) : nullptr;
     } else {
         fill_frame(h, in.src == 0 ? in.params : nullptr, sa.frame0);
+        sa.orig0_single = in.sweep_orig0 ? in.sweep_orig0[0] : 0;
     }
     sa.n_sweeps = in.n_sweeps; sa.n = in.n; sa.sweep_id0 = shard ? shard->sweep_id0 : 0;
     sa.xyzi = in.xyzi; sa.rgb = in.rgb; sa.orig = in.orig;
@@ -562,32 +589,37 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
         GEM_HIP(h, launch_sort(sbin, sa, src, with_src, ev));
     }
     if (shard) {
-        // where the strips begin in the sorted records: one 32-ary search per boundary, then the only host round trip of the path
+        // where the strips begin in the sorted records (one 32-ary search per boundary) and where every block's records are
+        // (k_block_ranges): behind the sort, on its stream
         gem_handle::Shard& sd = h->shard;
         sd.valid = false;
         if (!h->sh_host) GEM_HIP(h, hipHostMalloc(&h->sh_host, kShardHostBytes, hipHostMallocDefault));
-        if ((rc = ensure(h, h->sh_dev, 4096 + sizeof(float) * 512))) return rc;
+        if ((rc = ensure(h, pb.s_shard, 64 * sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(h, pb.s_ranges, (size_t)4 * T * sizeof(uint2)))) return rc;
         uint32_t* host = static_cast<uint32_t*>(h->sh_host);
         for (int k = 0; k <= shard->nstrips; ++k) {
             const int tile_row = shard->strip_rows[k] >= h->L ? geo.tiles_per_row : shard->strip_rows[k] / 32;
-            host[k] = (uint32_t)(tile_row * geo.tiles_per_row) << 10;                // first cell id of the strip
+            host[k] = (uint32_t)(tile_row * geo.tiles_per_row) << 10;                // first cell id of the strip (the same every call)
         }
-        uint32_t* d_ids = static_cast<uint32_t*>(h->sh_dev.p), *d_bounds = d_ids + 16;
-        GEM_HIP(h, hipMemcpyAsync(d_ids, host, sizeof(uint32_t) * (shard->nstrips + 1), hipMemcpyHostToDevice, h->stream));
-        GEM_HIP(h, launch_strip_bounds(h->stream, final_b ? sa.key_b : sa.key_a, sa.total, geo.id_bits, d_ids, d_bounds, shard->nstrips + 1));
-        sd.hv = final_b ? sa.hv_b : sa.hv_a; sd.key = final_b ? sa.key_b : sa.key_a;
-        sd.nstrips = shard->nstrips;
-        if (shard->bounds_stay_on_device) {                  // gem_add_sharded_device all-gathers them from where they are: one host round trip per step, not two
+        uint32_t* d_ids = static_cast<uint32_t*>(pb.s_shard.p), *d_bounds = d_ids + 16;
+        const uint32_t* keys = final_b ? sa.key_b : sa.key_a;
+        GEM_HIP(h, hipMemcpyAsync(d_ids, host, sizeof(uint32_t) * (shard->nstrips + 1), hipMemcpyHostToDevice, sbin));
+        GEM_HIP(h, launch_strip_bounds(sbin, keys, sa.total, geo.id_bits, d_ids, d_bounds, shard->nstrips + 1));
+        GEM_HIP(h, hipMemsetAsync(pb.s_ranges.p, 0, (size_t)4 * T * sizeof(uint2), sbin));
+        GEM_HIP(h, launch_block_ranges(sbin, keys, sa.total, in.n, geo.id_bits, static_cast<uint2*>(pb.s_ranges.p)));
+        sd.hv = final_b ? sa.hv_b : sa.hv_a; sd.key = keys; sd.ranges = static_cast<const uint2*>(pb.s_ranges.p);
+        sd.d_bounds = d_bounds; sd.nstrips = shard->nstrips; sd.slot = overlap ? (int)slot : -1;
+        h->stats.points_in = in.n;
+        if (shard->bounds_stay_on_device) {                  // gem_add_sharded_device all-gathers them from where they are
             for (int k = 0; k <= shard->nstrips; ++k) sd.bounds[k] = 0;
+            if (overlap) GEM_HIP(h, hipEventRecord(pb.bin_done, sbin));
             sd.valid = true;
-            h->stats.points_in = in.n;
             return GEM_OK;
         }
-        GEM_HIP(h, hipMemcpyAsync(host + 32, d_bounds, sizeof(uint32_t) * (shard->nstrips + 1), hipMemcpyDeviceToHost, h->stream));
-        GEM_HIP(h, hipStreamSynchronize(h->stream));
+        GEM_HIP(h, hipMemcpyAsync(host + 32, d_bounds, sizeof(uint32_t) * (shard->nstrips + 1), hipMemcpyDeviceToHost, sbin));
+        GEM_HIP(h, hipStreamSynchronize(sbin));
         for (int k = 0; k <= shard->nstrips; ++k) sd.bounds[k] = host[32 + k];
         sd.valid = true;
-        h->stats.points_in = in.n;
         return GEM_OK;
     }
     if (overlap) {
@@ -932,16 +964,19 @@ void gem_destroy(gem_handle* h)
     if (h->bin_stream) hipStreamSynchronize(h->bin_stream);
     if (h->bin_stream2) hipStreamSynchronize(h->bin_stream2);
     if (h->tab_stream) hipStreamSynchronize(h->tab_stream);
+    if (h->comm_stream) hipStreamSynchronize(h->comm_stream);
     if (h->comm) ncclCommDestroy(h->comm);
+    if (h->comm_stream) hipStreamDestroy(h->comm_stream);
+    for (hipEvent_t e : {h->ev_sorted, h->ev_exchanged, h->ev_walked, h->ev_published, h->ev_gathered}) if (e) hipEventDestroy(e);
     fold_events(h);
     for (auto& ep : h->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
     if (h->layers.elevation) hipFree(h->layers.elevation);      // base of the single layer allocation
     if (h->d_counters) hipFree(h->d_counters);
-    for (Arena* a : {&h->stage, &h->scratch, &h->dbg, &h->color, &h->sh_dev, &h->sh_recv_hv, &h->sh_recv_key}) if (a->p) hipFree(a->p);
+    for (Arena* a : {&h->stage, &h->scratch, &h->dbg, &h->color, &h->sh_dev, &h->sh_recv_hv, &h->sh_recv_key, &h->sh_recv_rng, &h->sh_ranges, &h->published}) if (a->p) hipFree(a->p);
     if (h->sh_host) hipHostFree(h->sh_host);
     for (auto& b : h->pb) {
         for (Arena* a : {&b.rec, &b.srt, &b.seg, &b.flag, &b.gflag, &b.tables, &b.s_hv1, &b.s_hv2, &b.s_key1, &b.s_key2, &b.s_src1, &b.s_src2,
-                         &b.s_cnt1, &b.s_cnt2, &b.s_misc}) if (a->p) hipFree(a->p);
+                         &b.s_cnt1, &b.s_cnt2, &b.s_misc, &b.s_ranges, &b.s_shard}) if (a->p) hipFree(a->p);
         if (b.host_tables) hipHostFree(b.host_tables);
         if (b.tables_done) hipEventDestroy(b.tables_done);
         if (b.bin_done) hipEventDestroy(b.bin_done);
@@ -988,6 +1023,7 @@ int gem_synchronize(gem_handle* h)
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
     { const int rcd = flush_deferred(h); if (rcd) return rcd; }
+    { const int rcd = wait_gather(h); if (rcd) return rcd; }
     GEM_HIP(h, hipStreamSynchronize(h->stream));
     return GEM_OK;
 }
@@ -1009,6 +1045,7 @@ int gem_move(gem_handle* h, const float position[3], float out_center[2], int ou
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
     { const int rcd = flush_deferred(h); if (rcd) return rcd; }
+    { const int rcd = wait_gather(h); if (rcd) return rcd; }       // the clears below touch every rank's strip
     const int L = h->L; const float res = h->res;
     h->sensor_z = position[2];
     int shift[2]; float aligned[2];
@@ -1620,6 +1657,11 @@ static int comm_init_common(gem_handle* h, const void* unique_id_128_bytes, int 
     ncclResult_t r = ncclCommInitRank(&h->comm, nranks, id, rank);
     if (r != ncclSuccess) { h->comm = nullptr; return fail(h, GEM_ERR_COMM, ncclGetErrorString(r)); }
     h->nranks = nranks; h->rank = rank; h->tile_strips = tile_strips;
+    if (!h->comm_stream) {
+        GEM_HIP(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+        for (hipEvent_t* e : {&h->ev_sorted, &h->ev_exchanged, &h->ev_walked, &h->ev_published, &h->ev_gathered})
+            GEM_HIP(h, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
     // row strips in STORAGE coordinates: Move never migrates data between devices
     const int tile_rows = (h->L + 31) / 32;
     for (int k = 0; k <= nranks; ++k)
@@ -1647,33 +1689,46 @@ int gem_get_strip(gem_handle* h, int* out_row0, int* out_row1)
     return GEM_OK;
 }
 
+// Every rank's strip to every other rank, DIRECT: one ncclSend / ncclRecv pair per peer and layer in one group (xGMI is
+// point-to-point: each peer has its own link; a ring would pass every strip through seven hops), strips of any sizes.  The sends
+// read a PUBLISHED COPY of the strip, taken on the handle's stream behind everything enqueued so far; the transfers run on the
+// communication stream and write the other ranks' strips only -- so the next pass's projection / sort / fusion of this rank's own
+// strip goes on beside them.  Whatever observes the whole map (gem_get_layer, gem_synchronize, gem_move, ...) waits for them.
 int gem_allgather_layers(gem_handle* h, int with_attributes)
 {
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
     if (!h->comm) return fail(h, GEM_ERR_COMM, "gem_allgather_layers: gem_comm_init not called");
-    int rc = flush_pending(h, false);
+    int rc = flush_pending(h, false);               // (also: behind the previous gather)
     if (rc) return rc;
+    const int W = h->nranks;
+    if (W == 1) return GEM_OK;
     const int nl = with_attributes ? 6 : 2;
     void* ptrs[6] = {h->layers.elevation, h->layers.variance, h->layers.intensity, h->layers.colorR, h->layers.colorG, h->layers.colorB};
-    bool even = true;
-    for (int k = 0; k < h->nranks; ++k) even = even && h->strip_row[k + 1] - h->strip_row[k] == h->strip_row[1] - h->strip_row[0];
+    const size_t own = (size_t)(h->strip_row[h->rank + 1] - h->strip_row[h->rank]) * h->L;       // 4-byte elements of this rank's strip
+    if ((rc = ensure(h, h->published, own * 4 * 6 + 256))) return rc;
+    unsigned char* pub = static_cast<unsigned char*>(h->published.p);
+    if (own)
+        for (int l = 0; l < nl; ++l)
+            GEM_HIP(h, hipMemcpyAsync(pub + (size_t)l * own * 4, static_cast<unsigned char*>(ptrs[l]) + (size_t)h->strip_row[h->rank] * h->L * 4, own * 4,
+                                      hipMemcpyDeviceToDevice, h->stream));
+    GEM_HIP(h, hipEventRecord(h->ev_published, h->stream));
+    GEM_HIP(h, hipStreamWaitEvent(h->comm_stream, h->ev_published, 0));
     ncclResult_t r = ncclGroupStart();
-    for (int l = 0; l < nl && r == ncclSuccess; ++l) {
-        unsigned char* base = static_cast<unsigned char*>(ptrs[l]);
-        if (even) {
-            const size_t count = (size_t)(h->strip_row[1] - h->strip_row[0]) * h->L;      // 4-byte elements per rank
-            r = ncclAllGather(base + (size_t)h->rank * count * 4, base, count, ncclFloat, h->comm, h->stream);   // in place
-        } else {
-            for (int k = 0; k < h->nranks && r == ncclSuccess; ++k) {
-                const size_t r0 = (size_t)h->strip_row[k], r1 = (size_t)h->strip_row[k + 1];
-                if (r1 > r0) r = ncclBroadcast(base + r0 * h->L * 4, base + r0 * h->L * 4, (r1 - r0) * h->L, ncclFloat, k, h->comm, h->stream);
-            }
+    for (int p = 0; p < W && r == ncclSuccess; ++p) {
+        if (p == h->rank) continue;
+        const size_t theirs = (size_t)(h->strip_row[p + 1] - h->strip_row[p]) * h->L;
+        for (int l = 0; l < nl && r == ncclSuccess; ++l) {
+            if (own) r = ncclSend(pub + (size_t)l * own * 4, own, ncclFloat, p, h->comm, h->comm_stream);
+            if (r == ncclSuccess && theirs)
+                r = ncclRecv(static_cast<unsigned char*>(ptrs[l]) + (size_t)h->strip_row[p] * h->L * 4, theirs, ncclFloat, p, h->comm, h->comm_stream);
         }
     }
     ncclResult_t r2 = ncclGroupEnd();
     if (r != ncclSuccess || r2 != ncclSuccess) return fail(h, GEM_ERR_COMM, ncclGetErrorString(r != ncclSuccess ? r : r2));
+    GEM_HIP(h, hipEventRecord(h->ev_gathered, h->comm_stream));
+    h->gather_pending = true;
     return GEM_OK;
 }
 
@@ -1691,9 +1746,10 @@ static int shard_checks(gem_handle* h, int n_global_sweeps, SortGeometry* geo)
 }
 
 static int shard_sort_locked(gem_handle* h, int n_local_sweeps, const gem_frame_params* params, const void* d_xyzi, const long long* offsets,
-                             int first_global_sweep, int n_global_sweeps, int nstrips, const int* strip_rows,
-                             uint32_t* out_bounds, const void** out_d_hv, const void** out_d_key, bool bounds_stay_on_device)
+                             int first_global_sweep, int n_global_sweeps, int first_point_in_sweep, int nstrips, const int* strip_rows,
+                             uint32_t* out_bounds, const void** out_d_hv, const void** out_d_key, const void** out_d_ranges, bool bounds_stay_on_device)
 {
+    if (first_point_in_sweep < 0) return fail(h, GEM_ERR_INVALID, "gem_shard_sort_device: negative first_point_in_sweep");
     if (n_local_sweeps < 0 || nstrips <= 0 || nstrips > kMaxRanks || !strip_rows || first_global_sweep < 0 ||
         first_global_sweep + n_local_sweeps > n_global_sweeps || (n_local_sweeps > 0 && (!params || !offsets || !d_xyzi)))
         return fail(h, GEM_ERR_INVALID, "gem_shard_sort_device: bad argument");
@@ -1709,13 +1765,15 @@ static int shard_sort_locked(gem_handle* h, int n_local_sweeps, const gem_frame_
     gem_handle::Shard& sd = h->shard;
     const long long n = n_local_sweeps > 0 ? offsets[n_local_sweeps] - offsets[0] : 0;
     if (n >= (1ll << 31)) return fail(h, GEM_ERR_INVALID, "gem_shard_sort_device: shard too large");
-    if (n == 0) {                                        // an empty shard contributes nothing to any strip
-        sd.valid = true; sd.hv = nullptr; sd.key = nullptr; sd.nstrips = nstrips;
+    if (n == 0) {                                        // an empty shard contributes nothing to any strip: no records, empty ranges, zero bounds
+        const size_t n_blocks = (size_t)4 * geo.T;
+        if ((rc = ensure(h, h->sh_ranges, n_blocks * sizeof(uint2)))) return rc;
+        if ((rc = ensure(h, h->sh_dev, 4096 + sizeof(float) * 512))) return rc;
+        GEM_HIP(h, hipMemsetAsync(h->sh_ranges.p, 0, n_blocks * sizeof(uint2), h->stream));
+        GEM_HIP(h, hipMemsetAsync(static_cast<uint32_t*>(h->sh_dev.p) + 16, 0, 16 * sizeof(uint32_t), h->stream));
+        sd.valid = true; sd.hv = nullptr; sd.key = nullptr; sd.nstrips = nstrips; sd.slot = -1;
+        sd.ranges = static_cast<const uint2*>(h->sh_ranges.p); sd.d_bounds = static_cast<const uint32_t*>(h->sh_dev.p) + 16;
         for (int k = 0; k <= nstrips; ++k) sd.bounds[k] = 0;
-        if (bounds_stay_on_device) {
-            if ((rc = ensure(h, h->sh_dev, 4096 + sizeof(float) * 512))) return rc;
-            GEM_HIP(h, hipMemsetAsync(static_cast<uint32_t*>(h->sh_dev.p) + 16, 0, 16 * sizeof(uint32_t), h->stream));
-        }
     } else {
         for (int s = 0; s < n_local_sweeps; ++s) if (offsets[s + 1] < offsets[s]) return fail(h, GEM_ERR_INVALID, "gem_shard_sort_device: offsets not monotone");
         PassInput in; in.src = 0; in.n_sweeps = n_local_sweeps; in.n = n; in.params = params; in.device_input = true;
@@ -1723,6 +1781,11 @@ static int shard_sort_locked(gem_handle* h, int n_local_sweeps, const gem_frame_
         for (int s = 0; s <= n_local_sweeps; ++s) off0[s] = offsets[s] - offsets[0];
         in.offsets = off0.data(); in.var_updates = nullptr;
         in.xyzi = static_cast<const float4*>(d_xyzi) + offsets[0];
+        // a sweep split between two ranks: the camera models take the pixel row / column from the point's index INSIDE ITS SWEEP
+        // (gem_device.hpp, sensor_variances), so the shard that holds a sweep's tail says where that tail begins
+        std::vector<int> orig0(n_local_sweeps, 0);
+        orig0[0] = first_point_in_sweep;
+        in.sweep_orig0 = orig0.data();
         ShardOpts so{first_global_sweep, nstrips, strip_rows, bounds_stay_on_device};
         if ((rc = run_sort_pipeline(h, in, 0, geo, &so))) return rc;
     }
@@ -1730,34 +1793,45 @@ static int shard_sort_locked(gem_handle* h, int n_local_sweeps, const gem_frame_
     if (out_bounds) for (int k = 0; k <= nstrips; ++k) out_bounds[k] = sd.bounds[k];
     if (out_d_hv) *out_d_hv = sd.hv;
     if (out_d_key) *out_d_key = sd.key;
+    if (out_d_ranges) *out_d_ranges = sd.ranges;
     return GEM_OK;
 }
 
 int gem_shard_sort_device(gem_handle* h, int n_local_sweeps, const gem_frame_params* params, const void* d_xyzi, const long long* offsets,
-                          int first_global_sweep, int n_global_sweeps, int nstrips, const int* strip_rows,
-                          uint32_t* out_bounds, const void** out_d_hv, const void** out_d_key)
+                          int first_global_sweep, int n_global_sweeps, int first_point_in_sweep, int nstrips, const int* strip_rows,
+                          uint32_t* out_bounds, const void** out_d_hv, const void** out_d_key, const void** out_d_ranges)
 {
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
-    return shard_sort_locked(h, n_local_sweeps, params, d_xyzi, offsets, first_global_sweep, n_global_sweeps, nstrips, strip_rows,
-                             out_bounds, out_d_hv, out_d_key, false);
+    return shard_sort_locked(h, n_local_sweeps, params, d_xyzi, offsets, first_global_sweep, n_global_sweeps, first_point_in_sweep, nstrips, strip_rows,
+                             out_bounds, out_d_hv, out_d_key, out_d_ranges, false);
 }
 
+// d_ranges / bases (both or neither): per source the block ranges of ITS sorted records, entry 0 = the first block of this handle's
+// strip, and the position d_hv[s] / d_key[s] point at in the source's own arrays; without them the walk searches every source.
+// own: this device's own sorted records are the ONLY source (one rank), taken in place through their block ranges.
+// slot: the pass-buffer set whose sort the walk reads (its fuse_done event lets the sort after next reuse the buffers), -1: none.
 static int shard_fuse_locked(gem_handle* h, int n_src, const void* const* d_hv, const void* const* d_key, const uint32_t* counts,
-                             int n_global_sweeps, const float* var_updates_global)
+                             const void* const* d_ranges, const uint32_t* bases, int n_global_sweeps, const float* var_updates_global,
+                             const gem_handle::Shard* own = nullptr, int slot = -1)
 {
     SortGeometry geo;
     int rc = shard_checks(h, n_global_sweeps, &geo);
     if (rc) return rc;
     { const int rcd = flush_deferred(h); if (rcd) return rcd; }
     WalkArgs wa{};
-    wa.n_src = std::max(n_src, 2);                       // always the multi-source form (a single source is followed by an empty one)
-    for (int s = 0; s < kMaxRanks; ++s) {
-        const bool on = s < n_src && counts[s] > 0;
+    wa.n_src = own ? 1 : std::max(n_src, 2);             // the multi-source form (a single source is followed by an empty one) unless the records are this device's own
+    if (own) { wa.hv = own->hv; wa.key = own->key; wa.ranges = own->ranges; }
+    for (int s = 0; s < kMaxRanks && !own; ++s) {
+        const bool ranged = s < n_src && d_ranges && bases && d_ranges[s] && d_hv[s] && d_key[s];
+        const bool on = ranged || (s < n_src && counts && counts[s] > 0);
         wa.src_hv[s] = on ? static_cast<const uint2*>(d_hv[s]) : nullptr;
         wa.src_key[s] = on ? static_cast<const uint32_t*>(d_key[s]) : nullptr;
-        wa.src_n[s] = on ? counts[s] : 0u;
+        wa.src_n[s] = on && counts ? counts[s] : 0u;
+        wa.src_ranges[s] = ranged ? static_cast<const uint2*>(d_ranges[s]) : nullptr;
+        wa.src_base[s] = ranged ? bases[s] : 0u;
     }
+    wa.blk0 = (uint32_t)((h->row0 / 32) * geo.tiles_per_row) << 2;    // first block of this handle's strip (whole tile rows)
     wa.T = geo.T; wa.tiles_per_row = geo.tiles_per_row; wa.L = h->L; wa.row0 = h->row0; wa.row1 = h->row1;
     wa.id_bits = geo.id_bits; wa.bin_shift = geo.dshift[geo.n_passes - 1]; wa.n_sweeps = n_global_sweeps;
     wa.mahal = h->cfg.mahalanobis_threshold; wa.var_floor = h->cfg.variance_floor;
@@ -1784,73 +1858,119 @@ static int shard_fuse_locked(gem_handle* h, int n_src, const void* const* d_hv, 
     }
     if (h->counting) GEM_HIP(h, hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
     { Timed t(h, 9); GEM_HIP(h, launch_block_walk(h->stream, wa, 0, t.events())); }
+    if (h->ev_walked) { GEM_HIP(h, hipEventRecord(h->ev_walked, h->stream)); h->walk_recorded = true; }    // (the receive buffers have been read)
+    if (slot >= 0) { GEM_HIP(h, hipEventRecord(h->pb[slot].fuse_done, h->stream)); h->pb[slot].fuse_recorded = true; }
+    else h->main_reads_pb = true;
     h->n_pending = 0;
     h->floor_dirty = false;
-    h->main_reads_pb = true;
     return GEM_OK;
 }
 
 int gem_shard_fuse_device(gem_handle* h, int n_src, const void* const* d_hv, const void* const* d_key, const uint32_t* counts,
-                          int n_global_sweeps, const float* var_updates_global)
+                          const void* const* d_ranges, const uint32_t* bases, int n_global_sweeps, const float* var_updates_global)
 {
-    if (!h || n_src <= 0 || n_src > kMaxRanks || !d_hv || !d_key || !counts || n_global_sweeps <= 0)
+    if (!h || n_src <= 0 || n_src > kMaxRanks || !d_hv || !d_key || !counts || n_global_sweeps <= 0 || ((d_ranges == nullptr) != (bases == nullptr)))
         return h ? fail(h, GEM_ERR_INVALID, "gem_shard_fuse_device: bad argument") : GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
-    return shard_fuse_locked(h, n_src, d_hv, d_key, counts, n_global_sweeps, var_updates_global);
+    if (h->tile_strips == false && (h->row0 % 32 != 0)) return fail(h, GEM_ERR_INVALID, "gem_shard_fuse_device: the handle's strip must start at a tile row");
+    return shard_fuse_locked(h, n_src, d_hv, d_key, counts, d_ranges, bases, n_global_sweeps, var_updates_global);
 }
 
 int gem_add_sharded_device(gem_handle* h, int n_local_sweeps, const gem_frame_params* params, const void* d_xyzi, const long long* offsets,
-                           int first_global_sweep, int n_global_sweeps, const float* var_updates_global)
+                           int first_global_sweep, int n_global_sweeps, int first_point_in_sweep, const float* var_updates_global)
 {
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     if (!h->comm || !h->tile_strips) return fail(h, GEM_ERR_COMM, "gem_add_sharded_device: gem_comm_init_tiles not called");
     const int W = h->nranks;
+    // Everything that can fail on this rank alone -- arguments, geometry, allocations -- fails HERE, before the first collective:
+    // a rank that returned early would leave the others waiting in ncclRecv.  (An error after this point means the communicator
+    // has to be aborted.)
+    {
+        SortGeometry geo;
+        int rc0 = shard_checks(h, n_global_sweeps, &geo);
+        if (rc0) return rc0;
+        if (n_local_sweeps < 0 || first_global_sweep < 0 || first_global_sweep + n_local_sweeps > n_global_sweeps || first_point_in_sweep < 0 ||
+            (n_local_sweeps > 0 && (!params || !offsets || !d_xyzi)))
+            return fail(h, GEM_ERR_INVALID, "gem_add_sharded_device: bad argument");
+        hipSetDevice(h->device);
+        if (!h->sh_host) GEM_HIP(h, hipHostMalloc(&h->sh_host, kShardHostBytes, hipHostMallocDefault));
+        if ((rc0 = ensure(h, h->sh_dev, 4096 + sizeof(float) * 512))) return rc0;
+    }
     // the sort leaves this rank's strip boundaries on the device (k_strip_bounds' output, 16 words reserved) ...
-    int rc = shard_sort_locked(h, n_local_sweeps, params, d_xyzi, offsets, first_global_sweep, n_global_sweeps, W, h->strip_row,
-                               nullptr, nullptr, nullptr, true);
+    int rc = shard_sort_locked(h, n_local_sweeps, params, d_xyzi, offsets, first_global_sweep, n_global_sweeps, first_point_in_sweep, W, h->strip_row,
+                               nullptr, nullptr, nullptr, nullptr, true);
     if (rc) return rc;
     hipSetDevice(h->device);
     gem_handle::Shard& sd = h->shard;
+    const uint32_t my_blk0 = (uint32_t)((h->row0 / 32) * ((h->L + 31) / 32)) << 2;
+    hipStream_t sorted_on = sd.slot >= 0 ? nullptr : h->stream;
+    if (W == 1) {
+        // one rank: its own sorted records, in place, through their block ranges -- no exchange, nothing returns to the host
+        const uint32_t cnt[1] = {0u};
+        const void* none[1] = {nullptr};
+        if (sd.slot >= 0) GEM_HIP(h, hipStreamWaitEvent(h->stream, h->pb[sd.slot].bin_done, 0));
+        if (!sd.hv) return shard_fuse_locked(h, 1, none, none, cnt, nullptr, nullptr, n_global_sweeps, var_updates_global);
+        return shard_fuse_locked(h, 1, none, none, cnt, nullptr, nullptr, n_global_sweeps, var_updates_global, &sd, sd.slot);
+    }
     // ... and every rank learns what it receives from whom -- and what it sends -- from ONE all-gather of them (W + 1 words per
-    // rank) and one host round trip
+    // rank) and one host round trip, on the communication stream: behind the previous step's all-gather of the layers, which
+    // meanwhile overlapped this step's sort
     uint32_t* host = static_cast<uint32_t*>(h->sh_host);
-    if (!host) { GEM_HIP(h, hipHostMalloc(&h->sh_host, kShardHostBytes, hipHostMallocDefault)); host = static_cast<uint32_t*>(h->sh_host); }
-    if ((rc = ensure(h, h->sh_dev, 4096 + sizeof(float) * 512))) return rc;
-    uint32_t* d_mine = static_cast<uint32_t*>(h->sh_dev.p) + 16, *d_all = static_cast<uint32_t*>(h->sh_dev.p) + 64;   // [W][16]
-    ncclResult_t r = ncclAllGather(d_mine, d_all, 16, ncclUint32, h->comm, h->stream);
+    const uint32_t* d_mine = sd.d_bounds; uint32_t* d_all = static_cast<uint32_t*>(h->sh_dev.p) + 64;   // [W][16]
+    if (sorted_on) { GEM_HIP(h, hipEventRecord(h->ev_sorted, sorted_on)); GEM_HIP(h, hipStreamWaitEvent(h->comm_stream, h->ev_sorted, 0)); }
+    else GEM_HIP(h, hipStreamWaitEvent(h->comm_stream, h->pb[sd.slot].bin_done, 0));
+    if (h->walk_recorded) GEM_HIP(h, hipStreamWaitEvent(h->comm_stream, h->ev_walked, 0));          // the previous walk has read the receive buffers
+    ncclResult_t r = ncclAllGather(d_mine, d_all, 16, ncclUint32, h->comm, h->comm_stream);
     if (r != ncclSuccess) return fail(h, GEM_ERR_COMM, ncclGetErrorString(r));
-    GEM_HIP(h, hipMemcpyAsync(host + 64, d_all, (size_t)W * 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-    GEM_HIP(h, hipStreamSynchronize(h->stream));
+    GEM_HIP(h, hipMemcpyAsync(host + 64, d_all, (size_t)W * 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->comm_stream));
+    GEM_HIP(h, hipStreamSynchronize(h->comm_stream));
     for (int k = 0; k <= W; ++k) sd.bounds[k] = host[64 + h->rank * 16 + k];
-    uint32_t cnt[kMaxRanks], off[kMaxRanks + 1];
+    const int tpr = (h->L + 31) / 32;
+    auto strip_blocks = [&](int p) { return (size_t)4 * tpr * ((std::min(h->strip_row[p + 1], tpr * 32) + 31) / 32 - h->strip_row[p] / 32); };
+    const size_t my_blocks = strip_blocks(h->rank);
+    uint32_t cnt[kMaxRanks], off[kMaxRanks + 1], base[kMaxRanks];
     off[0] = 0;
     for (int s = 0; s < W; ++s) {
-        cnt[s] = host[64 + s * 16 + h->rank + 1] - host[64 + s * 16 + h->rank];
-        off[s + 1] = off[s] + ((cnt[s] + 3u) & ~3u);        // every source segment starts at a multiple of four records
+        base[s] = host[64 + s * 16 + h->rank];
+        cnt[s] = host[64 + s * 16 + h->rank + 1] - base[s];
+        off[s + 1] = off[s] + (s == h->rank ? 0u : ((cnt[s] + 3u) & ~3u));      // (this rank's own records stay where they are)
     }
     if ((rc = ensure(h, h->sh_recv_hv, (size_t)off[W] * 8 + 64))) return rc;
     if ((rc = ensure(h, h->sh_recv_key, (size_t)off[W] * 4 + 64))) return rc;
+    if ((rc = ensure(h, h->sh_recv_rng, (size_t)W * my_blocks * sizeof(uint2) + 64))) return rc;
     uint2* rhv = static_cast<uint2*>(h->sh_recv_hv.p); uint32_t* rkey = static_cast<uint32_t*>(h->sh_recv_key.p);
-    // the exchange: every strip's records to its owner, received in source-rank order
+    uint2* rrng = static_cast<uint2*>(h->sh_recv_rng.p);
+    // the exchange: every strip's records and their block ranges to the strip's owner
     r = ncclGroupStart();
     for (int p = 0; p < W && r == ncclSuccess; ++p) {
+        if (p == h->rank) continue;
         const uint32_t sc = sd.bounds[p + 1] - sd.bounds[p];
         if (sc > 0) {
-            r = ncclSend(sd.hv + sd.bounds[p], (size_t)sc * 2, ncclUint32, p, h->comm, h->stream);
-            if (r == ncclSuccess) r = ncclSend(sd.key + sd.bounds[p], sc, ncclUint32, p, h->comm, h->stream);
+            const uint32_t p_blk0 = (uint32_t)((h->strip_row[p] / 32) * tpr) << 2;
+            r = ncclSend(sd.hv + sd.bounds[p], (size_t)sc * 2, ncclUint32, p, h->comm, h->comm_stream);
+            if (r == ncclSuccess) r = ncclSend(sd.key + sd.bounds[p], sc, ncclUint32, p, h->comm, h->comm_stream);
+            if (r == ncclSuccess) r = ncclSend(sd.ranges + p_blk0, strip_blocks(p) * 2, ncclUint32, p, h->comm, h->comm_stream);
         }
         if (r == ncclSuccess && cnt[p] > 0) {
-            r = ncclRecv(rhv + off[p], (size_t)cnt[p] * 2, ncclUint32, p, h->comm, h->stream);
-            if (r == ncclSuccess) r = ncclRecv(rkey + off[p], cnt[p], ncclUint32, p, h->comm, h->stream);
+            r = ncclRecv(rhv + off[p], (size_t)cnt[p] * 2, ncclUint32, p, h->comm, h->comm_stream);
+            if (r == ncclSuccess) r = ncclRecv(rkey + off[p], cnt[p], ncclUint32, p, h->comm, h->comm_stream);
+            if (r == ncclSuccess) r = ncclRecv(rrng + (size_t)p * my_blocks, my_blocks * 2, ncclUint32, p, h->comm, h->comm_stream);
         }
     }
     ncclResult_t r2 = ncclGroupEnd();
     if (r != ncclSuccess || r2 != ncclSuccess) return fail(h, GEM_ERR_COMM, ncclGetErrorString(r != ncclSuccess ? r : r2));
-    const void* phv[kMaxRanks]; const void* pkey[kMaxRanks];
-    for (int s = 0; s < W; ++s) { phv[s] = rhv + off[s]; pkey[s] = rkey + off[s]; }
-    return shard_fuse_locked(h, W, phv, pkey, cnt, n_global_sweeps, var_updates_global);
+    GEM_HIP(h, hipEventRecord(h->ev_exchanged, h->comm_stream));
+    GEM_HIP(h, hipStreamWaitEvent(h->stream, h->ev_exchanged, 0));
+    const void* phv[kMaxRanks]; const void* pkey[kMaxRanks]; const void* prng[kMaxRanks];
+    for (int s = 0; s < W; ++s) {
+        const bool mine = s == h->rank;
+        phv[s] = cnt[s] ? (mine ? (const void*)(sd.hv + base[s]) : (const void*)(rhv + off[s])) : nullptr;
+        pkey[s] = cnt[s] ? (mine ? (const void*)(sd.key + base[s]) : (const void*)(rkey + off[s])) : nullptr;
+        prng[s] = cnt[s] ? (mine ? (const void*)(sd.ranges + my_blk0) : (const void*)(rrng + (size_t)s * my_blocks)) : nullptr;
+    }
+    return shard_fuse_locked(h, W, phv, pkey, cnt, prng, base, n_global_sweeps, var_updates_global, nullptr, sd.slot);
 }
 
 } // extern "C"

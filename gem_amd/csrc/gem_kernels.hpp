@@ -105,6 +105,7 @@ struct SortArgs {
     const int*        sweep_chunk0;    // [n_sweeps+1]  first pass-1 chunk of each sweep (chunks never span sweeps); NULL = one sweep
     const long long*  sweep_first;     // [n_sweeps+1]  first point of each sweep in the concatenated cloud
     const int*        sweep_orig0;     // [n_sweeps]    original index of the sweep's first point, or NULL
+    int               orig0_single;    // the same for a single-sweep call (no tables)
     int               n_sweeps;
     int               sweep_id0;       // id of the first sweep in the record keys (0; the first GLOBAL sweep of a multi-GPU shard)
     long long         n;               // total points
@@ -160,11 +161,15 @@ struct WalkArgs {
     int   count_per_pass;
     // k_fuse_block only:
     unsigned long long* dbg;           // optional: [blocks][16] cycle stamps of thread 0 (profiling aid, gem_debug_fuse_stamps)
+    const uint2* ranges;               // single source, optional: [4 T] every block's records {first, end} (k_block_ranges) instead of bin_base + search
     int   lane_sort;                   // 1: the block's cells are handed to the threads in descending order of their record count in the first batch
     int   exact_bins;                  // 1: the last pass's bins ARE the blocks (one-pass sort): bin_base gives a block's records without a search
     // multi-GPU strip owner (gem_add_sharded_device): the block-sorted records received from every rank, taken in rank order
     int   n_src;                       // <= 1: the single source above (hv / key / src, searched through bin_base)
     const uint2* src_hv[kMaxRanks]; const uint32_t* src_key[kMaxRanks]; uint32_t src_n[kMaxRanks];
+    // optional per source: its block ranges (k_block_ranges), entry 0 = block blk0 (the strip's first); positions count from src_base
+    // in the source's own arrays, src_hv / src_key point at position src_base.  NULL: the block's records are found by search.
+    const uint2* src_ranges[kMaxRanks]; uint32_t src_base[kMaxRanks]; uint32_t blk0;
 };
 
 struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };   // optional dispatch time-stamps
@@ -174,6 +179,7 @@ hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, co
 hipError_t launch_walk(hipStream_t st, const WalkArgs& a, int flags, LaunchEvents ev);                    // cell-sorted records
 hipError_t launch_block_walk(hipStream_t st, const WalkArgs& a, int flags, LaunchEvents ev);              // block-sorted records
 constexpr int kOnePassMaxBins = 2048;  // block-sorted: maps of up to this many blocks are sorted by ONE counting-sort pass
+hipError_t launch_block_ranges(hipStream_t st, const uint32_t* keys, const uint32_t* n_records, long long max_records, int id_bits, uint2* ranges);
 hipError_t launch_strip_bounds(hipStream_t st, const uint32_t* keys, const uint32_t* n_records, int id_bits, const uint32_t* ids, uint32_t* out, int n);
 constexpr int kSortChunkRecords = 4096, kSortSegsPerChunk = 4;   // records per counting-sort chunk; 1024-point wave segments per pass-1 chunk (seg_cnt words)
 constexpr int kSortMaxBins = 8000;     // bins per pass the sorted pipeline handles (LDS of k_sort_scatter)

@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256, (SRC == 4 ? 4 : (SRC == 2 ? 3 : 1))) void k_so
     const int tid = (int)threadIdx.x, chunk = (int)blockIdx.x;
     for (int i = tid; i < a.dbins[0]; i += NT) hist[i] = 0u;
     if (chunk == 0 && tid == 0) *a.total = 0u;                         // k_sort_scan of this pass adds the column totals up
-    const ChunkRange cr = chunk_range<CH>(a.sweep_chunk0, a.sweep_first, a.sweep_orig0, a.n_sweeps, a.n, chunk);
+    ChunkRange cr = chunk_range<CH>(a.sweep_chunk0, a.sweep_first, a.sweep_orig0, a.n_sweeps, a.n, chunk);
+    if (!a.sweep_chunk0) cr.orig0 = a.orig0_single;                    // (a single sweep whose head another device holds)
     // BY VALUE: the stores below may alias the frame table as far as the compiler knows, and a reference would make it reload
     // every constant after every store (measured: 105 us instead of 25 for the 32 sweeps of C4)
     const FrameConst fc = a.sweep_chunk0 ? a.frames[cr.sweep] : a.frame0;
@@ -900,16 +901,19 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
     };
     uint32_t first0 = 0;                                               // single source: the block's first record (block-uniform)
     if (a.n_src <= 1) {
-        const uint32_t bin = id0 >> a.bin_shift;
-        uint32_t end = a.bin_base[bin + 1];
-        first0 = a.bin_base[bin];
+        uint32_t end;
+        if (a.ranges) { const uint2 r = a.ranges[id0 >> 8]; first0 = r.x; end = r.y; }
+        else { const uint32_t bin = id0 >> a.bin_shift; first0 = a.bin_base[bin]; end = a.bin_base[bin + 1]; }
         if (first0 == end && !a.dense) return;
-        if (!a.exact_bins && first0 != end) search(a.key, first0, end, first0, end);
+        if (!a.ranges && !a.exact_bins && first0 != end) search(a.key, first0, end, first0, end);
         if (tid == 0) { seg_off[0] = 0u; seg_off[1] = end - first0; }
     } else {
         for (int s = w; s < n_src; s += NW) {                          // wave-uniform
             uint32_t first = 0, end = 0;
-            if (a.src_n[s]) search(a.src_key[s], 0u, a.src_n[s], first, end);
+            if (a.src_ranges[s]) {                                     // the source's own block ranges came with its records
+                const uint2 r = a.src_ranges[s][(id0 >> 8) - a.blk0];
+                first = r.x - (r.y != r.x ? a.src_base[s] : r.x); end = first + (r.y - r.x);
+            } else if (a.src_n[s]) search(a.src_key[s], 0u, a.src_n[s], first, end);
             if (lane == 0) {
                 seg_first[s] = first; cbase[s] = end - first;         // (cbase: free until the first batch)
                 seg_key[s] = (unsigned long long)(uintptr_t)a.src_key[s]; seg_hv[s] = (unsigned long long)(uintptr_t)a.src_hv[s];
@@ -1133,6 +1137,32 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         const uint32_t s = wave_inclusive_scan(mine);
         if (lane == 63 && s) atomicAdd(&a.counters[1], (unsigned long long)s);
     }
+}
+
+// Where every block's records are in a device's BLOCK-sorted records: ranges[b] = {first record, one past the last}; a block without
+// records keeps {0, 0} (the array is zeroed before).  One look at every key and its predecessor's: a block ends and the next
+// begins where the block id changes.  Used when the last pass's bins are not the blocks (maps of more than kOnePassMaxBins blocks)
+// -- the multi-GPU strip owners get the ranges of every source with its records and never search.
+__global__ __launch_bounds__(256) void k_block_ranges(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ n_records, int id_bits,
+                                                      uint2* __restrict__ ranges)
+{
+    const uint32_t M = *n_records, idmask = (1u << id_bits) - 1u;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= M) return;
+    const uint32_t b = (keys[i] & idmask) >> 8;
+    const uint32_t prev = i ? (keys[i - 1u] & idmask) >> 8 : 0xffffffffu;
+    if (b != prev) {
+        ranges[b].x = i;
+        if (i) ranges[prev].y = i;
+    }
+    if (i + 1u == M) ranges[b].y = M;
+}
+
+hipError_t launch_block_ranges(hipStream_t st, const uint32_t* keys, const uint32_t* n_records, long long max_records, int id_bits, uint2* ranges)
+{
+    if (max_records <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_block_ranges, dim3((unsigned)((max_records + 255) / 256)), dim3(256), 0, st, keys, n_records, id_bits, ranges);
+    return hipGetLastError();
 }
 
 // The boundaries of the tile-row strips in a device's sorted records (multi-GPU tiling): out[k] = first record whose cell id is

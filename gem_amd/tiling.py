@@ -51,6 +51,12 @@ def shard_batch(offsets, world: int, rank: int):
     return first, [max(off[first], lo)] + [min(max(off[s + 1], lo), hi) for s in range(first, last + 1)]
 
 
+def first_point_in_sweep(offsets, first_global_sweep: int, local_offsets) -> int:
+    """Index, inside its sweep, of a shard's first point (0 unless the shard begins in the middle of a sweep whose head the
+    rank before it holds): the camera sensor models take the pixel row / column from it."""
+    return int(local_offsets[0]) - int(offsets[first_global_sweep]) if len(local_offsets) > 1 else 0
+
+
 def route_sorted_records(bounds_by_rank, rank: int):
     """Stage-B routing table.  bounds_by_rank[s][k] = first record of strip k in rank s's sorted records.  Returns
     (send, recv): send[d] = (begin, end) of what this rank sends to strip owner d; recv[s] = number of records it gets
@@ -122,13 +128,14 @@ class TiledElevationMap:
         first, local = shard_batch(offsets, self.world, self.rank)
         local_frames = [frames[first + i] for i in range(len(local) - 1)]
         pb = self.map.pack_batch(local_frames, local, None)
+        fp = first_point_in_sweep(offsets, first, local)
         if self.exchange == "rccl":
-            self.map.add_sharded(pb, xyzi, first, n_global, var_updates)
+            self.map.add_sharded(pb, xyzi, first, n_global, var_updates, fp)
             return
         # the exchange carried by torch.distributed (gloo on CPU stand-ins, NCCL == RCCL on devices)
         import torch
         import torch.distributed as dist
-        bounds, hv, key = self.map.shard_sort_tensors(pb, xyzi, first, n_global, self.strip_rows)
+        bounds, hv, key = self.map.shard_sort_tensors(pb, xyzi, first, n_global, self.strip_rows, fp)
         gathered = [torch.zeros(self.world + 1, dtype=torch.int64, device=hv.device) for _ in range(self.world)]    # (NCCL carries device tensors only)
         dist.all_gather(gathered, torch.as_tensor(bounds, dtype=torch.int64).to(hv.device), group=group)
         send, recv = route_sorted_records([g.tolist() for g in gathered], self.rank)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GEM_ABI_VERSION 7
+#define GEM_ABI_VERSION 8
 
 typedef enum gem_status {
     GEM_OK = 0,
@@ -247,8 +247,11 @@ int  gem_get_stats(gem_handle* h, gem_stats* out, int reset);
 /* ---- multi-GPU: RCCL all-gather of the fused strips over xGMI ------------------------
  *      One process per GPU, one handle per process.  gem_comm_init splits the map into row strips in STORAGE coordinates
  *      (rank r owns rows [L r / W, L (r+1) / W): Move never migrates data); gem_comm_init_tiles makes the strips whole rows of
- *      32 x 32-cell tiles, which the sharded path below needs.  gem_allgather_layers completes every rank's copy of the layers
- *      (in-place ncclAllGather when the strips are equal, grouped ncclBroadcasts otherwise), enqueued on the handle's stream.
+ *      32 x 32-cell tiles, which the sharded path below needs.  gem_allgather_layers completes every rank's copy of the layers:
+ *      every rank's strip goes DIRECTLY to every other rank (one grouped ncclSend / ncclRecv pair per peer and layer: each peer
+ *      has its own xGMI link; strips of any sizes), read from a published copy of the strip and carried by the handle's
+ *      communication stream -- the call returns at once, later passes over this rank's own strip run beside the transfers, and
+ *      whatever observes the whole map (gem_get_layer, gem_synchronize, gem_move, ...) waits for them.
  *      Stage A (replicated binning): every rank calls gem_add* with the WHOLE cloud and fuses only its strip.             */
 int  gem_comm_unique_id(void* out_128_bytes);
 int  gem_comm_init(gem_handle* h, const void* unique_id_128_bytes, int nranks, int rank);
@@ -258,23 +261,35 @@ int  gem_allgather_layers(gem_handle* h, int with_attributes);   /* elevation+va
 
 /*      Stage B (points sharded): rank r holds a contiguous index range of the batch -- sweeps first_global_sweep ..
  *      first_global_sweep + n_local_sweeps - 1 of n_global_sweeps (a sweep may be split between two neighbouring ranks: both
- *      pass it, the lower rank holds its head).  gem_add_sharded_device = for s: Mapvar_update(var_updates_global[s]);
- *      add(sweep s) on the map tiled over the ranks: each rank projects / bins / sorts its own points for the whole map, the
- *      sorted records of every strip travel to the strip's owner (ncclSend / ncclRecv, one group), and the owner walks its
- *      cells through the sources in rank order -- ascending index ranges, so rank order is input order and every cell sees
- *      its points exactly as on one device.  Follow with gem_allgather_layers.  var_updates_global (n_global_sweeps values,
- *      identical on all ranks) may be NULL.  No colours, no lowest tracking on this path.
+ *      pass it, the lower rank holds its head; first_point_in_sweep = index, inside its sweep, of this rank's first point --
+ *      the camera sensor models derive the pixel row / column from it).  gem_add_sharded_device = for s:
+ *      Mapvar_update(var_updates_global[s]); add(sweep s) on the map tiled over the ranks: each rank projects / bins / sorts its
+ *      own points for the whole map (block-sorted: the records of a strip, and of every block of 256 cells, are one contiguous
+ *      range), the sorted records of every strip travel to the strip's owner together with their block ranges (ncclSend /
+ *      ncclRecv, one group, on the handle's communication stream; a rank's own records stay where they are), and the owner takes
+ *      every block's records source by source in rank order -- ascending index ranges, so rank order is input order and every
+ *      cell sees its points exactly as on one device.  With one rank nothing is exchanged and nothing returns to the host; with
+ *      more, one host round trip per call tells the ranks what they receive.  Follow with gem_allgather_layers (asynchronous:
+ *      it overlaps the next call's sort).  var_updates_global (n_global_sweeps values, identical on all ranks) may be NULL.  No
+ *      colours, no lowest tracking on this path.  An error returned after the first collective of a call means the communicator
+ *      has to be aborted (the other ranks wait in theirs); arguments, geometry and allocations are checked before it.
  *      The two halves are exported for hosts that carry the exchange themselves (gem_amd/tiling.py with torch.distributed):
- *      gem_shard_sort_device returns the device arrays of the sorted records {h, var} (8 bytes) / keys (4 bytes) and
- *      out_bounds[nstrips + 1], the first record of every strip; gem_shard_fuse_device walks this handle's strip through
- *      n_src sources (device pointers and record counts, in input order).                                               */
+ *      gem_shard_sort_device returns the device arrays of the sorted records {h, var} (8 bytes) / keys (4 bytes),
+ *      out_bounds[nstrips + 1] = the first record of every strip, and (optional) the device array of the block ranges
+ *      {first, end} (8 bytes per block of 256 cells, 4 x tiles entries, positions in the sorted arrays; empty block = {0, 0});
+ *      gem_shard_fuse_device walks this handle's strip through n_src sources in input order: device pointers and record counts,
+ *      and optionally (d_ranges, bases -- both or neither) every source's block ranges with entry 0 = the first block of this
+ *      handle's strip, and the position in the source's own arrays that d_hv[s] / d_key[s] point at; without them the blocks'
+ *      records are found by search.                                                                                        */
 int  gem_add_sharded_device(gem_handle* h, int n_local_sweeps, const gem_frame_params* params, const void* d_xyzi,
-                            const long long* offsets, int first_global_sweep, int n_global_sweeps, const float* var_updates_global);
+                            const long long* offsets, int first_global_sweep, int n_global_sweeps, int first_point_in_sweep,
+                            const float* var_updates_global);
 int  gem_shard_sort_device(gem_handle* h, int n_local_sweeps, const gem_frame_params* params, const void* d_xyzi,
-                           const long long* offsets, int first_global_sweep, int n_global_sweeps, int nstrips, const int* strip_rows,
-                           uint32_t* out_bounds, const void** out_d_hv, const void** out_d_key);
+                           const long long* offsets, int first_global_sweep, int n_global_sweeps, int first_point_in_sweep,
+                           int nstrips, const int* strip_rows,
+                           uint32_t* out_bounds, const void** out_d_hv, const void** out_d_key, const void** out_d_ranges);
 int  gem_shard_fuse_device(gem_handle* h, int n_src, const void* const* d_hv, const void* const* d_key, const uint32_t* counts,
-                           int n_global_sweeps, const float* var_updates_global);
+                           const void* const* d_ranges, const uint32_t* bases, int n_global_sweeps, const float* var_updates_global);
 
 #ifdef __cplusplus
 }
