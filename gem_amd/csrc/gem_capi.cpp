@@ -136,6 +136,7 @@ struct gem_handle {
     void* sh_host = nullptr;            // pinned staging of the small tables (kShardHostBytes)
 
     Arena dbg;          // optional k_fuse phase stamps
+    Arena ray;          // gem_raytracing: the cells that walk + their number
     Arena color;        // gem_colorize: its own sort arrays and tables (never shared with a pass in flight on the binning stream)
     bool  dbg_on = false;
     int   dbg_rows = 0;  // rows of `dbg` the last pass wrote, if it was a block-sorted one (else h->T rows)
@@ -740,7 +741,7 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     // (batches / aggregated clouds: C4 379 -> 313 us); single sweeps stay on one stream.
     bool overlap = h->overlap && in.n >= h->overlap_min_points && h->stream == h->own_stream && !h->counting && !h->dbg_on;
     // one launch per frame for a stream of single sweeps (k_frame): needs the other half of the double buffer
-    const bool defer = h->defer && in.device_input && in.src == 0 && !batched && attr == 0 && ts == 4 && !overlap &&
+    const bool defer = h->defer && in.device_input && in.src == 0 && !batched && (attr & 3) == 0 && ts == 4 && !overlap &&
                        !h->counting && !h->dbg_on;
     if (!defer) { const int rcd = flush_deferred(h); if (rcd) return rcd; }
     gem_handle::PassBuffers& pb = h->pb[(overlap || defer) ? (h->pass++ & 1u) : 0u];
@@ -861,7 +862,8 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     }
 
     if (defer) {
-        if (h->deferred.valid) { Timed t(h, 2); GEM_HIP(h, launch_frame(h->stream, h->deferred.fa, ba, t.events())); }
+        if (h->deferred.valid && h->deferred.attr != attr) { const int rcd = flush_deferred(h); if (rcd) return rcd; }   // (cannot happen: toggling the tracking flushes)
+        if (h->deferred.valid) { Timed t(h, 2); GEM_HIP(h, launch_frame(h->stream, h->deferred.fa, ba, attr, t.events())); }
         else                   { Timed t(h, 0); GEM_HIP(h, launch_bin(h->stream, ba, in.src, ts, t.events())); }
         h->deferred.fa = fa; h->deferred.ts = ts; h->deferred.attr = attr; h->deferred.valid = true;
         h->n_pending = 0;
@@ -972,7 +974,7 @@ void gem_destroy(gem_handle* h)
     for (auto& ep : h->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
     if (h->layers.elevation) hipFree(h->layers.elevation);      // base of the single layer allocation
     if (h->d_counters) hipFree(h->d_counters);
-    for (Arena* a : {&h->stage, &h->scratch, &h->dbg, &h->color, &h->sh_dev, &h->sh_recv_hv, &h->sh_recv_key, &h->sh_recv_rng, &h->sh_ranges, &h->published}) if (a->p) hipFree(a->p);
+    for (Arena* a : {&h->stage, &h->scratch, &h->dbg, &h->color, &h->ray, &h->sh_dev, &h->sh_recv_hv, &h->sh_recv_key, &h->sh_recv_rng, &h->sh_ranges, &h->published}) if (a->p) hipFree(a->p);
     if (h->sh_host) hipHostFree(h->sh_host);
     for (auto& b : h->pb) {
         for (Arena* a : {&b.rec, &b.srt, &b.seg, &b.flag, &b.gflag, &b.tables, &b.s_hv1, &b.s_hv2, &b.s_key1, &b.s_key2, &b.s_src1, &b.s_src2,
@@ -1531,8 +1533,13 @@ int gem_raytracing(gem_handle* h)
     if (h->row0 != 0 || h->row1 != h->L) return fail(h, GEM_ERR_INVALID, "gem_raytracing: not available on a row-strip handle");
     int rc = flush_pending(h, false);               // the queued variance increments are part of what the kernel reads
     if (rc) return rc;
+    if (!h->ray.p) {                                    // the list of walking cells and its counter (zeroed once; every call leaves it zero)
+        if ((rc = ensure(h, h->ray, ((size_t)h->cells + 4) * sizeof(uint32_t)))) return rc;
+        GEM_HIP(h, hipMemsetAsync(static_cast<uint32_t*>(h->ray.p) + h->cells, 0, 4 * sizeof(uint32_t), h->stream));
+    }
+    uint32_t* list = static_cast<uint32_t*>(h->ray.p);
     GEM_HIP(h, launch_raytracing(h->stream, h->layers, h->L, h->start[0], h->start[1], h->sensor_z, h->cfg.obstacle_threshold,
-                                 h->row0, h->row1));
+                                 h->row0, h->row1, list, list + h->cells));
     return GEM_OK;
 }
 

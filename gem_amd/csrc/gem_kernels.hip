@@ -1007,11 +1007,13 @@ __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_
 // of the double-buffered arenas.  Saves one kernel boundary (~3 us here) per frame and lets the binning run on
 // the CUs the fuse leaves idle.
 // ------------------------------------------------------------------------------------------
+// FLAGS: 0, or 4 = the fusion also maintains map_lowest (GPU:432-439; the adapter of the unmodified node turns it on for Raytracing).
+template <int FLAGS>
 __global__ __launch_bounds__(256, 4) void k_frame(FuseArgs fa, BinArgs ba)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
     const int nf = (fa.T + 3) & ~3;                                      // fuse blocks (see the block -> tile mapping)
-    if ((int)blockIdx.x < nf) { TileState<1> st; fuse_list_body<4, 256, 1024, 0, false, 0>(fa, (int)blockIdx.x, lds_dyn, st); }
+    if ((int)blockIdx.x < nf) { TileState<1> st; fuse_list_body<4, 256, 1024, FLAGS, false, 0>(fa, (int)blockIdx.x, lds_dyn, st); }
     else bin_wave_body<0, 4, false>(ba, (int)blockIdx.x - nf);
 }
 
@@ -1435,10 +1437,12 @@ hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr, int 
 }
 
 // fuse of the previous frame + bin of this one (single sweeps on 16x16 tiles, no attributes)
-hipError_t launch_frame(hipStream_t st, const FuseArgs& fa, const BinArgs& ba, LaunchEvents ev)
+hipError_t launch_frame(hipStream_t st, const FuseArgs& fa, const BinArgs& ba, int attr, LaunchEvents ev)
 {
     const dim3 grid(((fa.T + 3) & ~3) + (ba.B + 3) / 4), block(256);
-    GEM_LAUNCH((k_frame), grid, block, fuse_list_lds(256, 4, 1024, 0), st, ev, fa, ba);
+    if (attr == 4)      GEM_LAUNCH((k_frame<4>), grid, block, fuse_list_lds(256, 4, 1024, 0), st, ev, fa, ba);
+    else if (attr == 0) GEM_LAUNCH((k_frame<0>), grid, block, fuse_list_lds(256, 4, 1024, 0), st, ev, fa, ba);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -1452,53 +1456,113 @@ hipError_t launch_frame(hipStream_t st, const FuseArgs& fa, const BinArgs& ba, L
 // A thread writes only its own cell's elevation and reads only its own cell's elevation / variance: no ordering issue.
 // The walks diverge (up to L steps); at 600 x 600 the kernel is a few tens of microseconds, once per frame.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_raytracing(LayerPtrs m, int L, int start0, int start1, float sensor_z, float obstacle_threshold,
-                                                   int row0, int row1)
+// The DDA divides by the same two direction components at every step (GPU:831-832 and twins).  hipcc expands an IEEE float division
+// into v_div_scale x 2, v_rcp, two Newton steps on the reciprocal, the quotient, two residual corrections (the last one
+// v_div_fmas) and v_div_fixup; for operands far from the ends of the exponent range -- here |a| in [0.5, L + 1], |b| in
+// [1 / (1.5 L), 1] -- the scale factors are 1, v_div_fmas is a plain fma and v_div_fixup passes the quotient through.  So the
+// refined reciprocal is computed ONCE per cell and every step runs only the quotient and its two corrections: the same
+// operations in the same order on the same values, i.e. the same bits, in five dependent instructions instead of ten.
+__device__ __forceinline__ float refined_rcp(float b)
+{
+    const float r = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+__device__ __forceinline__ float div_by(float a, float b, float r)     // a / b, r = refined_rcp(b); see above for the operand ranges
+{
+    float q = a * r;
+    float e = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(e, r, q);
+}
+
+// The cells that walk: obstacle cells (GPU:712) off the centre row and column (GPU:760-791: there the bound is computed and never
+// applied).  Most of a map's cells do not, and a wave lasts as long as its longest ray: the walkers are compacted into a list first
+// (one ballot and one atomic per wave; the order is irrelevant, every cell only touches itself) and k_raytracing runs on full waves.
+__device__ __forceinline__ int ray_robot_index(int L) { return (L % 2 == 0) ? (int)(float)(L / 2 - 0.5) : (int)(float)(L / 2); }   // GPU:733, 739: float -> int
+
+__global__ __launch_bounds__(256) void k_ray_list(LayerPtrs m, int L, int start0, int start1, float obstacle_threshold, int row0, int row1,
+                                                 uint32_t* __restrict__ list, uint32_t* __restrict__ count)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L * L) return;
+    bool walks = false;
+    if (i < L * L) {
+        const int cell_x = i / L, cell_y = i - cell_x * L;
+        if (cell_x >= row0 && cell_x < row1 && m.traver[i] < obstacle_threshold && m.elevation[i] != kEmptyElevation) {    // GPU:712
+            int ob0 = cell_x + L - start0; ob0 -= ob0 >= L ? L : 0;                              // GPU:672-675 (% L)
+            int ob1 = cell_y + L - start1; ob1 -= ob1 >= L ? L : 0;
+            const int robot_index = ray_robot_index(L);
+            walks = ob0 != robot_index && ob1 != robot_index;
+        }
+    }
+    const uint64_t mk = __ballot(walks);
+    if (mk == 0) return;
+    uint32_t base = 0;
+    if (lane_id() == 0) base = atomicAdd(count, (uint32_t)__popcll(mk));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (walks) list[base + (uint32_t)__popcll(mk & lanemask_lt())] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void k_raytracing(LayerPtrs m, int L, int start0, int start1, float sensor_z,
+                                                   const uint32_t* __restrict__ list, const uint32_t* __restrict__ count)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= *count) return;
+    const int i = (int)list[t];
     const int cell_x = i / L, cell_y = i - cell_x * L;
-    if (cell_x < row0 || cell_x >= row1) return;
     const float obstacle_ele = m.elevation[i];
-    if (!(m.traver[i] < obstacle_threshold && obstacle_ele != kEmptyElevation)) return;         // GPU:712
     int ob0 = cell_x + L - start0; ob0 -= ob0 >= L ? L : 0;                                      // GPU:672-675 (% L)
     int ob1 = cell_y + L - start1; ob1 -= ob1 >= L ? L : 0;
-    const int robot_index = (L % 2 == 0) ? (int)(float)(L / 2 - 0.5) : (int)(float)(L / 2);     // GPU:733, 739: float -> int
+    const int robot_index = ray_robot_index(L);
     const float inc0 = (float)(ob0 - robot_index), inc1 = (float)(ob1 - robot_index);
-    const int inc_x = inc0 > 0 ? 1 : (inc0 == 0 ? 0 : -1), inc_y = inc1 > 0 ? 1 : (inc1 == 0 ? 0 : -1);
-    if (inc_x == 0 || inc_y == 0) return;                                                        // GPU:760-791: bound computed, never applied
+    const int inc_x = inc0 > 0 ? 1 : -1, inc_y = inc1 > 0 ? 1 : -1;                              // (neither is 0: k_ray_list)
     const float dis = sqrtf(inc0 * inc0 + inc1 * inc1);                                          // GPU:793
     const float dir0 = inc0 / dis, dir1 = inc1 / dis;
     float threshold;                                                                             // GPU:798-802, double arithmetic
     if (fabsf(inc0) > fabsf(inc1)) { const double t = 0.5 / (double)inc0 * (double)inc1; threshold = (float)sqrt(0.5 * 0.5 + t * t); }
     else                           { const double t = 0.5 / (double)inc1 * (double)inc0; threshold = (float)sqrt(0.5 * 0.5 + t * t); }
     float bound_x = (float)inc_x / 2, bound_y = (float)inc_y / 2;                               // GPU:808-809
-    float dir_num_x = bound_x / dir0, dir_num_y = bound_y / dir1, later = 0.0f;
+    const float rcp0 = refined_rcp(dir0), rcp1 = refined_rcp(dir1);
+    float dir_num_x = div_by(bound_x, dir0, rcp0), dir_num_y = div_by(bound_y, dir1, rcp1), later = 0.0f;
     float restrict_ele = obstacle_ele;
     const float robot_f = (float)robot_index;
     int c0 = ob0, c1 = ob1;
     // GPU:819-880.  The reference's three branches (step in y / step in x / step in both when the two border distances tie)
     // are one straight-line body here: the crossed-cell test uses the smaller distance (dir_num_x when they tie, as in the
     // reference's last branch), and each axis advances under a select.  Every value is computed by the reference's own
-    // expression; lanes of a wave do not serialise over the three variants (measured: no faster than the branchy form -- the
-    // kernel is bound by the two IEEE divisions per step -- but one body instead of three).
-    while (c0 >= 0 && c0 < L && c1 >= 0 && c1 < L) {
-        const bool step_y = dir_num_x > dir_num_y;                 // GPU:821
-        const bool step_x = dir_num_x < dir_num_y;                 // GPU:838; neither: both axes (GPU:855)
-        const float step = step_y ? dir_num_y : dir_num_x;
-        if (step - later > threshold && c0 != ob0 && c1 != ob1) {  // GPU:823-830 and twins
-            const float low = m.lowest[(size_t)c0 * L + c1];
-            if (low != 10.0f) {                                    // GPU:681-689
-                const float x1 = (float)(c0 - ob0), x2 = (float)c0 - robot_f;                    // GPU:691-706
-                const float e = low + (sensor_z - low) / x2 * x1;
+    // expression (the two divisions per step through div_by, above); lanes of a wave do not serialise over the three variants.
+    // The walk itself (c0, c1, the border distances) never depends on what it reads: the lowest scan point of a crossed cell only
+    // lowers `restrict_ele`, a running minimum.  A load waited for in every step made the loop a chain of memory latencies
+    // (~70 us for the 600^2 map); here the walk runs four steps ahead -- four loads in flight, addresses clamped instead of
+    // branched round -- and the bounds are folded in afterwards (a minimum: any order).
+    constexpr int RD = 4;
+    bool inside = c0 >= 0 && c0 < L && c1 >= 0 && c1 < L;
+    while (__ballot(inside) != 0) {                                   // wave-uniform; lanes that left the map idle
+        float low[RD]; int hc0[RD]; bool hit[RD];
+#pragma unroll
+        for (int u = 0; u < RD; ++u) {
+            const bool step_y = dir_num_x > dir_num_y;                 // GPU:821
+            const bool step_x = dir_num_x < dir_num_y;                 // GPU:838; neither: both axes (GPU:855)
+            const float step = step_y ? dir_num_y : dir_num_x;
+            hit[u] = inside && step - later > threshold && c0 != ob0 && c1 != ob1;       // GPU:823-830 and twins
+            hc0[u] = c0;
+            low[u] = m.lowest[hit[u] ? (size_t)c0 * L + c1 : (size_t)0];
+            later = inside ? step : later;
+            const float nbx = bound_x + (float)inc_x, nby = bound_y + (float)inc_y;
+            const float ndx = div_by(nbx, dir0, rcp0), ndy = div_by(nby, dir1, rcp1);
+            if (inside && !step_y) { c0 += inc_x; bound_x = nbx; dir_num_x = ndx; }
+            if (inside && !step_x) { c1 += inc_y; bound_y = nby; dir_num_y = ndy; }
+            inside = inside && c0 >= 0 && c0 < L && c1 >= 0 && c1 < L;
+        }
+#pragma unroll
+        for (int u = 0; u < RD; ++u) {
+            if (hit[u] && low[u] != 10.0f) {                           // GPU:681-689
+                const float x1 = (float)(hc0[u] - ob0), x2 = (float)hc0[u] - robot_f;            // GPU:691-706
+                const float e = low[u] + (sensor_z - low[u]) / x2 * x1;
                 if (e < restrict_ele) restrict_ele = e;
             }
         }
-        later = step;
-        const float nbx = bound_x + (float)inc_x, nby = bound_y + (float)inc_y;
-        const float ndx = nbx / dir0, ndy = nby / dir1;
-        if (!step_y) { c0 += inc_x; bound_x = nbx; dir_num_x = ndx; }
-        if (!step_x) { c1 += inc_y; bound_y = nby; dir_num_y = ndy; }
     }
     if (obstacle_ele - 3 * sqrtf(m.variance[i]) > restrict_ele) m.elevation[i] = kEmptyElevation;   // GPU:884-885
 }
@@ -1533,11 +1597,22 @@ __global__ __launch_bounds__(256) void k_fill(float* p, int n, float v)
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
 }
 
-hipError_t launch_raytracing(hipStream_t st, const LayerPtrs& m, int L, int start0, int start1, float sensor_z, float obstacle_threshold,
-                             int row0, int row1)
+// G_Clear_maplowest (GPU:232-239) behind the walks; the same launch zeroes the list's counter for the next call
+__global__ __launch_bounds__(256) void k_clear_lowest(float* p, int n, uint32_t* count)
 {
-    hipLaunchKernelGGL(k_raytracing, dim3((L * L + 255) / 256), dim3(256), 0, st, m, L, start0, start1, sensor_z, obstacle_threshold, row0, row1);
-    hipLaunchKernelGGL(k_fill, dim3(grid_for(L * L, 256)), dim3(256), 0, st, m.lowest, L * L, 10.0f);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *count = 0u;
+    if (i < n) p[i] = 10.0f;
+}
+
+// list: L * L words (the walking cells); count: their number, zero on entry (zeroed at allocation and by every call on its way out)
+hipError_t launch_raytracing(hipStream_t st, const LayerPtrs& m, int L, int start0, int start1, float sensor_z, float obstacle_threshold,
+                             int row0, int row1, uint32_t* list, uint32_t* count)
+{
+    const dim3 grid((L * L + 255) / 256), block(256);
+    hipLaunchKernelGGL(k_ray_list, grid, block, 0, st, m, L, start0, start1, obstacle_threshold, row0, row1, list, count);
+    hipLaunchKernelGGL(k_raytracing, grid, block, 0, st, m, L, start0, start1, sensor_z, (const uint32_t*)list, (const uint32_t*)count);
+    hipLaunchKernelGGL(k_clear_lowest, grid, block, 0, st, m.lowest, L * L, count);
     return hipGetLastError();
 }
 

@@ -111,7 +111,7 @@ def main():
         m.synchronize(); dtf = (time.perf_counter() - t0) / (args.reps * 2)
         print(json.dumps({"config": "C2 node sequence: add (lowest tracking on) + Map_feature + Raytracing, device-resident",
                           "wall_us": dt * 1e6, "add_with_lowest_tracking_us": dtf * 1e6,
-                          "note": "tracking on: k_bin_wave + k_fuse_list<LOWEST> (two launches, no deferred k_frame)"}), flush=True)
+                          "note": "tracking on: k_frame<LOWEST> (one launch per frame, the fusion deferred like the plain stream)"}), flush=True)
         m.close()
 
     if "color" in want:
