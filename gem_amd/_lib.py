@@ -84,6 +84,7 @@ SIGNATURES = {
     "gem_colorize_device": (c_int, [c_void_p, POINTER(Camera), c_int, c_void_p, c_void_p, C.c_size_t, c_void_p]),
     "gem_show": (c_int, [c_void_p, c_double, c_double, POINTER(c_double), c_void_p, c_void_p, c_void_p, POINTER(c_int), c_void_p]),
     "gem_comm_init_tiles": (c_int, [c_void_p, c_void_p, c_int, c_int]),
+    "gem_reserve": (c_int, [c_void_p, c_longlong, c_int, c_int]),
     "gem_get_strip": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     "gem_add_sharded_device": (c_int, [c_void_p, c_int, POINTER(FrameParams), c_void_p, POINTER(c_longlong), c_int, c_int, c_int, POINTER(c_float)]),
     "gem_shard_sort_device": (c_int, [c_void_p, c_int, POINTER(FrameParams), c_void_p, POINTER(c_longlong), c_int, c_int, c_int, c_int, POINTER(c_int),
@@ -94,6 +95,7 @@ SIGNATURES = {
 # include/gem_hip_debug.h (tuning knobs / profiling aids, not part of the drop-in surface)
 DEBUG_SIGNATURES = {
     "gem_debug_set": (c_int, [c_void_p, c_char_p, c_longlong]),
+    "gem_debug_get": (c_int, [c_void_p, c_char_p, POINTER(c_longlong)]),
     "gem_debug_fuse_stamps": (c_int, [c_void_p, c_int, c_void_p, c_int]),
 }
 

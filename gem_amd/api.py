@@ -261,6 +261,11 @@ class ElevationMap:
         """Tuning / test knob (gem_debug_set, include/gem_hip_debug.h): selects between code paths that produce the same map."""
         self._check(self._lib.gem_debug_set(self._h, key.encode(), int(value)), f"gem_debug_set({key})")
 
+    def debug_get(self, key: str) -> int:
+        v = C.c_longlong()
+        self._check(self._lib.gem_debug_get(self._h, key.encode(), C.byref(v)), f"gem_debug_get({key})")
+        return int(v.value)
+
     def set_stream(self, hip_stream: Optional[int]) -> None:
         self._check(self._lib.gem_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None), "gem_set_stream")
 
@@ -356,6 +361,10 @@ class ElevationMap:
                                                    pb.var_updates), "gem_add_batch_device")
 
     # -- Mapvar_update (RMU.cpp:81) ------------------------------------------------------------------
+    def reserve(self, max_points: int, max_sweeps: int = 1, with_colours: bool = False) -> None:
+        """Pre-size the device arenas for the largest pass to come (gem_reserve): no pass within these bounds allocates afterwards."""
+        self._check(self._lib.gem_reserve(self._h, int(max_points), int(max_sweeps), int(with_colours)), "gem_reserve")
+
     def mapvar_update(self, var_update: float) -> None:
         self._check(self._lib.gem_mapvar_update(self._h, float(var_update)), "gem_mapvar_update")
 

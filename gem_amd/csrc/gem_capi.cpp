@@ -139,6 +139,7 @@ struct gem_handle {
     Arena ray;          // gem_raytracing: the cells that walk + their number
     Arena color;        // gem_colorize: its own sort arrays and tables (never shared with a pass in flight on the binning stream)
     bool  dbg_on = false;
+    long long arena_allocations = 0;   // hipMalloc calls of ensure() so far (gem_debug_get: a stream of frames after gem_reserve must not add any)
     int   dbg_rows = 0;  // rows of `dbg` the last pass wrote, if it was a block-sorted one (else h->T rows)
     int fuse_variant = 12;
 };
@@ -172,6 +173,7 @@ int ensure(gem_handle* h, Arena& a, size_t bytes)
     hipError_t e = hipMalloc(&a.p, want);
     if (e != hipSuccess) return fail(h, GEM_ERR_NOMEM, "hipMalloc(arena)", e);
     a.cap = want;
+    ++h->arena_allocations;
     return GEM_OK;
 }
 
@@ -1240,6 +1242,78 @@ int gem_add_batch_device(gem_handle* h, int n_sweeps, const gem_frame_params* pa
     return run_pipeline(h, in);
 }
 
+// Arenas for the largest pass the caller is going to make, allocated NOW: the arenas only ever grow, but growing means waiting for
+// everything in flight, hipFree and hipMalloc -- in the middle of a stream of frames that is a stall of a millisecond or more the
+// first time a bigger cloud arrives (measured: tools/bench_configs.py --configs reserve).  max_points points in at most max_sweeps
+// sweeps per call (1 for gem_add*); colours as they will be passed.  Sizes follow run_pipeline / run_sort_pipeline.
+int gem_reserve(gem_handle* h, long long max_points, int max_sweeps, int with_colours)
+{
+    if (!h || max_points < 0 || max_sweeps < 1 || max_points >= (1ll << 31)) return h ? fail(h, GEM_ERR_INVALID, "gem_reserve: bad argument") : GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
+    if (max_points == 0) return GEM_OK;
+    int rc;
+    const size_t N = (size_t)max_points;
+    // staging of host-pointer inputs (gem_add: XYZI + rgb + orig; gem_fuse: seven arrays; gem_process_points: nine)
+    if ((rc = ensure(h, h->stage, N * 4 * 9))) return rc;
+    const long long sort_from = max_sweeps > 1 ? h->sort_min_points_batch : h->sort_min_points;
+    const long long blocks = 4ll * ((h->L + 31) / 32) * ((h->L + 31) / 32);
+    bool sorted = false;
+    if (h->sort_path && max_points >= sort_from) {
+        const bool block_form = h->sort_form == 2 || (h->sort_form == 0 && max_sweeps > 1 && blocks <= kOnePassMaxBins);
+        SortGeometry geo = sort_geometry(h, max_sweeps, block_form);
+        if (!geo.ok) geo = sort_geometry(h, max_sweeps, !block_form);
+        if (geo.ok) {
+            sorted = true;
+            const size_t chunk = (size_t)kSortChunkRecords;
+            const size_t NC1 = (N + chunk - 1) / chunk + (size_t)max_sweeps, nc2 = (N + chunk - 1) / chunk;
+            int bins_hi = 1;
+            for (int i = 1; i < geo.n_passes; ++i) bins_hi = std::max(bins_hi, geo.dbins[i]);
+            size_t misc = 0;
+            for (int i = 0; i < geo.n_passes; ++i) misc += (size_t)geo.dbins[i] * 16;
+            misc = ((misc + 4 + 15) & ~(size_t)15) + (((size_t)geo.dbins[geo.n_passes - 1] + 1) * 4 + 15) + NC1 * kSortSegsPerChunk * 4 + 64;
+            const size_t tables = sizeof(FrameConst) * max_sweeps + (sizeof(int) + sizeof(long long)) * (max_sweeps + 1) + (sizeof(float) + sizeof(int)) * max_sweeps + 64;
+            const int slots = std::max(1, std::min(h->sort_ring, 4));
+            for (int k = 0; k < slots; ++k) {
+                gem_handle::PassBuffers& pb = h->pb[k];
+                if ((rc = ensure(h, pb.s_hv1, N * 8 + 64)) || (rc = ensure(h, pb.s_hv2, N * 8 + 64)) ||
+                    (rc = ensure(h, pb.s_key1, N * 4 + 64)) || (rc = ensure(h, pb.s_key2, N * 4 + 64))) return rc;
+                if (with_colours && ((rc = ensure(h, pb.s_src1, N * 4 + 64)) || (rc = ensure(h, pb.s_src2, N * 4 + 64)))) return rc;
+                if ((rc = ensure(h, pb.s_cnt1, NC1 * geo.dbins[0] * 4)) || (rc = ensure(h, pb.s_cnt2, nc2 * bins_hi * 4 + 16)) ||
+                    (rc = ensure(h, pb.s_misc, misc))) return rc;
+                if (max_sweeps > 1 && (rc = ensure(h, pb.tables, tables))) return rc;
+            }
+        }
+    }
+    if (!sorted) {
+        // tile pipeline: units of 64 points, every sweep rounded up to 32 units; the descriptor table is [sweep][tile][units of the longest sweep]
+        const long long units1 = ((max_points + kUnit - 1) / kUnit + 31) & ~31ll;
+        const long long B = units1 + 32ll * (max_sweeps - 1);
+        const int ts = h->ts ? h->ts : 4;
+        const long long tpr = (h->L + (1 << ts) - 1) >> ts, T = tpr * tpr;
+        const size_t seg = (size_t)max_sweeps * T * units1 * sizeof(uint16_t);
+        if (seg > ((size_t)1 << 31)) return fail(h, GEM_ERR_INVALID, "gem_reserve: a tile-pipeline pass of this shape would need a descriptor table beyond 2 GiB");
+        for (int k = 0; k < 2; ++k) {
+            gem_handle::PassBuffers& pb = h->pb[k];
+            if ((rc = ensure(h, pb.rec, (size_t)B * kUnit * sizeof(uint4))) || (rc = ensure(h, pb.srt, (size_t)B * kUnit * sizeof(uint4) + 16))) return rc;
+            if (seg > pb.seg.cap) {                          // (the table is all-zero between passes: cleared when it is (re)allocated)
+                if ((rc = ensure(h, pb.seg, seg))) return rc;
+                GEM_HIP(h, hipMemsetAsync(pb.seg.p, 0, pb.seg.cap, h->stream));
+            }
+            const size_t flag = (size_t)T * max_sweeps * sizeof(uint32_t), gflag = (size_t)max_sweeps * T * (units1 / 32) * sizeof(uint32_t);
+            if (flag > pb.flag.cap || gflag > pb.gflag.cap) {
+                if ((rc = ensure(h, pb.flag, flag)) || (rc = ensure(h, pb.gflag, gflag))) return rc;
+                GEM_HIP(h, hipMemsetAsync(pb.flag.p, 0, pb.flag.cap, h->stream));
+                GEM_HIP(h, hipMemsetAsync(pb.gflag.p, 0, pb.gflag.cap, h->stream));
+                pb.epoch = 0;
+            }
+        }
+    }
+    GEM_HIP(h, hipStreamSynchronize(h->stream));
+    return GEM_OK;
+}
+
 int gem_mapvar_update(gem_handle* h, float var_update)
 {
     if (!h) return GEM_ERR_INVALID;
@@ -1621,6 +1695,16 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "fast_laser")         h->fast_laser = value != 0;
     else if (k == "sort_form")          { if (value < 0 || value > 2) return fail(h, GEM_ERR_INVALID, "sort_form: 0 (by pass), 1 (cell-sorted), 2 (block-sorted)"); h->sort_form = (int)value; }
     else return fail(h, GEM_ERR_INVALID, "gem_debug_set: unknown key");
+    return GEM_OK;
+}
+
+int gem_debug_get(gem_handle* h, const char* key, long long* out)
+{
+    if (!h || !key || !out) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    const std::string k(key);
+    if (k == "arena_allocations") *out = h->arena_allocations;
+    else return fail(h, GEM_ERR_INVALID, "gem_debug_get: unknown key");
     return GEM_OK;
 }
 

@@ -1591,12 +1591,6 @@ hipError_t launch_unpack_aos(hipStream_t st, const void* src, int n, int step, i
     return hipGetLastError();
 }
 
-// G_Clear_maplowest (GPU:232-239)
-__global__ __launch_bounds__(256) void k_fill(float* p, int n, float v)
-{
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
-}
-
 // G_Clear_maplowest (GPU:232-239) behind the walks; the same launch zeroes the list's counter for the next call
 __global__ __launch_bounds__(256) void k_clear_lowest(float* p, int n, uint32_t* count)
 {

@@ -244,6 +244,12 @@ int  gem_set_timing(gem_handle* h, int enabled);      /* record hipEvents around
 int  gem_set_counting(gem_handle* h, int enabled);    /* count binned points / touched cells on device */
 int  gem_get_stats(gem_handle* h, gem_stats* out, int reset);
 
+/* Pre-size the handle's device arenas for the largest pass that is going to come: max_points points in at most max_sweeps sweeps
+ * per call (1 for gem_add / gem_add_device / gem_fuse), with or without colours.  The arenas only ever grow, but growing in the
+ * middle of a stream -- the first bigger cloud after smaller ones -- waits for everything in flight and re-allocates; after
+ * gem_reserve no pass within these bounds allocates.  Synchronous; call it once after gem_create.                            */
+int  gem_reserve(gem_handle* h, long long max_points, int max_sweeps, int with_colours);
+
 /* ---- multi-GPU: RCCL all-gather of the fused strips over xGMI ------------------------
  *      One process per GPU, one handle per process.  gem_comm_init splits the map into row strips in STORAGE coordinates
  *      (rank r owns rows [L r / W, L (r+1) / W): Move never migrates data); gem_comm_init_tiles makes the strips whole rows of

@@ -16,11 +16,17 @@ extern "C" {
  *       "defer" (0/1: one launch per frame for streams of single sweeps), "dense_min" (records of one sweep in one
  *       16x16 tile above which the tile is counting-sorted), "dbg_sweep", "overlap" (0/1: binning of big passes on a
  *       second stream), "overlap_min_points", "sort_path" (0/1: the sorted pipeline for big passes), "sort_min_points",
- *       "sort_passes" (0 = by map size, 2, 3: counting-sort passes over the cell id), "walk_permute" (0/1),
+ *       "sort_passes" (0 = by map size and form, 1..3: counting-sort passes), "sort_form" (0 = by pass: batches of sweeps block-sorted
+ *       (k_fuse_block), single clouds cell-sorted (k_fuse_walk); 1 / 2 force cell / block), "fast_laser" (0/1: the
+ *       zero-rotation-variance form of the laser variance for frames that qualify), "lane_sort" (0/1: k_fuse_block hands the
+ *       cells to the threads by record count), "walk_permute" (0/1),
  *       "sort_streams" (1, 2: binning streams consecutive overlapped passes of the sorted pipeline alternate between), "sort_ring" (2..4: the buffer sets they rotate through),
  *       "trace" (0/1: one line on stderr per pass of the sorted pipeline), "stream_roles" (a permutation of 0123 as a decimal
  *       number: which of the handle's current own / bin / bin2 / upload streams takes each role; tools/dbg/roles.py).  Returns GEM_ERR_INVALID for an unknown key or a value out of range. */
 int gem_debug_set(gem_handle* h, const char* key, long long value);
+
+/* read-outs: "arena_allocations" (device allocations the handle's arenas have made so far: none may follow gem_reserve) */
+int gem_debug_get(gem_handle* h, const char* key, long long* out);
 
 /* per-tile cycle stamps of the last fuse launch ([tile][16] 64-bit counters); enable != 0 turns the stamps on for the
  * following passes; with out != NULL copies up to max_tiles rows and returns their number */

@@ -97,3 +97,28 @@ def test_random_call_sequence(oracle_mod, monkeypatch, seed):
     for name in ("elevation", "variance", "intensity", "color_r"):
         assert np.array_equal(gpu.layer(name), ref.layer(name)), name
     assert checks >= 3
+
+
+def test_reserve_then_no_allocation_in_the_stream(oracle_mod):
+    """gem_reserve sizes the arenas for the largest pass to come: a stream that starts with small clouds and then meets the big
+    one -- on either pipeline, single sweeps and a batch -- allocates nothing on the way, and the map is the oracle's."""
+    import torch
+    wl = synth.config_c4(n_sweeps=6)
+    gpu, ref = ElevationMap(wl.length, wl.resolution), oracle_mod.OracleMap(wl.length, wl.resolution)
+    n = wl.clouds[0].shape[0]
+    gpu.reserve(n, 1)
+    gpu.reserve(6 * n, 6)
+    before = gpu.debug_get("arena_allocations")
+    assert before > 0
+    d = [torch.from_numpy(c).cuda() for c in wl.clouds]
+    for k in (0, 1):
+        gpu.add(wl.frames[k], d[k][:5000]); ref.add(wl.frames[k], wl.clouds[k][:5000])          # small clouds first
+    for k in (2, 3):
+        gpu.add(wl.frames[k], d[k]); ref.add(wl.frames[k], wl.clouds[k])                        # the full sweep
+    off = np.concatenate([[0], np.cumsum([c.shape[0] for c in wl.clouds])])
+    gpu.add_batch(wl.frames, torch.from_numpy(np.concatenate(wl.clouds)).cuda(), off, wl.var_updates)
+    for k in range(6):
+        ref.mapvar_update(wl.var_updates[k]); ref.add(wl.frames[k], wl.clouds[k])
+    for name in ("elevation", "variance"):
+        assert np.array_equal(gpu.layer(name), ref.layer(name)), name
+    assert gpu.debug_get("arena_allocations") == before, "a pass inside the reserved bounds allocated"

@@ -137,6 +137,29 @@ def main():
                           "note": "memset of the pixel table (3.7 MB) + k_sort_project<camera> + 2 x (scan, scatter) + count + 3 colour kernels"}), flush=True)
         m.close()
 
+    if "reserve" in want:
+        # the first big frame after small ones: the arenas grow (everything in flight is waited for, hipFree + hipMalloc) unless
+        # gem_reserve sized them beforehand
+        wl = synth.config_c4(n_sweeps=2)
+        big = torch.from_numpy(wl.clouds[1]).to(dev)
+        small = torch.from_numpy(wl.clouds[0][:8192].copy()).to(dev)
+        out = {}
+        for label, reserve in (("first_big_frame_us_without_reserve", False), ("first_big_frame_us_after_gem_reserve", True)):
+            m = ElevationMap(wl.length, wl.resolution)
+            if reserve:
+                m.reserve(big.shape[0], 1)
+            for _ in range(8):
+                m.add(wl.frames[0], small)
+            m.synchronize(); t0 = time.perf_counter()
+            m.add(wl.frames[1], big); m.synchronize()
+            out[label] = (time.perf_counter() - t0) * 1e6
+            t0 = time.perf_counter()
+            m.add(wl.frames[1], big); m.synchronize()
+            out[label.replace("first", "second")] = (time.perf_counter() - t0) * 1e6
+            out["arena_allocations" + ("_after_reserve" if reserve else "")] = m.debug_get("arena_allocations")
+            m.close()
+        print(json.dumps({"config": "gem_reserve: 8 x 8192-pt frames, then a 131072-pt frame (each timed with a synchronisation)", **out}), flush=True)
+
     if "c3" in want:
         wl = synth.config_c3()
         d = torch.from_numpy(wl.clouds[0]).to(dev)
