@@ -132,3 +132,61 @@ class RefMap:
             a = np.ascontiguousarray(values, np.int32).reshape(-1); self._l.gemref_set_layer(self.INT[name], _vp(a))
         else:
             a = np.ascontiguousarray(values, np.float32).reshape(-1); self._l.gemref_set_layer(self.FLOAT[name], _vp(a))
+
+
+# ---- the reference's RobotMotionMapUpdater.cpp compiled against stand-ins for Eigen / kindr / ROS (build_ref.build_motion) ----------
+_motion_lib = None
+
+
+def motion_lib():
+    global _motion_lib
+    if _motion_lib is None:
+        import build_ref
+        path = build_ref.build_motion()
+        if path is None:
+            return None
+        l = C.CDLL(str(path))
+        l.gemref_motion_create.restype = c_void_p; l.gemref_motion_create.argtypes = [c_double]
+        l.gemref_motion_destroy.argtypes = [c_void_p]
+        l.gemref_motion_update.restype = c_int
+        l.gemref_motion_update.argtypes = [c_void_p, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double), c_int, c_double, POINTER(c_float)]
+        _motion_lib = l
+    return _motion_lib
+
+
+def quaternion_from_matrix(R) -> np.ndarray:
+    """Hamilton unit quaternion (w, x, y, z), w >= 0, of a rotation matrix."""
+    R = np.asarray(R, np.float64)
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2; q = [0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s]
+    else:
+        i = int(np.argmax(np.diag(R))); j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+        q = [0.0] * 4
+        q[0] = (R[k, j] - R[j, k]) / s; q[1 + i] = 0.25 * s; q[1 + j] = (R[j, i] + R[i, j]) / s; q[1 + k] = (R[k, i] + R[i, k]) / s
+    q = np.array(q); q /= np.linalg.norm(q)
+    return q if q[0] >= 0 else -q
+
+
+class RefMotion:
+    """RobotMotionMapUpdater of the reference: update() with a pose (position, rotation matrix R_IB), the 6 x 6 pose covariance and
+    the map's rotation; returns the float it hands to Mapvar_update (RMU.cpp:80-81)."""
+
+    def __init__(self, covariance_scale: float = 1.0, length: int = 600):
+        self._l = motion_lib()
+        self._u = self._l.gemref_motion_create(covariance_scale)
+        self._t, self._len = 0.0, length
+
+    def __del__(self):
+        if getattr(self, "_u", None):
+            self._l.gemref_motion_destroy(self._u); self._u = None
+
+    def compute(self, position, R_IB, cov6x6, map_rotation=None) -> float:
+        d = lambda a, n: (c_double * n)(*np.asarray(a, np.float64).reshape(-1).tolist())
+        self._t += 1.0
+        out = c_float()
+        q, mq = quaternion_from_matrix(R_IB), quaternion_from_matrix(np.eye(3) if map_rotation is None else map_rotation)
+        ok = self._l.gemref_motion_update(self._u, d(position, 3), d(q, 4), d(cov6x6, 36), d(mq, 4), self._len, self._t, C.byref(out))
+        assert ok == 1, "the reference skipped the update"
+        return float(out.value)

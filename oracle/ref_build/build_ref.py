@@ -70,6 +70,36 @@ def build(reference: Path = Path("/root/reference"), force: bool = False, verbos
     return OUT
 
 
+OUT_MOTION = HERE.parent / "_ref" / "libgem_ref_motion.so"
+REL_MOTION = "elevation_mapping/elevation_mapping/src/RobotMotionMapUpdater.cpp"
+REL_INCLUDE = "elevation_mapping/elevation_mapping/include"
+
+
+def build_motion(reference: Path = Path("/root/reference"), force: bool = False, verbose: bool = False) -> Path | None:
+    """oracle/_ref/libgem_ref_motion.so: the reference's RobotMotionMapUpdater.cpp (and its own header) compiled where they lie,
+    against the stand-ins under motion/ for what is not installed here -- Eigen, kindr, ROS, and the one method of ElevationMap the
+    class touches.  The Jacobians, the F matrix and the covariance products are the reference's text; nothing of it is copied."""
+    src = reference / REL_MOTION
+    if not src.exists():
+        return OUT_MOTION if OUT_MOTION.exists() else None
+    m = HERE / "motion"
+    deps = [src, reference / REL_INCLUDE / "elevation_mapping" / "RobotMotionMapUpdater.hpp", Path(__file__)] + [f for f in m.rglob("*") if f.is_file()]
+    if OUT_MOTION.exists() and not force and all(OUT_MOTION.stat().st_mtime >= d.stat().st_mtime for d in deps):
+        return OUT_MOTION
+    OUT_MOTION.parent.mkdir(exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        tu = Path(tmp) / "gem_ref_motion_tu.cpp"
+        tu.write_text(f'#include "{src}"\n#include "{m / "motion_exports.inc"}"\n')
+        cmd = ["g++", "-O2", "-ffp-contract=off", "-fno-fast-math", "-std=c++14", "-w", "-fPIC", "-shared",
+               f"-I{m}", f"-I{reference / REL_INCLUDE}", str(tu), "-o", str(OUT_MOTION)]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("g++ failed on the reference's RobotMotionMapUpdater.cpp:\n" + res.stderr[-4000:])
+    return OUT_MOTION
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -77,3 +107,5 @@ if __name__ == "__main__":
     a = ap.parse_args()
     p = build(Path(a.reference), a.force, verbose=True)
     print(p if p else "reference not found and no prebuilt library", file=sys.stderr if not p else sys.stdout)
+    p = build_motion(Path(a.reference), a.force, verbose=True)
+    print(p if p else "reference not found and no prebuilt motion library", file=sys.stderr if not p else sys.stdout)

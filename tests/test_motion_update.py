@@ -86,3 +86,30 @@ def test_tan_pitch_jacobian_couples_yaw_variance_into_height(oracle_mod):
     upd = RobotMotionMapUpdater(2.0)
     upd.compute([0, 0, 0], Ry(p), cov)
     assert abs(upd.compute([0, d, 0], Ry(p), cov) - 2.0 * want) <= 4e-7 * abs(want)
+
+
+def test_against_the_references_own_code_over_random_trajectories(oracle_mod):
+    """RobotMotionMapUpdater.cpp itself -- its Jacobians (A.4, A.5), the F matrix (A.8), the relative covariance (A.13) and the
+    projection into the map (RMU.cpp:58-69) are the reference's text, compiled where it lies against stand-ins for Eigen / kindr /
+    ROS (oracle/ref_build/motion) -- against the oracle's restatement AND the product's host implementation: random walks with
+    pitched and rolled robots, full covariances, a rotated map, several covariance scales."""
+    import ref
+    if ref.motion_lib() is None:
+        import pytest
+        pytest.skip("no /root/reference to build from and no prebuilt oracle/_ref/libgem_ref_motion.so")
+    worst = 0.0
+    for seed in range(12):
+        rng = np.random.default_rng(100 + seed)
+        scale = [1.0, 0.5, 2.5, 1.3][seed % 4]
+        theirs, ours, mine = ref.RefMotion(scale), oracle_mod.OracleMotion(scale), RobotMotionMapUpdater(scale)
+        map_R = synth.rot_zyx(rng.normal(0, 0.4), 0.0, 0.0) if seed % 3 == 0 else None
+        pos = np.zeros(3)
+        for k in range(20):
+            pos = pos + rng.normal(0, 0.3, 3)
+            R = synth.rot_zyx(rng.uniform(-3.0, 3.0), rng.normal(0, 0.25), rng.normal(0, 0.25))
+            cov = rand_cov(rng) * (1 + 0.2 * k)
+            t, o, m = theirs.compute(pos, R, cov, map_R), ours.compute(pos, R, cov, map_R), mine.compute(pos, R, cov, map_R)
+            tol = 2e-6 * max(abs(t), 1e-9) + 1e-12      # one float32 ulp: the doubles' summation order differs between the three
+            assert abs(o - t) <= tol and abs(m - t) <= tol, (seed, k, t, o, m)
+            worst = max(worst, abs(o - t) / max(abs(t), 1e-12))
+    assert worst < 2e-6
