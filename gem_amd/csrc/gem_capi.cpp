@@ -90,7 +90,10 @@ struct gem_handle {
     long long overlap_min_points = 1000000;        // tile pipeline: a cross-stream event pair costs 3 us, the second stream only pays for big passes
     long long sort_overlap_min_points = 100000;    // sorted pipeline: its walk is a few long chains on a mostly idle chip; the next pass's sort fits beside it (depth image 120 -> 83 us)
     bool sort_path = true;              // passes of at least sort_min_points points run the sorted pipeline (gem_sort.hip)
-    long long sort_min_points = 200000, sort_min_points_batch = 600000;      // single cloud / batch of sweeps (tools/dbg/crossover.py)
+    // single cloud / batch of sweeps (tools/dbg/crossover.py).  Batches: block-sorted from three LiDAR sweeps on (393 k points: 43 us
+    // against the tile pipeline's 46; four sweeps 43 / 56, two 46 / 35); single clouds: a 131 k-point LiDAR sweep takes 10 us on
+    // the tile pipeline and 35 sorted, a 150 k-point depth image 60 and 38
+    long long sort_min_points = 200000, sort_min_points_batch = 390000;
     bool walk_permute = true;           // k_fuse_walk: blocks take the tile rows centre-first
     int  sort_passes = 0;               // 0 = by map size and form (sort_geometry); 1 / 2 / 3 force it
     bool fast_laser = true;             // frames that qualify use the zero-rotation-variance form of the laser variance (fill_frame; debug knob)

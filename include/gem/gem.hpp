@@ -252,6 +252,9 @@ public:
         return v;
     }
     void synchronize() { check(gem_synchronize(h_), "gem_synchronize"); }
+    // arenas for the largest pass to come (points per call, sweeps per call): no allocation inside the stream of frames afterwards
+    void reserve(long long maxPoints, int maxSweeps = 1, bool withColours = false)
+    { check(gem_reserve(h_, maxPoints, maxSweeps, withColours ? 1 : 0), "gem_reserve"); }
     // device inputs produced on another stream: everything enqueued from now on waits for this hipEvent_t (gem_wait_event)
     void waitEvent(void* hipEvent) { check(gem_wait_event(h_, hipEvent), "gem_wait_event"); }
 

@@ -118,12 +118,12 @@ def test_big_batch_on_two_streams_then_small_passes(oracle_mod):
     for rnd in range(3):
         gpu.add_batch(wl.frames, cat, off, wl.var_updates)                      # 1.3 M points: sorted pipeline, two streams
         gpu.add(wl.frames[0], d[0]); gpu.add(wl.frames[1], d[1])                # single sweeps: k_frame, fusion deferred
-        gpu.add_batch(wl.frames[:3], cat[:off[3]], off[:4], None)               # 393 k points in 3 sweeps: tile pipeline
+        gpu.add_batch(wl.frames[:2], cat[:off[2]], off[:3], None)               # 262 k points in 2 sweeps: tile pipeline
         gpu.add_batch(wl.frames, cat, off, None)                                # sorted again, right behind it
         for k in range(10):
             ref.mapvar_update(wl.var_updates[k]); ref.add(wl.frames[k], wl.clouds[k])
         ref.add(wl.frames[0], wl.clouds[0]); ref.add(wl.frames[1], wl.clouds[1])
-        for k in range(3):
+        for k in range(2):
             ref.add(wl.frames[k], wl.clouds[k])
         for k in range(10):
             ref.add(wl.frames[k], wl.clouds[k])
