@@ -81,7 +81,9 @@ __device__ __forceinline__ void bin_wave_body(const BinArgs& a, int block)
         int row, col; float h, v; bool colour_ok = false;
         if (SRC == 0) {
             const float4 p = a.xyzi[i];
-            const Projected r = project_point(fc, p.x, p.y, p.z, a.orig ? a.orig[i] : (int)(i - sweep_begin) + orig0);
+            // (wave-uniform: a laser frame whose rotation variance is zero takes the short form of the variance, gem_device.hpp)
+            const Projected r = fc.fast_laser ? project_point<kModelLaserFast>(fc, p.x, p.y, p.z, 0)
+                                              : project_point(fc, p.x, p.y, p.z, a.orig ? a.orig[i] : (int)(i - sweep_begin) + orig0);
             row = r.row; col = r.col; h = r.h; v = r.var;
             if (a.rgb) {
                 const uint32_t c = a.rgb[i];

@@ -30,7 +30,7 @@ def main():
         sections.append(cur)
     print(f"# {f}: {len(rows)} dispatches, {len(sections)} sections")
     for si, sec in enumerate(sections):
-        walks = [i for i, r in enumerate(sec) if r[2].startswith("gem::k_fuse_walk") or r[2].startswith("gem::k_fuse_list") or r[2].startswith("gem::k_frame")]
+        walks = [i for i, r in enumerate(sec) if r[2].startswith("gem::k_fuse_walk") or r[2].startswith("gem::k_fuse_block") or r[2].startswith("gem::k_fuse_list") or r[2].startswith("gem::k_frame")]
         if len(walks) < 3:
             continue
         # three passes from the first QUARTER of the section (the steady timed loop; its second half are the instrumented passes,
