@@ -1,32 +1,34 @@
-// gem_sort.hip -- the SORTED pipeline of the GEM hot path for big passes (batches of sweeps, aggregated clouds, depth images).
+// gem_sort.hip -- the SORTED pipelines of the GEM hot path for big passes (batches of sweeps, aggregated clouds, depth images).
 //
 // G_fuse (gpu_process.cu:477-537) is one thread per CELL scanning all points in input order; the recurrence is not
 // associative (variance floor inside the loop, Mahalanobis branch), so what every cell needs is ITS points, in input order.
 // For a stream of single LiDAR sweeps that list is short and k_frame (gem_kernels.hip) builds it per tile in LDS.  For a big
 // pass -- millions of points, tens of sweeps -- the lists are long, the tile under the sensor carries a hundred times the
 // records of a tile at the rim, and any per-tile batching is bound by that one tile.  Here the lists are built by the whole
-// chip instead: a stable two-digit LSD counting sort of the in-map points by (tile, cell-in-tile), every pass split into
-// equal chunks, and then every cell walks its own contiguous run:
+// chip instead: a stable LSD counting sort of the in-map points, every pass split into equal 4096-record chunks, in two forms
+// (gem_kernels.hpp; gem_capi.cpp picks one per pass, both give the same map):
 //
-//   k_sort_project  chunk of 8192 points: project + bin (G_pointsprocess, GPU:384-455) ONCE; {h, var} and the key
-//                   {cell | tile | sweep} of every point stored in input order (rejected points: key = ~0), histogram over
-//                   the LOW digit of the key in LDS                                         -> cntA[chunk][bins0]
-//   k_sort_scan     column-wise exclusive prefix over the chunks, column totals             -> cntA (in place), totA, M
-//   k_sort_scatter  the same chunk again, records only: STABLE rank inside the chunk (wave w owns the w-th contiguous
-//                   share, 64 consecutive records per step, equal bins matched by ballots, a per-wave cursor per bin
-//                   in LDS), every record written to its final place of the pass
-//   k_sort_count / k_sort_scan / k_sort_scatter   the same over the HIGH digit on the records of pass 1
-//   k_fuse_walk     one WAVE per 64 consecutive cells (two rows of a 32x32 tile): a 32-ary search finds the wave's share of
-//                   the sorted records, one look at its keys gives the cell boundaries, then every lane streams its own
-//                   cell's run through the reference's recurrence (GPU:480-531), the variance increments of the sweeps in
-//                   between (GPU:540-547) and the floors (GPU:533-534) replayed per cell.
-// The key's cell id (tile << 10 | cell in tile) is split into two digits of about equal width, so that both passes have a few
-// hundred to a few thousand bins whatever the map size (600^2: 512 x 722; 2400^2: 2048 x 2813).
+//   k_sort_project  chunk of 4096 points, four waves of 1024: project + bin (G_pointsprocess, GPU:384-455) ONCE; {h, var} and the
+//                   key {id | sweep} of every point that stays, stored in input order, compacted per wave; histogram over the
+//                   first digit in LDS                                                        -> cnt[chunk][bins0]
+//   k_sort_scan     column-wise exclusive prefix over the chunks (four segments), segment sums -> cnt (in place), segtot, M
+//   k_sort_scatter  the same chunk again, records only: STABLE rank inside the chunk (wave w owns the w-th contiguous share,
+//                   64 consecutive records per step; equal bins matched through the LDS or by ballot, a per-wave cursor per
+//                   bin in LDS), the chunk staged in LDS in sorted order and written out from there
+//   k_sort_count / k_sort_scan / k_sort_scatter   the same over the next digit on the records of the pass before
 //
-// Stability of both passes keeps ascending input order inside every cell; no float atomics, no LDS batches, no fast / generic /
-// dense cases: a wave takes the time of its LONGEST cell chain, and the waves of the tile under the sensor spread over the chip.
-// Algorithmic bytes: 16 B per point (read) + 16 B per distinct touched cell (+ 8 L^2 per dense variance pass).  What the
-// sort moves on top of that is stated in DESIGN.md section 4.
+//   CELL-sorted:  digits over the whole id (tile << 10 | cell in tile), two passes (three beyond 2^20 cells);
+//     k_fuse_walk   256 consecutive cells per workgroup: a 32-ary search finds their share of the sorted records, one look at
+//                   its keys gives the cell boundaries, then every lane streams its own cell's run through the reference's
+//                   recurrence (GPU:480-531), the sweeps' variance increments (GPU:540-547) and floors (GPU:533-534) replayed
+//                   per cell in between.
+//   BLOCK-sorted: digits over the block id (id >> 8: eight rows of a tile) only -- ONE pass for maps of up to 2048 blocks;
+//     k_fuse_block  one workgroup per block: the block's records, in input order, a batch at a time: ordered by cell in LDS
+//                   (stable), then every thread runs its cell's records of the batch from LDS; the cell state stays in registers.
+//
+// Stability of every pass keeps ascending input order inside every cell; no float atomics.  A wave takes the time of its LONGEST
+// cell chain.  Algorithmic bytes: 16 B per point (read) + 16 B per distinct touched cell (+ 8 L^2 per dense variance pass).  What
+// the sort moves on top of that is stated in DESIGN.md section 4.
 //
 // Built with -ffp-contract=off (see gem_device.hpp).
 #include "gem_kernels.hpp"
