@@ -97,6 +97,7 @@ struct gem_handle {
     bool walk_permute = true;           // k_fuse_walk: blocks take the tile rows centre-first
     int  sort_passes = 0;               // 0 = by map size and form (sort_geometry); 1 / 2 / 3 force it
     bool fast_laser = true;             // frames that qualify use the zero-rotation-variance form of the laser variance (fill_frame; debug knob)
+    bool rank_by_ballot = false;        // k_sort_scatter ranks by ballot in every pass (debug knob)
     bool lane_sort = true;              // k_fuse_block: cells to threads by record count (debug knob)
     int  sort_form = 0;                 // 0 = batches of sweeps BLOCK-sorted (k_fuse_block), single clouds CELL-sorted (k_fuse_walk); 1 / 2 force cell / block
     int dbg_sweep = 0;                  // debug stamps of the dense path: which sweep (GEM_DBG_SWEEP)
@@ -543,6 +544,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     sa.f_index = in.f_index; sa.f_height = in.f_height; sa.f_var = in.f_var;
     sa.f_R = in.f_R; sa.f_G = in.f_G; sa.f_B = in.f_B; sa.f_I = in.f_I;
     sa.keep_sentinel = h->track_lowest ? 1 : 0;
+    sa.rank_by_ballot = h->rank_by_ballot ? 1 : 0;
     sa.tiles_per_row = geo.tiles_per_row; sa.T = T;
     sa.id_bits = geo.id_bits; sa.n_passes = geo.n_passes;
     for (int i = 0; i < 3; ++i) { sa.dshift[i] = geo.dshift[i]; sa.dbits[i] = geo.dbits[i]; sa.dbins[i] = geo.dbins[i]; }
@@ -1704,6 +1706,7 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "sort_ring")          { if (value < 2 || value > 4) return fail(h, GEM_ERR_INVALID, "sort_ring: 2..4"); h->sort_ring = (int)value; }
     else if (k == "sort_streams")       { if (value != 1 && value != 2) return fail(h, GEM_ERR_INVALID, "sort_streams: 1 or 2"); h->sort_streams = (int)value; }
     else if (k == "sort_passes")        { if (value < 0 || value > 3) return fail(h, GEM_ERR_INVALID, "sort_passes: 0..3"); h->sort_passes = (int)value; }
+    else if (k == "rank_by_ballot")     h->rank_by_ballot = value != 0;
     else if (k == "lane_sort")          h->lane_sort = value != 0;
     else if (k == "fast_laser")         h->fast_laser = value != 0;
     else if (k == "sort_form")          { if (value < 0 || value > 2) return fail(h, GEM_ERR_INVALID, "sort_form: 0 (by pass), 1 (cell-sorted), 2 (block-sorted)"); h->sort_form = (int)value; }

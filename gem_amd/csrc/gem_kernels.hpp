@@ -113,6 +113,8 @@ struct SortArgs {
     const int* f_index; const float* f_height; const float* f_var;                    // SRC 1: Fuse()'s arrays (GPU:1154)
     const int* f_R; const int* f_G; const int* f_B; const float* f_I;
     int keep_sentinel;                 // keep records with h == -1 (GPU:482) for the LOWEST walk
+    int rank_by_ballot;                // k_sort_scatter matches equal bins by ballot in every pass (what coarse digits take anyway; debug knob:
+                                       // the two ways of ranking -- through the LDS and by ballot -- are checked against each other by the tests)
     CameraConst cam;                   // SRC 3 (input colourisation): id = the pixel a point samples, record = {point index, 0}
     int tiles_per_row, T;              // 32x32-cell tiles
     int id_bits;

@@ -1285,7 +1285,7 @@ hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, co
     p.seg_cnt = a.seg_cnt;
     const bool last0 = a.n_passes == 1;
     p.bin_base = last0 ? a.bin_base : nullptr; p.counters = last0 ? a.counters : nullptr;
-    const bool coherent = a.dshift[0] >= 8;                          // block-sorted form: coarse digits, few bins per wave instruction
+    const bool coherent = a.dshift[0] >= 8 || a.rank_by_ballot;                          // block-sorted form: coarse digits, few bins per wave instruction
     if ((e = launch_pass(st, sh[0], p, attr, coherent, a.n_chunks1, false, ev[2])) != hipSuccess) return e;
     // ---- the higher digits: count, scan, scatter on the records of the pass before (ping-pong between the arrays); the
     //      live chunks are known on the device only

@@ -18,7 +18,8 @@ extern "C" {
  *       second stream), "overlap_min_points", "sort_path" (0/1: the sorted pipeline for big passes), "sort_min_points",
  *       "sort_passes" (0 = by map size and form, 1..3: counting-sort passes), "sort_form" (0 = by pass: batches of sweeps block-sorted
  *       (k_fuse_block), single clouds cell-sorted (k_fuse_walk); 1 / 2 force cell / block), "fast_laser" (0/1: the
- *       zero-rotation-variance form of the laser variance for frames that qualify), "lane_sort" (0/1: k_fuse_block hands the
+ *       zero-rotation-variance form of the laser variance for frames that qualify), "rank_by_ballot" (0/1: k_sort_scatter matches equal bins by ballot in every pass instead
+ *       of through the LDS), "lane_sort" (0/1: k_fuse_block hands the
  *       cells to the threads by record count), "walk_permute" (0/1),
  *       "sort_streams" (1, 2: binning streams consecutive overlapped passes of the sorted pipeline alternate between), "sort_ring" (2..4: the buffer sets they rotate through),
  *       "trace" (0/1: one line on stderr per pass of the sorted pipeline), "stream_roles" (a permutation of 0123 as a decimal
