@@ -366,6 +366,27 @@ static hipError_t acquire_streams(int device, StreamSet& out)
     return hipSuccess;
 }
 
+// the communication stream of a handle that joined a communicator (gem_comm_init*): pooled like the others, never destroyed
+static std::vector<hipStream_t> g_comm_pool[64];
+
+static hipError_t acquire_comm_stream(int device, hipStream_t* out)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+        if (device >= 0 && device < 64 && !g_comm_pool[device].empty()) { *out = g_comm_pool[device].back(); g_comm_pool[device].pop_back(); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+static void release_comm_stream(int device, hipStream_t st)
+{
+    if (!st) return;
+    hipStreamSynchronize(st);
+    if (device < 0 || device >= 64) { hipStreamDestroy(st); return; }
+    std::lock_guard<std::mutex> lk(g_stream_pool_mu);
+    g_comm_pool[device].push_back(st);
+}
+
 static void release_streams(int device, const StreamSet& set)
 {
     if (!set.s[0]) return;
@@ -985,7 +1006,7 @@ void gem_destroy(gem_handle* h)
     if (h->tab_stream) hipStreamSynchronize(h->tab_stream);
     if (h->comm_stream) hipStreamSynchronize(h->comm_stream);
     if (h->comm) ncclCommDestroy(h->comm);
-    if (h->comm_stream) hipStreamDestroy(h->comm_stream);
+    release_comm_stream(h->device, h->comm_stream);
     for (hipEvent_t e : {h->ev_sorted, h->ev_exchanged, h->ev_walked, h->ev_published, h->ev_gathered}) if (e) hipEventDestroy(e);
     fold_events(h);
     for (auto& ep : h->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
@@ -1765,7 +1786,7 @@ static int comm_init_common(gem_handle* h, const void* unique_id_128_bytes, int 
     if (r != ncclSuccess) { h->comm = nullptr; return fail(h, GEM_ERR_COMM, ncclGetErrorString(r)); }
     h->nranks = nranks; h->rank = rank; h->tile_strips = tile_strips;
     if (!h->comm_stream) {
-        GEM_HIP(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+        GEM_HIP(h, acquire_comm_stream(h->device, &h->comm_stream));
         for (hipEvent_t* e : {&h->ev_sorted, &h->ev_exchanged, &h->ev_walked, &h->ev_published, &h->ev_gathered})
             GEM_HIP(h, hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
