@@ -230,6 +230,10 @@ __device__ __forceinline__ Projected project_point(const FrameConst& f, float x,
 // correctly-rounded divisions, so all three are issued together and the reference's three-way
 // branch becomes a select.  Every value that is kept is computed by exactly the reference's
 // expression (GPU:502, 518, 519); discarded lanes may hold inf / NaN, which is harmless.
+// SHARED_RCP: the two Kalman quotients from one refined reciprocal (below).  Measured per kernel: k_fuse_block's one-step loop
+// gains (C4: 99.5 -> 95.8 us per batch), k_fuse_walk's four-step groups lose (C3: 85 -> 91 us: the guard and its branch cost more
+// than the divisions' slow instructions there), k_frame's straight-line chains are even -- so only k_fuse_block asks for it.
+template <bool SHARED_RCP = false>
 __device__ __forceinline__ bool fuse_step(float& e, float& s, float h, float v, float mahal_thr, float var_floor)
 {
     const bool empty = e == kEmptyElevation;                                       // GPU:484
@@ -244,8 +248,32 @@ __device__ __forceinline__ bool fuse_step(float& e, float& s, float h, float v, 
     if (__builtin_expect(fabsf(m - mahal_thr) <= 1e-5f * fabsf(mahal_thr) || !(sf >= 1e-30f), 0))
         m = d / sqrtf(sf);                                                         // a float, not a flag, leaves the rare branch
     const bool outlier = m > mahal_thr;
-    const float en = (sf * h + v * e) / (sf + v);                                  // GPU:518
-    const float sn = (v * sf) / (v + sf);                                          // GPU:519
+    // GPU:518, 519: two IEEE divisions by the same denominator D = sf + v.  hipcc expands each into v_div_scale x 2, v_rcp, one
+    // Newton step on the reciprocal, the quotient, two residual corrections (the last a v_div_fmas) and v_div_fixup -- eleven
+    // instructions, five of them quarter-rate, the longest part of the recurrence's step.  When D and both numerators lie well
+    // inside the exponent range (here: within 2^-60 .. 2^60; v_div_scale only rescales operands near its ends, v_div_fixup only
+    // touches zeros, infinities, NaNs and denormals) the scale factors are 1, v_div_fmas is a plain fma and the fix-up passes
+    // the quotient through: the SAME operations on the same values -- the same bits -- are one shared refined reciprocal and,
+    // per quotient, a multiplication and four fmas.  Anything else (a zero or denormal numerator, NaNs, huge values: decided for
+    // the whole wave) takes the division as written.  Every exactness test of the suite runs through this.
+    const float D = sf + v, N1 = sf * h + v * e, N2 = v * sf;
+    float en, sn;
+    if constexpr (!SHARED_RCP) {
+        en = N1 / D;
+        sn = N2 / (v + sf);
+    } else {
+        const uint32_t xd = (__float_as_uint(D) >> 23) & 0xffu, x1 = (__float_as_uint(N1) >> 23) & 0xffu, x2 = (__float_as_uint(N2) >> 23) & 0xffu;
+        const bool plain = min(xd, min(x1, x2)) >= 67u && max(xd, max(x1, x2)) <= 187u && D > 0.0f;
+        if (__builtin_expect(__ballot(!plain) == 0, 1)) {               // wave-uniform
+            const float r0 = __builtin_amdgcn_rcpf(D);
+            const float r = __builtin_fmaf(__builtin_fmaf(-D, r0, 1.0f), r0, r0);
+            float q = N1 * r;  float t = __builtin_fmaf(-D, q, N1);  q = __builtin_fmaf(t, r, q);  t = __builtin_fmaf(-D, q, N1);  en = __builtin_fmaf(t, r, q);
+            q = N2 * r;        t = __builtin_fmaf(-D, q, N2);        q = __builtin_fmaf(t, r, q);  t = __builtin_fmaf(-D, q, N2);  sn = __builtin_fmaf(t, r, q);
+        } else {
+            en = N1 / D;
+            sn = N2 / (v + sf);
+        }
+    }
     // (bitwise, not short-circuit: `||` / `&&` become selects between i1 values, which this compiler carries through VGPRs --
     //  five instructions per record; `|` / `&` stay operations on the wave's lane masks)
     const bool replace = empty | (outlier & (e < h));                              // GPU:484-486, 505-507

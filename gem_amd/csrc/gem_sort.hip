@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
             if constexpr (HAS_VU) rp.advance(cs, live ? sw : rp.cur, vu, a.var_floor);
             if constexpr (COUNT_SWEEPS) { if (live && sw != last_sweep) { ++sweeps_seen; last_sweep = sw; } }
             float e2 = ce, s2 = cs;
-            const bool taken = fuse_step(e2, s2, h, v, a.mahal, a.var_floor);
+            const bool taken = fuse_step<true>(e2, s2, h, v, a.mahal, a.var_floor);
             const bool fl = live && (!LOWEST || h != -1.0f);           // GPU:482 (only LOWEST passes carry such records)
             ce = fl ? e2 : ce; cs = fl ? s2 : cs;
             if constexpr (LOWEST) { const float l2 = lowest_step(lw, h, v); lw = live ? l2 : lw; }
