@@ -24,6 +24,7 @@ HEADERS = [CSRC / "gem_device.hpp", CSRC / "gem_kernels.hpp", CSRC / "gem_wave.h
 FLAGS = [
     "--offload-arch=gfx950", "-O3", *(["-g"] if os.environ.get("GEM_DEBUG_BUILD") else []), "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
     "-Wno-unused-value",
+    *os.environ.get("GEM_BUILD_DEFINES", "").split(),          # build-time experiments (A/B builds on the GPU box), e.g. -DGEM_X=1
 ]
 
 
