@@ -224,6 +224,36 @@ __device__ __forceinline__ Projected project_point(const FrameConst& f, float x,
     return r;
 }
 
+// project_point<kModelLaserFast> + the binning as STRAIGHT-LINE code: the same expressions, every decision a select (the branchy form
+// spends a third of its issue slots on exec-mask bookkeeping; computing the variance of a rejected point costs less).  Returns
+// "accepted, inside the map, inside this device's strip, not the h == -1 sentinel (GPU:482) unless those are kept".
+__device__ __forceinline__ bool project_bin_laser_fast(const FrameConst& fc, float x, float y, float z, bool in_range, bool keep_sentinel,
+                                                       int& row, int& col, float& h_out, float& var_out)
+{
+    const float h = fc.T[8] * x + fc.T[9] * y + fc.T[10] * z + fc.T[11];           // GPU:389
+    bool acc = in_range && h > fc.lower_f && h < fc.upper_f;                        // GPU:397 (doubles there: see FrameConst)
+    if (fc.filter_on)                                                              // GPU:393 (frame-uniform)
+        acc = acc && !((x > -fc.fbx && x < fc.fbx && y > -fc.fby && y < fc.fby) || (y > -fc.fband && y < fc.fband) || (y > fc.fplane));
+    const float xt = fc.T[0] * x + fc.T[1] * y + fc.T[2] * z + fc.T[3];            // GPU:399
+    const float yt = fc.T[4] * x + fc.T[5] * y + fc.T[6] * z + fc.T[7];            // GPU:400
+    var_out = height_variance<kModelLaserFast>(fc, x, y, z, 0);
+    h_out = h;
+    const float shx = xt - fc.cx, shy = yt - fc.cy;
+    int ix, iy;
+    if ((fc.L & 1) == 0) {                                                         // GPU:340-348, even L (map-uniform)
+        const float vx = (float)(fc.L / 2) - shx / fc.res, vy = (float)(fc.L / 2) - shy / fc.res;
+        const bool okx = vx > -2147483648.0f && vx < 2147483648.0f, oky = vy > -2147483648.0f && vy < 2147483648.0f;
+        ix = okx ? (int)(okx ? vx : 0.0f) : -1;                                    // truncation toward zero; non-finite / unrepresentable -> outside
+        iy = oky ? (int)(oky ? vy : 0.0f) : -1;
+    } else {
+        ix = axis_index(fc.L, fc.res, shx); iy = axis_index(fc.L, fc.res, shy);
+    }
+    const bool inside = ix >= 0 && ix < fc.L && iy >= 0 && iy < fc.L;
+    const int stx = ix + fc.sx, sty = iy + fc.sy;
+    row = stx >= fc.L ? stx - fc.L : stx; col = sty >= fc.L ? sty - fc.L : sty;    // (% L: one conditional subtraction)
+    return acc && inside && row >= fc.row0 && row < fc.row1 && (h != -1.0f || keep_sentinel);
+}
+
 // The per-cell recurrence of G_fuse (GPU:484-529) on register state (e, s).  Returns true when the
 // point was "taken" (colour / intensity of this point may overwrite the cell's, GPU:487-494 etc.).
 // Straight-line form: the Mahalanobis quotient and the two Kalman quotients are independent

@@ -77,7 +77,16 @@ __device__ __forceinline__ void bin_wave_body(const BinArgs& a, int block)
 
     bool valid = false;
     uint32_t tile = 0, cl = 0, src = 0; float hh = 0.0f, vv = 0.0f;
-    if (i < sweep_end) {
+    if (SRC == 0 && fc.fast_laser && !a.rgb) {
+        // (wave-uniform) a laser frame whose rotation variance is zero, no colours: projection + binning as straight-line code
+        const float4 p = a.xyzi[i < sweep_end ? i : sweep_begin];
+        int row, col;
+        valid = project_bin_laser_fast(fc, p.x, p.y, p.z, i < sweep_end, a.keep_sentinel != 0, row, col, hh, vv);
+        tile = (uint32_t)((row >> TS) * a.tiles_per_row + (col >> TS));
+        cl = (uint32_t)(((row & (TE - 1)) << TS) | (col & (TE - 1)));
+        src = (uint32_t)i;
+        if (!valid) { tile = 0; cl = 0; }
+    } else if (i < sweep_end) {
         int row, col; float h, v; bool colour_ok = false;
         if (SRC == 0) {
             const float4 p = a.xyzi[i];

@@ -90,39 +90,17 @@ __device__ __forceinline__ Binned bin_one(const SortArgs& a, const FrameConst& f
     return b;
 }
 
-// SRC 4 (every frame the laser model with zero rotation variance) as STRAIGHT-LINE code: the same expressions as project_point /
-// map_row_col / bin_one, every decision a select.  The branchy form spends a third of k_sort_project's issue slots on exec-mask
-// bookkeeping (per point 17 s_and_saveexec, 25 s_or, 23 v_mov carrying values round the branches: 3.75 M SALU next to 9.8 M VALU
-// instructions per C4 batch); computing the variance of the three points in ten that are rejected anyway costs less.
+// SRC 4 (every frame the laser model with zero rotation variance): straight-line projection + binning (gem_device.hpp).  The
+// branchy form spent per point 17 s_and_saveexec, 25 s_or and 23 v_mov on carrying values round its branches: 3.75 M SALU next to
+// 9.8 M VALU instructions per C4 batch; this one takes C4 from 104.0 to 98.2 us per batch on the same box.
 __device__ __forceinline__ Binned bin_one_laser_fast(const SortArgs& a, const FrameConst& fc, const float4& p, bool in_range)
 {
     Binned b;
-    const float x = p.x, y = p.y, z = p.z;
-    const float h = fc.T[8] * x + fc.T[9] * y + fc.T[10] * z + fc.T[11];           // GPU:389
-    bool acc = in_range && h > fc.lower_f && h < fc.upper_f;                        // GPU:397 (doubles there: see FrameConst)
-    if (fc.filter_on)                                                              // GPU:393 (frame-uniform)
-        acc = acc && !((x > -fc.fbx && x < fc.fbx && y > -fc.fby && y < fc.fby) || (y > -fc.fband && y < fc.fband) || (y > fc.fplane));
-    const float xt = fc.T[0] * x + fc.T[1] * y + fc.T[2] * z + fc.T[3];            // GPU:399
-    const float yt = fc.T[4] * x + fc.T[5] * y + fc.T[6] * z + fc.T[7];            // GPU:400
-    const float var = height_variance<kModelLaserFast>(fc, x, y, z, 0);
-    const float shx = xt - fc.cx, shy = yt - fc.cy;
-    int ix, iy;
-    if ((fc.L & 1) == 0) {                                                         // GPU:340-348, even L (map-uniform)
-        const float vx = (float)(fc.L / 2) - shx / fc.res, vy = (float)(fc.L / 2) - shy / fc.res;
-        const bool okx = vx > -2147483648.0f && vx < 2147483648.0f, oky = vy > -2147483648.0f && vy < 2147483648.0f;
-        ix = okx ? (int)(okx ? vx : 0.0f) : -1;                                    // truncation toward zero; non-finite / unrepresentable -> outside
-        iy = oky ? (int)(oky ? vy : 0.0f) : -1;
-    } else {
-        ix = axis_index(fc.L, fc.res, shx); iy = axis_index(fc.L, fc.res, shy);
-    }
-    const bool inside = ix >= 0 && ix < fc.L && iy >= 0 && iy < fc.L;
-    const int stx = ix + fc.sx, sty = iy + fc.sy;
-    const int row = stx >= fc.L ? stx - fc.L : stx, col = sty >= fc.L ? sty - fc.L : sty;   // (% L: one conditional subtraction)
-    // GPU:482: a height of exactly -1 is the reference's "rejected" sentinel (kept when the lowest scan points are tracked)
-    b.valid = acc && inside && row >= fc.row0 && row < fc.row1 && (h != -1.0f || a.keep_sentinel);
+    int row, col;
+    b.valid = project_bin_laser_fast(fc, p.x, p.y, p.z, in_range, a.keep_sentinel != 0, row, col, b.h, b.v);
     const uint32_t tile = (uint32_t)((row >> 5) * a.tiles_per_row + (col >> 5));
     b.id = (tile << 10) | (uint32_t)(((row & 31) << 5) | (col & 31));
-    b.h = h; b.v = var; b.colour_ok = false;                                       // (colours: the kernel looks the point's up)
+    b.colour_ok = false;                                                           // (colours: the kernel looks the point's up)
     return b;
 }
 
