@@ -96,6 +96,7 @@ struct gem_handle {
     long long sort_min_points = 200000, sort_min_points_batch = 390000;
     bool walk_permute = true;           // k_fuse_walk: blocks take the tile rows centre-first
     int  sort_passes = 0;               // 0 = by map size and form (sort_geometry); 1 / 2 / 3 force it
+    int ray_depth = 4, ray_lanes = 16;  // k_raytracing: loads in flight per lane, lanes per ray (debug knobs; 16 x 4 measured best on C2)
     bool fast_laser = true;             // frames that qualify use the zero-rotation-variance form of the laser variance (fill_frame; debug knob)
     bool rank_by_ballot = false;        // k_sort_scatter ranks by ballot in every pass (debug knob)
     bool lane_sort = true;              // k_fuse_block: cells to threads by record count (debug knob)
@@ -1649,7 +1650,7 @@ int gem_raytracing(gem_handle* h)
     }
     uint32_t* list = static_cast<uint32_t*>(h->ray.p);
     GEM_HIP(h, launch_raytracing(h->stream, h->layers, h->L, h->start[0], h->start[1], h->sensor_z, h->cfg.obstacle_threshold,
-                                 h->row0, h->row1, list, list + h->cells));
+                                 h->row0, h->row1, list, list + h->cells, h->ray_depth, h->ray_lanes));
     return GEM_OK;
 }
 
@@ -1729,6 +1730,8 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "sort_passes")        { if (value < 0 || value > 3) return fail(h, GEM_ERR_INVALID, "sort_passes: 0..3"); h->sort_passes = (int)value; }
     else if (k == "rank_by_ballot")     h->rank_by_ballot = value != 0;
     else if (k == "lane_sort")          h->lane_sort = value != 0;
+    else if (k == "ray_depth")          h->ray_depth = (int)value;
+    else if (k == "ray_lanes")          h->ray_lanes = (int)value;
     else if (k == "fast_laser")         h->fast_laser = value != 0;
     else if (k == "sort_form")          { if (value < 0 || value > 2) return fail(h, GEM_ERR_INVALID, "sort_form: 0 (by pass), 1 (cell-sorted), 2 (block-sorted)"); h->sort_form = (int)value; }
     else return fail(h, GEM_ERR_INVALID, "gem_debug_set: unknown key");

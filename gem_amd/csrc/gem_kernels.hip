@@ -1458,14 +1458,14 @@ hipError_t launch_frame(hipStream_t st, const FuseArgs& fa, const BinArgs& ba, i
 }
 
 // ------------------------------------------------------------------------------------------
-// k_raytracing : the visibility clean-up, G_Raytracing (GPU:708-891; helpers GPU:672-706).  One thread per cell.
+// k_raytracing : the visibility clean-up, G_Raytracing (GPU:708-891; helpers GPU:672-706).
 // A cell that holds an elevation and whose traversability is below the obstacle threshold walks AWAY from the map centre
 // along the centre->cell ray (a DDA over cell borders); every crossed cell with a lowest scan point this frame bounds the
 // obstacle's height by the line of sight from the sensor over that point; if elevation - 3 sigma is above the tightest
 // bound the cell is deleted.  Quirks kept: map_lowest in GEOGRAPHIC cell order, the
 // int robot_index, centre row / column cells never deleted, x-only abscissae, "no scan point" == 10.
 // A thread writes only its own cell's elevation and reads only its own cell's elevation / variance: no ordering issue.
-// The walks diverge (up to L steps); at 600 x 600 the kernel is a few tens of microseconds, once per frame.
+// The walks are long (up to ~2 L steps) and few (the obstacle cells): each is split over G lanes (k_raytracing, below).
 // ------------------------------------------------------------------------------------------
 // The DDA divides by the same two direction components at every step (GPU:831-832 and twins).  hipcc expands an IEEE float division
 // into v_div_scale x 2, v_rcp, two Newton steps on the reciprocal, the quotient, two residual corrections (the last one
@@ -1515,67 +1515,114 @@ __global__ __launch_bounds__(256) void k_ray_list(LayerPtrs m, int L, int start0
     if (walks) list[base + (uint32_t)__popcll(mk & lanemask_lt())] = (uint32_t)i;
 }
 
+// One ray is walked by G adjacent lanes, each a run of S crossings of the ray's MAJOR axis (the one with the larger |increment|):
+// a wave lasts as long as its longest lane, the walkers fill a third of the chip's SIMDs with one wave each, and a 600-cell walk at
+// ~30 instructions a step was the whole 30 us of this kernel.  A lane can start in the middle of a walk because the walk is a merge
+// of two increasing sequences, the border distances dn_x(k) = (k + 1/2) inc_x / dir_x and dn_y(k) likewise (the bounds are
+// half-integers, exact in float; the quotients are correctly rounded, so increasing, and a whole cell apart): after the step
+// that makes the K-th major crossing the walk has made every minor crossing with dn_m(j) <= dn_M(K - 1) (equal distances step
+// together, GPU:855), stands in cell (ob_M + K inc_M, ob_m + k_m inc_m) and remembers `later` = dn_M(K - 1).  k_m is found from an
+// estimate corrected by evaluating dn_m itself, the very expression the walk compares.  Lane g walks from that state until its
+// major index reaches (g + 1) S or the walk leaves the map; the lanes' bounds are folded by a minimum (the order is irrelevant).
+template <int RD, int G>
 __global__ __launch_bounds__(256) void k_raytracing(LayerPtrs m, int L, int start0, int start1, float sensor_z,
                                                    const uint32_t* __restrict__ list, const uint32_t* __restrict__ count)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= *count) return;
-    const int i = (int)list[t];
-    const int cell_x = i / L, cell_y = i - cell_x * L;
-    const float obstacle_ele = m.elevation[i];
-    int ob0 = cell_x + L - start0; ob0 -= ob0 >= L ? L : 0;                                      // GPU:672-675 (% L)
-    int ob1 = cell_y + L - start1; ob1 -= ob1 >= L ? L : 0;
+    static_assert(G >= 1 && G <= 64 && (G & (G - 1)) == 0, "lanes per ray: a power of two inside a wave");
+    const uint32_t n_rays = *count;
     const int robot_index = ray_robot_index(L);
-    const float inc0 = (float)(ob0 - robot_index), inc1 = (float)(ob1 - robot_index);
-    const int inc_x = inc0 > 0 ? 1 : -1, inc_y = inc1 > 0 ? 1 : -1;                              // (neither is 0: k_ray_list)
-    const float dis = sqrtf(inc0 * inc0 + inc1 * inc1);                                          // GPU:793
-    const float dir0 = inc0 / dis, dir1 = inc1 / dis;
-    float threshold;                                                                             // GPU:798-802, double arithmetic
-    if (fabsf(inc0) > fabsf(inc1)) { const double t = 0.5 / (double)inc0 * (double)inc1; threshold = (float)sqrt(0.5 * 0.5 + t * t); }
-    else                           { const double t = 0.5 / (double)inc1 * (double)inc0; threshold = (float)sqrt(0.5 * 0.5 + t * t); }
-    float bound_x = (float)inc_x / 2, bound_y = (float)inc_y / 2;                               // GPU:808-809
-    const float rcp0 = refined_rcp(dir0), rcp1 = refined_rcp(dir1);
-    float dir_num_x = div_by(bound_x, dir0, rcp0), dir_num_y = div_by(bound_y, dir1, rcp1), later = 0.0f;
-    float restrict_ele = obstacle_ele;
     const float robot_f = (float)robot_index;
-    int c0 = ob0, c1 = ob1;
-    // GPU:819-880.  The reference's three branches (step in y / step in x / step in both when the two border distances tie)
-    // are one straight-line body here: the crossed-cell test uses the smaller distance (dir_num_x when they tie, as in the
-    // reference's last branch), and each axis advances under a select.  Every value is computed by the reference's own
-    // expression (the two divisions per step through div_by, above); lanes of a wave do not serialise over the three variants.
-    // The walk itself (c0, c1, the border distances) never depends on what it reads: the lowest scan point of a crossed cell only
-    // lowers `restrict_ele`, a running minimum.  A load waited for in every step made the loop a chain of memory latencies
-    // (~70 us for the 600^2 map); here the walk runs four steps ahead -- four loads in flight, addresses clamped instead of
-    // branched round -- and the bounds are folded in afterwards (a minimum: any order).
-    constexpr int RD = 4;
-    bool inside = c0 >= 0 && c0 < L && c1 >= 0 && c1 < L;
-    while (__ballot(inside) != 0) {                                   // wave-uniform; lanes that left the map idle
-        float low[RD]; int hc0[RD]; bool hit[RD];
-#pragma unroll
-        for (int u = 0; u < RD; ++u) {
-            const bool step_y = dir_num_x > dir_num_y;                 // GPU:821
-            const bool step_x = dir_num_x < dir_num_y;                 // GPU:838; neither: both axes (GPU:855)
-            const float step = step_y ? dir_num_y : dir_num_x;
-            hit[u] = inside && step - later > threshold && c0 != ob0 && c1 != ob1;       // GPU:823-830 and twins
-            hc0[u] = c0;
-            low[u] = m.lowest[hit[u] ? (size_t)c0 * L + c1 : (size_t)0];
-            later = inside ? step : later;
-            const float nbx = bound_x + (float)inc_x, nby = bound_y + (float)inc_y;
-            const float ndx = div_by(nbx, dir0, rcp0), ndy = div_by(nby, dir1, rcp1);
-            if (inside && !step_y) { c0 += inc_x; bound_x = nbx; dir_num_x = ndx; }
-            if (inside && !step_x) { c1 += inc_y; bound_y = nby; dir_num_y = ndy; }
-            inside = inside && c0 >= 0 && c0 < L && c1 >= 0 && c1 < L;
-        }
-#pragma unroll
-        for (int u = 0; u < RD; ++u) {
-            if (hit[u] && low[u] != 10.0f) {                           // GPU:681-689
-                const float x1 = (float)(hc0[u] - ob0), x2 = (float)hc0[u] - robot_f;            // GPU:691-706
-                const float e = low[u] + (sensor_z - low[u]) / x2 * x1;
-                if (e < restrict_ele) restrict_ele = e;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t / G < n_rays; t += gridDim.x * blockDim.x) {   // a ray's G lanes stay together
+        const int g = (int)(t % G);
+        const int i = (int)list[t / G];
+        const int cell_x = i / L, cell_y = i - cell_x * L;
+        const float obstacle_ele = m.elevation[i];
+        int ob0 = cell_x + L - start0; ob0 -= ob0 >= L ? L : 0;                                      // GPU:672-675 (% L)
+        int ob1 = cell_y + L - start1; ob1 -= ob1 >= L ? L : 0;
+        const float inc0 = (float)(ob0 - robot_index), inc1 = (float)(ob1 - robot_index);
+        const int inc_x = inc0 > 0 ? 1 : -1, inc_y = inc1 > 0 ? 1 : -1;                              // (neither is 0: k_ray_list)
+        const float dis = sqrtf(inc0 * inc0 + inc1 * inc1);                                          // GPU:793
+        const float dir0 = inc0 / dis, dir1 = inc1 / dis;
+        float threshold;                                                                             // GPU:798-802, double arithmetic
+        if (fabsf(inc0) > fabsf(inc1)) { const double q = 0.5 / (double)inc0 * (double)inc1; threshold = (float)sqrt(0.5 * 0.5 + q * q); }
+        else                           { const double q = 0.5 / (double)inc1 * (double)inc0; threshold = (float)sqrt(0.5 * 0.5 + q * q); }
+        float bound_x = (float)inc_x / 2, bound_y = (float)inc_y / 2;                               // GPU:808-809
+        const float rcp0 = refined_rcp(dir0), rcp1 = refined_rcp(dir1);
+        float dir_num_x = div_by(bound_x, dir0, rcp0), dir_num_y = div_by(bound_y, dir1, rcp1), later = 0.0f;
+        float restrict_ele = obstacle_ele;
+        int c0 = ob0, c1 = ob1;
+        // this lane's run of the walk
+        const bool maj_x = fabsf(inc0) >= fabsf(inc1);
+        const int obM = maj_x ? ob0 : ob1, incM = maj_x ? inc_x : inc_y;
+        int cM_end = -2;                                                   // (never reached: the last lane walks off the map)
+        if (G > 1) {
+            const int nM = incM > 0 ? L - 1 - obM : obM;                   // major crossings that stay inside; crossing number nM leaves
+            const int S = (nM + G) / G;                                    // ceil((nM + 1) / G)
+            const int K = g * S;
+            cM_end = g == G - 1 ? -2 : obM + (K + S) * incM;
+            if (K > 0) {
+                const int obm = maj_x ? ob1 : ob0, incm = maj_x ? inc_y : inc_x;
+                const float dirM = maj_x ? dir0 : dir1, rcpM = maj_x ? rcp0 : rcp1, dirm = maj_x ? dir1 : dir0, rcpm = maj_x ? rcp1 : rcp0;
+                const float fincM = (float)incM, fincm = (float)incm;
+                const float vprev = div_by(((float)K - 0.5f) * fincM, dirM, rcpM);               // dn_M(K - 1): the step that got here
+                const float dnM = div_by(((float)K + 0.5f) * fincM, dirM, rcpM);
+                int j = (int)floorf(vprev * fabsf(dirm) - 0.5f);                                 // about the last j with dn_m(j) <= vprev
+                j = j < -1 ? -1 : (j > 2 * L ? 2 * L : j);
+                while (div_by(((float)(j + 1) + 0.5f) * fincm, dirm, rcpm) <= vprev) ++j;
+                while (j >= 0 && div_by(((float)j + 0.5f) * fincm, dirm, rcpm) > vprev) --j;
+                const int km = j + 1;
+                const float bm = ((float)km + 0.5f) * fincm;
+                const float dnm = div_by(bm, dirm, rcpm);
+                const int cM = obM + K * incM, cm = obm + km * incm;
+                const float bM = ((float)K + 0.5f) * fincM;
+                c0 = maj_x ? cM : cm;              c1 = maj_x ? cm : cM;
+                bound_x = maj_x ? bM : bm;         bound_y = maj_x ? bm : bM;
+                dir_num_x = maj_x ? dnM : dnm;     dir_num_y = maj_x ? dnm : dnM;
+                later = vprev;
             }
         }
+        // GPU:819-880.  The reference's three branches (step in y / step in x / step in both when the two border distances tie)
+        // are one straight-line body here: the crossed-cell test uses the smaller distance (dir_num_x when they tie, as in the
+        // reference's last branch), and each axis advances under a select.  Every value is computed by the reference's own
+        // expression (the two divisions per step through div_by, above); lanes of a wave do not serialise over the three variants.
+        // The walk itself (c0, c1, the border distances) never depends on what it reads: the lowest scan point of a crossed cell only
+        // lowers `restrict_ele`, a running minimum.  The walk runs RD steps ahead -- RD loads in flight, addresses clamped instead
+        // of branched round -- and the bounds are folded in afterwards (a minimum: any order).
+        bool inside = c0 >= 0 && c0 < L && c1 >= 0 && c1 < L;
+        while (__ballot(inside) != 0) {                                   // wave-uniform; lanes that are done idle
+            float low[RD]; int hc0[RD]; bool hit[RD];
+#pragma unroll
+            for (int u = 0; u < RD; ++u) {
+                const bool step_y = dir_num_x > dir_num_y;                 // GPU:821
+                const bool step_x = dir_num_x < dir_num_y;                 // GPU:838; neither: both axes (GPU:855)
+                const float step = step_y ? dir_num_y : dir_num_x;
+                hit[u] = inside && step - later > threshold && c0 != ob0 && c1 != ob1;       // GPU:823-830 and twins
+                hc0[u] = c0;
+                low[u] = m.lowest[hit[u] ? (uint32_t)(c0 * L + c1) : 0u];
+                later = inside ? step : later;
+                const float nbx = bound_x + (float)inc_x, nby = bound_y + (float)inc_y;
+                const float ndx = div_by(nbx, dir0, rcp0), ndy = div_by(nby, dir1, rcp1);
+                if (inside && !step_y) { c0 += inc_x; bound_x = nbx; dir_num_x = ndx; }
+                if (inside && !step_x) { c1 += inc_y; bound_y = nby; dir_num_y = ndy; }
+                inside = inside && (unsigned)c0 < (unsigned)L && (unsigned)c1 < (unsigned)L;
+                if (G > 1) inside = inside && (maj_x ? c0 : c1) != cM_end;
+            }
+#pragma unroll
+            for (int u = 0; u < RD; ++u) {
+                if (hit[u] && low[u] != 10.0f) {                           // GPU:681-689
+                    const float x1 = (float)(hc0[u] - ob0), x2 = (float)hc0[u] - robot_f;            // GPU:691-706
+                    const float e = low[u] + (sensor_z - low[u]) / x2 * x1;
+                    if (e < restrict_ele) restrict_ele = e;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) {                                  // the ray's lanes: adjacent, all here
+            const float other = __shfl_xor(restrict_ele, o);
+            if (other < restrict_ele) restrict_ele = other;
+        }
+        if (g == 0 && obstacle_ele - 3 * sqrtf(m.variance[i]) > restrict_ele) m.elevation[i] = kEmptyElevation;   // GPU:884-885
     }
-    if (obstacle_ele - 3 * sqrtf(m.variance[i]) > restrict_ele) m.elevation[i] = kEmptyElevation;   // GPU:884-885
 }
 
 // AoS ingest (first half): the reference walks the PCL cloud on the host and copies x, y, z, r, g, b, intensity
@@ -1612,11 +1659,18 @@ __global__ __launch_bounds__(256) void k_clear_lowest(float* p, int n, uint32_t*
 
 // list: L * L words (the walking cells); count: their number, zero on entry (zeroed at allocation and by every call on its way out)
 hipError_t launch_raytracing(hipStream_t st, const LayerPtrs& m, int L, int start0, int start1, float sensor_z, float obstacle_threshold,
-                             int row0, int row1, uint32_t* list, uint32_t* count)
+                             int row0, int row1, uint32_t* list, uint32_t* count, int depth, int lanes)
 {
     const dim3 grid((L * L + 255) / 256), block(256);
     hipLaunchKernelGGL(k_ray_list, grid, block, 0, st, m, L, start0, start1, obstacle_threshold, row0, row1, list, count);
-    hipLaunchKernelGGL(k_raytracing, grid, block, 0, st, m, L, start0, start1, sensor_z, (const uint32_t*)list, (const uint32_t*)count);
+    auto k = lanes >= 16 ? (depth >= 8 ? k_raytracing<8, 16> : k_raytracing<4, 16>)
+           : lanes >= 8  ? (depth >= 8 ? k_raytracing<8, 8>  : k_raytracing<4, 8>)
+           : lanes >= 4  ? (depth >= 8 ? k_raytracing<8, 4>  : k_raytracing<4, 4>)
+                         : (depth >= 8 ? k_raytracing<8, 1>  : k_raytracing<4, 1>);
+    const int g_lanes = lanes >= 16 ? 16 : lanes >= 8 ? 8 : lanes >= 4 ? 4 : 1;
+    const long long want = ((long long)L * L * g_lanes + 255) / 256;
+    const dim3 ray_grid((unsigned)(want < 4096 ? want : 4096));           // the walkers are a fraction of the cells: grid-stride
+    hipLaunchKernelGGL(k, ray_grid, block, 0, st, m, L, start0, start1, sensor_z, (const uint32_t*)list, (const uint32_t*)count);
     hipLaunchKernelGGL(k_clear_lowest, grid, block, 0, st, m.lowest, L * L, count);
     return hipGetLastError();
 }

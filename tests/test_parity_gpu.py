@@ -416,6 +416,60 @@ def test_mixed_fast_and_generic_batches(oracle_mod):
         assert_maps_match(gpu, ref)
 
 
+def _laser_frames():
+    """Laser frames either side of every condition under which the library takes the short form of the laser variance
+    (gem_capi.cpp: fill_frame): the map it writes must be the oracle's whichever form ran."""
+    base = synth.pose_matrix(0.3, -0.2, 0.9, 0.4, 0.05, -0.03)
+    out = {}
+    out["plain"] = synth._frame_for(base, SensorModel.velodyne())
+    f = synth._frame_for(base, SensorModel.velodyne()); f.rotation_variance = np.full((3, 3), -0.0, F32); out["minus_zero_Q"] = f
+    f = synth._frame_for(base, SensorModel.velodyne()); q = np.zeros((3, 3), F32); q[0, 0] = q[1, 1] = 1e-4; q[0, 2] = q[2, 0] = 2e-5
+    f.rotation_variance = q; out["rotation_variance"] = f
+    f = synth._frame_for(base, SensorModel.velodyne()); f.sensor_jacobian = np.array([0.3, -0.2, 0.0], F32); out["Js2_zero"] = f
+    f = synth._frame_for(base, SensorModel.velodyne()); f.sensor_jacobian = np.array([0.0, 0.0, -1.0], F32); out["Js_negative"] = f
+    out["tiny_min_radius"] = synth._frame_for(base, SensorModel(SensorModel.velodyne().kind, (1e-24, 0.0006, 0.0015), 0.8, -5.0))
+    out["no_beam_growth"] = synth._frame_for(base, SensorModel(SensorModel.velodyne().kind, (0.018, 0.0, 0.0), 0.8, -5.0))
+    f = synth._frame_for(base, SensorModel.velodyne()); T = f.T.copy(); T[:3, :3] *= 1.03; f.T = T; out["scaled_T"] = f
+    f = synth._frame_for(base, SensorModel.velodyne()); T = f.T.copy(); T[0, :3] += np.array([0.0, 0.05, 0.0], F32); f.T = T; out["sheared_T"] = f
+    f = synth._frame_for(base, SensorModel.velodyne()); f.P_mul_C_BM_T = np.array([0.0, 0.0, 3e6], F32); out["huge_P"] = f
+    f = synth._frame_for(base, SensorModel.velodyne()); f.lower, f.upper = -np.inf, np.inf; out["open_window"] = f
+    return out
+
+
+@pytest.mark.parametrize("which", ["plain", "minus_zero_Q", "rotation_variance", "Js2_zero", "Js_negative", "tiny_min_radius",
+                                   "no_beam_growth", "scaled_T", "sheared_T", "huge_P", "open_window"])
+def test_laser_variance_short_form_qualification(oracle_mod, which):
+    f = _laser_frames()[which]
+    gpu, ref = make_pair(oracle_mod, 96, 0.1)
+    c = synth.random_cloud(77, 6000, 4.0)
+    c[::97, 2] += 30.0                                       # some points outside the height window
+    for _ in range(2):
+        gpu.add(f, c); ref.add(f, c)
+        assert_maps_match(gpu, ref)
+
+
+def test_batches_mixing_short_form_and_generic_frames(oracle_mod):
+    import torch
+    fr = _laser_frames()
+    frames = [fr["plain"], fr["rotation_variance"], fr["plain"], fr["scaled_T"], fr["Js_negative"]]
+    gpu, ref = make_pair(oracle_mod, 96, 0.1)
+    clouds = [synth.random_cloud(200 + k, 3000 + 500 * k, 4.0) for k in range(len(frames))]
+    offsets = np.concatenate([[0], np.cumsum([c.shape[0] for c in clouds])])
+    d = torch.from_numpy(np.concatenate(clouds, 0)).to("cuda:0")
+    incs = [1e-5 * (k + 1) for k in range(len(frames))]
+    for rep in range(2):
+        gpu.add_batch(frames, d, offsets, incs)
+        for k, f in enumerate(frames):
+            ref.mapvar_update(incs[k]); ref.add(f, clouds[k])
+        assert_maps_match(gpu, ref)
+    # a batch whose frames all qualify, next to the same one with the short form switched off
+    gpu2 = ElevationMap(96, 0.1, debug={"fast_laser": 0}); gpu3 = ElevationMap(96, 0.1)
+    for m in (gpu2, gpu3):
+        m.add_batch([fr["plain"], fr["open_window"], fr["minus_zero_Q"]], d[:offsets[3]], offsets[:4], incs[:3])
+    for name in ("elevation", "variance"):
+        assert np.array_equal(gpu2.layer(name), gpu3.layer(name))
+
+
 # ---- AoS ingest: the PCL point structs as they are (SURVEY 8f #4) --------------------------------------------------------
 def test_add_aos_equals_add_on_unpacked_arrays(oracle_mod):
     # PointXYZRGBICT (PointXYZRGBICT.hpp:28-46): x y z pad | b g r a | covariance | intensity | travers = 32 bytes
@@ -525,6 +579,42 @@ def test_lowest_tracking_and_raytracing(oracle_mod, ref_mod, monkeypatch, L, res
             assert np.array_equal(g, ref.layer(name)), (step, name, "reference, after raytracing")
         deleted += before - int((gpu.layer("elevation") != -10).sum())
     assert deleted > 20
+
+
+@pytest.mark.parametrize("L,res,pos", [(300, 0.05, (3.37, -2.11, 0.62)), (251, 0.1, (-7.05, 4.4, 1.3)), (64, 0.1, (0.0, 0.0, 0.4)), (33, 0.2, (1.0, 1.0, 0.9))])
+def test_raytracing_walks_split_over_lanes(oracle_mod, L, res, pos):
+    """k_raytracing hands one walk to several lanes, each starting in the middle of it (closed-form state of the border-distance
+    merge): every lane count / look-ahead depth must leave the map the oracle's one-thread-per-cell walk leaves.  Dense random
+    layers: long walks in all directions, ties on the diagonals, walks that leave through either axis."""
+    rng = np.random.default_rng(L)
+    gpu, ora = make_pair(oracle_mod, L, res)
+    for m in (gpu, ora):
+        m.move(pos)                                                       # circular-buffer start off zero, the sensor height
+    for trial in range(2):
+        e = rng.normal(0.0, 0.4, (L, L)).astype(F32); e[rng.random((L, L)) < 0.15] = F32(-10)
+        v = rng.uniform(1e-4, 4e-3, (L, L)).astype(F32)
+        t = rng.uniform(0.0, 1.0, (L, L)).astype(F32)
+        t[rng.random((L, L)) < 0.3] = F32(0.1)
+        low = np.full((L, L), 10.0, F32)
+        k = rng.random((L, L)) < (0.5 if trial else 0.05)
+        low[k] = rng.normal(-0.3 if trial else 0.2, 0.3, k.sum()).astype(F32)
+        results = []
+        for lanes, depth in [(0, 0), (1, 4), (1, 8), (4, 4), (4, 8), (8, 4), (8, 8), (16, 4), (16, 8)]:
+            m = ora if lanes == 0 else gpu
+            if lanes:
+                gpu.debug_set("ray_lanes", lanes); gpu.debug_set("ray_depth", depth)
+            for name, a in (("elevation", e), ("variance", v), ("traver", t), ("lowest", low)):
+                m.set_layer(name, a)
+            m.raytracing()
+            results.append((lanes, depth, m.layer("elevation"), m.layer("lowest")))
+        want = results[0]
+        deleted = int(((want[2] == -10) & (e != -10)).sum())
+        assert deleted > 5, "the case deletes nothing"
+        assert int(((want[2] != -10) & (t < 0.7)).sum()) > L, "the case deletes everything"
+        for lanes, depth, ge, gl in results[1:]:
+            bad = np.flatnonzero(ge.ravel() != want[2].ravel())
+            assert bad.size == 0, f"lanes {lanes} depth {depth}: {bad.size} cells differ, first {bad[:6]}"
+            assert np.array_equal(gl, want[3])
 
 
 def test_lowest_sees_the_minus_one_sentinel(oracle_mod):
