@@ -872,6 +872,7 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     ba.T = T; ba.tiles_per_row = tiles_per_row; ba.B = B; ba.Bpad = bpad;
     ba.tile_bits = 0; while ((1 << ba.tile_bits) < T) ++ba.tile_bits;
     ba.epoch = pb.epoch;
+    ba.rec_words = (attr & 3) != 0 ? 4 : 3;
     ba.rec = static_cast<uint4*>(pb.rec.p); ba.seg = static_cast<uint16_t*>(pb.seg.p); ba.flag = static_cast<uint32_t*>(pb.flag.p); ba.gflag = static_cast<uint32_t*>(pb.gflag.p);
     ba.counters = h->counting ? h->d_counters : nullptr;
     ba.keep_sentinel = h->track_lowest ? 1 : 0;

@@ -50,6 +50,24 @@ __global__ __launch_bounds__(256) void k_project(FrameConst fc, int n, float* __
 // Descriptor word of (sweep, tile, unit), 16 bits:  start << 7 | count  (count 1..64, 0 = empty).
 // Only the tiles a unit actually touches are written; k_fuse_list zeroes every word it consumes,
 // so the table is all-zero again after each pass and never needs a clearing kernel.
+
+// A binned record: {height, variance, cell in tile | colour flag << 31, index of the point}.  The last word is only read when colours are
+// fused (ATTR != 0): without them the records are 12 bytes -- a quarter less to write, to read back and to stage through the LDS.
+struct __attribute__((packed, aligned(4))) Rec3 { uint32_t x, y, z; };
+__device__ __forceinline__ void rec_store3(uint4* rec, size_t i, uint32_t x, uint32_t y, uint32_t z)
+{
+    *reinterpret_cast<Rec3*>(reinterpret_cast<uint32_t*>(rec) + i * 3) = Rec3{x, y, z};
+}
+template <int W> __device__ __forceinline__ uint4 rec_load(const uint4* __restrict__ rec, uint32_t i)
+{
+    if constexpr (W == 4) return rec[i];
+    else { const Rec3 r = *reinterpret_cast<const Rec3*>(reinterpret_cast<const uint32_t*>(rec) + (size_t)i * 3); return make_uint4(r.x, r.y, r.z, 0u); }
+}
+template <int W> __device__ __forceinline__ uint32_t rec_load_cell(const uint4* __restrict__ rec, uint32_t i)
+{
+    return reinterpret_cast<const uint32_t*>(rec)[(size_t)i * W + 2];
+}
+
 template <int SRC, int TS, bool BATCH>
 __device__ __forceinline__ void bin_wave_body(const BinArgs& a, int block)
 {
@@ -124,7 +142,11 @@ __device__ __forceinline__ void bin_wave_body(const BinArgs& a, int block)
     const uint32_t start_leader = wave_inclusive_scan(x) - x;       // groups laid out in order of first appearance
     const int my_leader = valid ? (__ffsll((unsigned long long)peers) - 1) : lane;
     const uint32_t start = (uint32_t)__shfl((int)start_leader, my_leader, 64);
-    if (valid) a.rec[(size_t)unit * U + start + rank] = make_uint4(__float_as_uint(hh), __float_as_uint(vv), cl, src);
+    if (valid) {
+        const size_t slot = (size_t)unit * U + start + rank;
+        if (a.rec_words == 3) rec_store3(a.rec, slot, __float_as_uint(hh), __float_as_uint(vv), cl);     // (wave-uniform) no colours: the source index is dead
+        else a.rec[slot] = make_uint4(__float_as_uint(hh), __float_as_uint(vv), cl, src);
+    }
     if (leader) {
         // table layout [sweep][tile][unit in sweep]: the words one sweep writes stay within T * Bpad * 4 bytes
         a.seg[((size_t)sweep * a.T + tile) * a.Bpad + (unit - unit_first)] = (uint16_t)((start << kSegCountBits) | cnt);
@@ -184,12 +206,13 @@ __device__ __forceinline__ DenseResult dense_tile(const uint4* __restrict__ rec,
                                                float mahal, float var_floor, unsigned long long* dbg)
 {
     constexpr int ATTR = FLAGS & 3;
+    constexpr int RW = ATTR != 0 ? 4 : 3;                                // words per binned record
     constexpr bool LOWEST = (FLAGS & 4) != 0;
 #define GEM_DSTAMP(k) do { if (dbg && threadIdx.x == 0) dbg[k] = (unsigned long long)__builtin_readcyclecounter(); } while (0)
     GEM_DSTAMP(0);
     constexpr int CELLS = 1 << (2 * TS), NW = NT / 64;
     static_assert(CELLS == NT, "one cell per thread");
-    using SRec = typename std::conditional<ATTR != 0, uint4, uint2>::type;   // sorted record: {h, v} (+ colour flag, source index)
+    using SRec = typename std::conditional<ATTR != 0, uint4, uint2>::type;   // sorted record: {h, v} (+ cell | colour flag, source index)
     SRec* const srt = reinterpret_cast<SRec*>(srt_raw);
     const int tid = (int)threadIdx.x, lane = lane_id(), w = tid >> 6;
     const uint64_t lt = lanemask_lt();
@@ -205,7 +228,7 @@ __device__ __forceinline__ DenseResult dense_tile(const uint4* __restrict__ rec,
             for (int x = 0; x < PFC; ++x) {
                 const uint2 de = dlc[min(d + x, nd - 1u)];
                 cn[x] = d + x < dw1 ? de.y : 0u;
-                z[x] = rec[de.x + ((uint32_t)lane < de.y ? (uint32_t)lane : 0u)].z;
+                z[x] = rec_load_cell<RW>(rec, de.x + ((uint32_t)lane < de.y ? (uint32_t)lane : 0u));
             }
         };
         auto count = [&](const uint32_t (&z)[PFC], const uint32_t (&cn)[PFC]) {
@@ -246,7 +269,7 @@ __device__ __forceinline__ DenseResult dense_tile(const uint4* __restrict__ rec,
             for (int x = 0; x < PFP; ++x) {
                 const uint2 de = dlc[min(d + x, nd - 1u)];
                 cn[x] = d + x < dw1 ? de.y : 0u;
-                r[x] = rec[de.x + ((uint32_t)lane < de.y ? (uint32_t)lane : 0u)];
+                r[x] = rec_load<RW>(rec, de.x + ((uint32_t)lane < de.y ? (uint32_t)lane : 0u));
             }
         };
         auto place = [&](const uint4 (&r)[PFP], const uint32_t (&cn)[PFP]) {
@@ -356,9 +379,12 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
     float*    s_v     = s_h + PB;                                          // [PB]
     uint32_t* s_src   = reinterpret_cast<uint32_t*>(s_v + PB);             // [PB] only when ATTR != 0
     uint32_t* dl_addr = DMA ? reinterpret_cast<uint32_t*>(stage + PB) : s_src + (ATTR ? PB : 0);   // [DCAP] arena index of the first record
+    // words per binned record in the arena; in `stage` a record keeps a 16-byte slot either way (global_load_lds_dwordx3 writes lane l's
+    // 12 bytes at base + 16 l: tools/ubench/lds_dma12.hip), the fourth word is then never written nor read
+    constexpr int RW = ATTR != 0 ? 4 : 3;
     auto rec_h   = [&](uint32_t sl) -> float    { if constexpr (DMA) return __uint_as_float(stage[sl].x); else return s_h[sl]; };
     auto rec_v   = [&](uint32_t sl) -> float    { if constexpr (DMA) return __uint_as_float(stage[sl].y); else return s_v[sl]; };
-    auto rec_src = [&](uint32_t sl) -> uint32_t { if constexpr (DMA) return (stage[sl].w & 0x7fffffffu) | (stage[sl].z & 0x80000000u); else return s_src[sl]; };
+    auto rec_src = [&](uint32_t sl) -> uint32_t { if constexpr (DMA && RW == 4) return (stage[sl].w & 0x7fffffffu) | (stage[sl].z & 0x80000000u); else if constexpr (DMA) return 0u; else return s_src[sl]; };
     uint32_t* dl_rc   = dl_addr + DCAP;                                    // [DCAP] record prefix << 9 | count
     uint32_t* bstart  = dl_rc + DCAP;                                      // [MAXB + 1] first descriptor of each batch
     uint32_t* scratch = bstart + MAXB + 1;                                 // [16]
@@ -588,8 +614,12 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
                         const uint32_t rc = (uint32_t)__builtin_amdgcn_readlane((int)my_rc, (int)i);
                         const uint32_t adr = (uint32_t)__builtin_amdgcn_readlane((int)my_addr, (int)i);
                         if ((uint32_t)lane < (rc & 0x1ffu))
-                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.rec + adr + (uint32_t)lane),
-                                                             (__attribute__((address_space(3))) void*)(stage + ((rc >> 9) - slot0)), 16, 0, 0);
+                        {
+                            const auto* gsrc = (const __attribute__((address_space(1))) void*)(reinterpret_cast<const uint32_t*>(a.rec) + (size_t)(adr + (uint32_t)lane) * (ATTR != 0 ? 4 : 3));
+                            auto* ldst = (__attribute__((address_space(3))) void*)(stage + ((rc >> 9) - slot0));
+                            if constexpr (ATTR != 0) __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 0, 0);
+                            else                     __builtin_amdgcn_global_load_lds(gsrc, ldst, 12, 0, 0);
+                        }
                     }
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -620,7 +650,7 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
                             const uint32_t rc = dl_rc[dd + x];
                             if ((uint32_t)lane < (rc & 0x1ffu)) {
                                 sl[x] = (rc >> 9) - slot0 + (uint32_t)lane;
-                                rr[x] = a.rec[dl_addr[dd + x] + (uint32_t)lane];
+                                rr[x] = rec_load<RW>(a.rec, dl_addr[dd + x] + (uint32_t)lane);
                             }
                         }
                     }

@@ -46,7 +46,8 @@ struct BinArgs {
     int B;                             // number of units (grid size)
     int Bpad;                          // units of the longest sweep, multiple of 32: row length of the descriptor table
     // outputs
-    uint4*    rec;                     // [B * U]
+    uint4*    rec;                     // [B * U] records of rec_words words (gem_kernels.hip: rec_load)
+    int       rec_words;               // 3 = {h, var, cell}; 4 = ... + the point's index (colours are fused)
     uint16_t* seg;                     // [n_sweeps][T][Bpad]  descriptor words (all-zero between passes)
     uint32_t* flag;                    // [T][n_sweeps]  == epoch when the sweep put a record into the tile
     uint32_t* gflag;                   // [n_sweeps][T][Bpad/32]  == epoch when that group of 32 units did
