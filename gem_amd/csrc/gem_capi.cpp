@@ -60,6 +60,7 @@ struct gem_handle {
     struct PassBuffers {
         Arena rec, srt, seg, flag, gflag;   // records, descriptor table, touched stamps per (tile, sweep) and per (sweep, tile, 32 units)
         Arena s_hv1, s_hv2, s_key1, s_key2, s_src1, s_src2, s_cnt1, s_cnt2, s_misc;   // the sorted pipeline of big passes (gem_sort.hip)
+        Arena s_blkcnt;                // [4 T] records per block, zero between passes (k_sort_project adds, k_block_prefix reads and clears)
         Arena s_ranges, s_shard;       // multi-GPU shard: every block's range in the sorted records; strip ids [16] | strip bounds [16]
         Arena tables;                  // batched-call tables (frames, sweep_unit0, sweep_first, var_updates)
         void* host_tables = nullptr;   // their pinned staging copy: the upload is asynchronous, `tables_done` guards its reuse
@@ -96,6 +97,7 @@ struct gem_handle {
     long long sort_min_points = 200000, sort_min_points_batch = 390000;
     bool walk_permute = true;           // k_fuse_walk: blocks take the tile rows centre-first
     int  sort_passes = 0;               // 0 = by map size and form (sort_geometry); 1 / 2 / 3 force it
+    int blk_batch = 0;                  // k_fuse_block's round: 0 = by the pass's mean block load, 512 / 2048 forced (debug knob)
     int ray_depth = 4, ray_lanes = 16;  // k_raytracing: loads in flight per lane, lanes per ray (debug knobs; 16 x 4 measured best on C2)
     bool fast_laser = true;             // frames that qualify use the zero-rotation-variance form of the laser variance (fill_frame; debug knob)
     bool rank_by_ballot = false;        // k_sort_scatter ranks by ballot in every pass (debug knob)
@@ -125,10 +127,11 @@ struct gem_handle {
     struct Shard {
         bool valid = false;
         const uint2* hv = nullptr; const uint32_t* key = nullptr;     // this device's sorted records
-        const uint2* ranges = nullptr;                                 // [4 T] where every block's records are in them (k_block_ranges)
+        const uint2* ranges = nullptr;                                 // [4 T] where every block's records are in them (k_block_prefix)
         uint32_t bounds[kMaxRanks + 1] = {0};                          // first record of every strip in them
         const uint32_t* d_bounds = nullptr;                            // ... on the device (16 words)
         int nstrips = 0, n_global_sweeps = 0;
+        long long points = 0;                                          // points this device sorted for the step
         int slot = -1;                                                 // pass-buffer set the sort ran in on a binning stream (its bin_done / fuse_done events), -1: on the handle's stream
     } shard;
     Arena sh_dev, sh_recv_hv, sh_recv_key, sh_recv_rng, sh_ranges;  // ids / bounds / gathered bounds / variance increments; records and block ranges received from the other ranks; own block ranges
@@ -179,6 +182,17 @@ int ensure(gem_handle* h, Arena& a, size_t bytes)
     if (e != hipSuccess) return fail(h, GEM_ERR_NOMEM, "hipMalloc(arena)", e);
     a.cap = want;
     ++h->arena_allocations;
+    return GEM_OK;
+}
+
+// ... for tables the kernels keep all-zero between passes: cleared when (re)allocated (allocation synchronises anyway)
+int ensure_zeroed(gem_handle* h, Arena& a, size_t bytes)
+{
+    if (bytes <= a.cap) return GEM_OK;
+    const int rc = ensure(h, a, bytes);
+    if (rc) return rc;
+    GEM_HIP(h, hipMemsetAsync(a.p, 0, a.cap, h->stream));
+    GEM_HIP(h, hipStreamSynchronize(h->stream));
     return GEM_OK;
 }
 
@@ -577,6 +591,11 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
         sa.segtot[i] = reinterpret_cast<uint32_t*>(misc + o_seg[i]);
     }
     sa.total = reinterpret_cast<uint32_t*>(misc + o_total); sa.bin_base = reinterpret_cast<uint32_t*>(misc + o_base);
+    sa.blk_cnt = nullptr;
+    if ((geo.block_form && geo.n_passes > 1) || shard) {             // the walk will want every block's range (the last pass's bins are not the blocks)
+        if ((rc = ensure_zeroed(h, pb.s_blkcnt, (size_t)4 * T * sizeof(uint32_t))) || (rc = ensure(h, pb.s_ranges, (size_t)4 * T * sizeof(uint2)))) return rc;
+        sa.blk_cnt = static_cast<uint32_t*>(pb.s_blkcnt.p);
+    }
     sa.seg_cnt = reinterpret_cast<uint32_t*>(misc + o_segcnt);
     // arrays a: the projected records in input order, later the final order; arrays b: the order after pass 1
     sa.hv_a = static_cast<uint2*>(pb.s_hv2.p); sa.hv_b = static_cast<uint2*>(pb.s_hv1.p);
@@ -595,6 +614,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     wa.id_bits = geo.id_bits; wa.bin_shift = geo.dshift[geo.n_passes - 1]; wa.n_sweeps = in.n_sweeps;
     wa.exact_bins = (geo.block_form && geo.n_passes == 1) ? 1 : 0;
     wa.lane_sort = h->lane_sort ? 1 : 0;
+    wa.light_blocks = h->blk_batch ? (h->blk_batch <= 512 ? 1 : 0) : ((long long)in.n <= 768ll * 4 * T ? 1 : 0);   // (by the mean: a heavy block just takes more rounds)
     wa.mahal = h->cfg.mahalanobis_threshold; wa.var_floor = h->cfg.variance_floor;
     wa.dense = dense ? 1 : 0;
     wa.n_pending = h->n_pending;
@@ -629,12 +649,11 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     }
     if (shard) {
         // where the strips begin in the sorted records (one 32-ary search per boundary) and where every block's records are
-        // (k_block_ranges): behind the sort, on its stream
+        // (k_block_prefix): behind the sort, on its stream
         gem_handle::Shard& sd = h->shard;
         sd.valid = false;
         if (!h->sh_host) GEM_HIP(h, hipHostMalloc(&h->sh_host, kShardHostBytes, hipHostMallocDefault));
         if ((rc = ensure(h, pb.s_shard, 64 * sizeof(uint32_t)))) return rc;
-        if ((rc = ensure(h, pb.s_ranges, (size_t)4 * T * sizeof(uint2)))) return rc;
         uint32_t* host = static_cast<uint32_t*>(h->sh_host);
         for (int k = 0; k <= shard->nstrips; ++k) {
             const int tile_row = shard->strip_rows[k] >= h->L ? geo.tiles_per_row : shard->strip_rows[k] / 32;
@@ -644,8 +663,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
         const uint32_t* keys = final_b ? sa.key_b : sa.key_a;
         GEM_HIP(h, hipMemcpyAsync(d_ids, host, sizeof(uint32_t) * (shard->nstrips + 1), hipMemcpyHostToDevice, sbin));
         GEM_HIP(h, launch_strip_bounds(sbin, keys, sa.total, geo.id_bits, d_ids, d_bounds, shard->nstrips + 1));
-        GEM_HIP(h, hipMemsetAsync(pb.s_ranges.p, 0, (size_t)4 * T * sizeof(uint2), sbin));
-        GEM_HIP(h, launch_block_ranges(sbin, keys, sa.total, in.n, geo.id_bits, static_cast<uint2*>(pb.s_ranges.p)));
+        GEM_HIP(h, launch_block_prefix(sbin, sa.blk_cnt, 4 * T, static_cast<uint2*>(pb.s_ranges.p)));
         sd.hv = final_b ? sa.hv_b : sa.hv_a; sd.key = keys; sd.ranges = static_cast<const uint2*>(pb.s_ranges.p);
         sd.d_bounds = d_bounds; sd.nstrips = shard->nstrips; sd.slot = overlap ? (int)slot : -1;
         h->stats.points_in = in.n;
@@ -660,6 +678,12 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
         for (int k = 0; k <= shard->nstrips; ++k) sd.bounds[k] = host[32 + k];
         sd.valid = true;
         return GEM_OK;
+    }
+    if (geo.block_form && geo.n_passes > 1) {
+        // the last digit's bins hold several blocks: where every block's records are (the prefix of the per-block counts
+        // k_sort_project took), behind the sort on its stream, instead of a search by every workgroup of the walk
+        GEM_HIP(h, launch_block_prefix(sbin, sa.blk_cnt, 4 * T, static_cast<uint2*>(pb.s_ranges.p)));
+        wa.ranges = static_cast<const uint2*>(pb.s_ranges.p);
     }
     if (overlap) {
         GEM_HIP(h, hipEventRecord(pb.bin_done, sbin));
@@ -697,10 +721,10 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
         // block-sorted form (one counting-sort pass for the 600^2 map instead of two, no per-cell order in HBM at all); a single
         // dense cloud (a depth image: a quarter of its points in one block, hundreds per cell, image row by image row) needs the
         // whole chip to order it by cell: the cell-sorted form.
-        // (Maps of more than kOnePassMaxBins blocks would need two passes over the block id and a search per block: their batches
-        //  stay cell-sorted -- C5, 2400^2: 341 us cell-sorted in three passes, 353 block-sorted in two.)
-        const long long blocks = 4ll * ((h->L + 31) / 32) * ((h->L + 31) / 32);
-        const bool block_form = h->sort_form == 2 || (h->sort_form == 0 && in0.n_sweeps > 1 && blocks <= kOnePassMaxBins);
+        // (Maps of more than kOnePassMaxBins blocks take two passes over the block id and k_block_prefix; with k_fuse_block's rounds
+        //  of 512 records for light blocks that is still the shorter way -- C5, 2400^2, same box: 351-365 us cell-sorted in three
+        //  passes, 333-340 block-sorted in two.)
+        const bool block_form = h->sort_form == 2 || (h->sort_form == 0 && in0.n_sweeps > 1);
         SortGeometry geo = sort_geometry(h, in0.n_sweeps, block_form);
         if (!geo.ok) geo = sort_geometry(h, in0.n_sweeps, !block_form);
         if (geo.ok) return run_sort_pipeline(h, in0, attr, geo);
@@ -1018,7 +1042,7 @@ void gem_destroy(gem_handle* h)
     if (h->sh_host) hipHostFree(h->sh_host);
     for (auto& b : h->pb) {
         for (Arena* a : {&b.rec, &b.srt, &b.seg, &b.flag, &b.gflag, &b.tables, &b.s_hv1, &b.s_hv2, &b.s_key1, &b.s_key2, &b.s_src1, &b.s_src2,
-                         &b.s_cnt1, &b.s_cnt2, &b.s_misc, &b.s_ranges, &b.s_shard}) if (a->p) hipFree(a->p);
+                         &b.s_cnt1, &b.s_cnt2, &b.s_misc, &b.s_ranges, &b.s_shard, &b.s_blkcnt}) if (a->p) hipFree(a->p);
         if (b.host_tables) hipHostFree(b.host_tables);
         if (b.tables_done) hipEventDestroy(b.tables_done);
         if (b.bin_done) hipEventDestroy(b.bin_done);
@@ -1299,7 +1323,7 @@ int gem_reserve(gem_handle* h, long long max_points, int max_sweeps, int with_co
     const long long blocks = 4ll * ((h->L + 31) / 32) * ((h->L + 31) / 32);
     bool sorted = false;
     if (h->sort_path && max_points >= sort_from) {
-        const bool block_form = h->sort_form == 2 || (h->sort_form == 0 && max_sweeps > 1 && blocks <= kOnePassMaxBins);
+        const bool block_form = h->sort_form == 2 || (h->sort_form == 0 && max_sweeps > 1);
         SortGeometry geo = sort_geometry(h, max_sweeps, block_form);
         if (!geo.ok) geo = sort_geometry(h, max_sweeps, !block_form);
         if (geo.ok) {
@@ -1321,6 +1345,7 @@ int gem_reserve(gem_handle* h, long long max_points, int max_sweeps, int with_co
                 if ((rc = ensure(h, pb.s_cnt1, NC1 * geo.dbins[0] * 4)) || (rc = ensure(h, pb.s_cnt2, nc2 * bins_hi * 4 + 16)) ||
                     (rc = ensure(h, pb.s_misc, misc))) return rc;
                 if (max_sweeps > 1 && (rc = ensure(h, pb.tables, tables))) return rc;
+                if (geo.block_form && geo.n_passes > 1 && ((rc = ensure(h, pb.s_ranges, (size_t)blocks * sizeof(uint2))) || (rc = ensure_zeroed(h, pb.s_blkcnt, (size_t)blocks * sizeof(uint32_t))))) return rc;
             }
         }
     }
@@ -1731,6 +1756,7 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "sort_passes")        { if (value < 0 || value > 3) return fail(h, GEM_ERR_INVALID, "sort_passes: 0..3"); h->sort_passes = (int)value; }
     else if (k == "rank_by_ballot")     h->rank_by_ballot = value != 0;
     else if (k == "lane_sort")          h->lane_sort = value != 0;
+    else if (k == "blk_batch")          h->blk_batch = (int)value;
     else if (k == "ray_depth")          h->ray_depth = (int)value;
     else if (k == "ray_lanes")          h->ray_lanes = (int)value;
     else if (k == "fast_laser")         h->fast_laser = value != 0;
@@ -1922,6 +1948,7 @@ static int shard_sort_locked(gem_handle* h, int n_local_sweeps, const gem_frame_
         if ((rc = run_sort_pipeline(h, in, 0, geo, &so))) return rc;
     }
     sd.n_global_sweeps = n_global_sweeps;
+    sd.points = n;
     if (out_bounds) for (int k = 0; k <= nstrips; ++k) out_bounds[k] = sd.bounds[k];
     if (out_d_hv) *out_d_hv = sd.hv;
     if (out_d_key) *out_d_key = sd.key;
@@ -1976,6 +2003,10 @@ static int shard_fuse_locked(gem_handle* h, int n_src, const void* const* d_hv, 
     wa.count_per_pass = 0;
     wa.walk_order = (h->walk_permute && 4ll * geo.T <= 4096) ? 1 : 0;
     wa.lane_sort = h->lane_sort ? 1 : 0;
+    {   // rounds of 512 records when the strip's blocks are light: about as many records arrive as this rank sorted (its share of the step)
+        const long long strip_blocks = 4ll * ((std::min(h->row1, h->L) - h->row0 + 31) / 32) * geo.tiles_per_row;
+        wa.light_blocks = h->blk_batch ? (h->blk_batch <= 512 ? 1 : 0) : (h->shard.valid && h->shard.points <= 768ll * strip_blocks ? 1 : 0);
+    }
     wa.center_tr = ((h->L / 2 + h->start[0]) % h->L) >> 5;
     if (var_updates_global) {
         if (n_global_sweeps > 512) return fail(h, GEM_ERR_INVALID, "sharded path: more than 512 sweeps");

@@ -126,6 +126,7 @@ struct SortArgs {
     uint32_t *seg_cnt;                 // [chunks of pass 1][4] records kept by each of k_sort_project's four waves: they are stored COMPACTED at the
                                        // head of the wave's 1024-slot segment of the chunk (the rejected points leave no record)
     uint32_t *total;                   // [0] records kept by pass 1 (in the map, in the strip, accepted)
+    uint32_t *blk_cnt;                 // [4 T] or NULL: k_sort_project adds the records of every block (id >> 8); launch_block_prefix turns them into ranges
     uint32_t *bin_base;                // [bins of the last pass + 1] first record of every highest-digit bin in the final order (what k_fuse_walk searches in)
     uint2 *hv_a, *hv_b;                // {h, var}: a = input order, then after the even passes; b = after the odd passes (the passes ping-pong)
     uint32_t *key_a, *key_b, *src_a, *src_b;      // keys; source point | colour flag << 31 (src only when colours are fused)
@@ -144,6 +145,7 @@ struct PassArgs {
     const int* sweep_chunk0; const long long* sweep_first; int n_sweeps;   // pass 1 of a batched call: sweep-aligned chunks
     uint32_t* bin_base;                          // last pass: [bins + 1] published by workgroup 0
     unsigned long long* counters;
+    int coherent;                                // coarse digits (block-sorted form): consecutive records mostly share their bin
 };
 
 struct WalkArgs {
@@ -164,13 +166,14 @@ struct WalkArgs {
     int   count_per_pass;
     // k_fuse_block only:
     unsigned long long* dbg;           // optional: [blocks][16] cycle stamps of thread 0 (profiling aid, gem_debug_fuse_stamps)
-    const uint2* ranges;               // single source, optional: [4 T] every block's records {first, end} (k_block_ranges) instead of bin_base + search
+    const uint2* ranges;               // single source, optional: [4 T] every block's records {first, end} (k_block_prefix) instead of bin_base + search
     int   lane_sort;                   // 1: the block's cells are handed to the threads in descending order of their record count in the first batch
+    int light_blocks;                  // k_fuse_block: rounds of 512 records instead of 2048 (blocks of a few hundred records)
     int   exact_bins;                  // 1: the last pass's bins ARE the blocks (one-pass sort): bin_base gives a block's records without a search
     // multi-GPU strip owner (gem_add_sharded_device): the block-sorted records received from every rank, taken in rank order
     int   n_src;                       // <= 1: the single source above (hv / key / src, searched through bin_base)
     const uint2* src_hv[kMaxRanks]; const uint32_t* src_key[kMaxRanks]; uint32_t src_n[kMaxRanks];
-    // optional per source: its block ranges (k_block_ranges), entry 0 = block blk0 (the strip's first); positions count from src_base
+    // optional per source: its block ranges (k_block_prefix), entry 0 = block blk0 (the strip's first); positions count from src_base
     // in the source's own arrays, src_hv / src_key point at position src_base.  NULL: the block's records are found by search.
     const uint2* src_ranges[kMaxRanks]; uint32_t src_base[kMaxRanks]; uint32_t blk0;
 };
@@ -180,9 +183,9 @@ struct SortShape { int nt, chunk; size_t lds; };
 SortShape  sort_shape(int bins, bool attr);   // workgroup shape of a pass with that many bins
 hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, const LaunchEvents ev[9]);   // project, scan, scatter | count, scan, scatter | (count, scan, scatter)
 hipError_t launch_walk(hipStream_t st, const WalkArgs& a, int flags, LaunchEvents ev);                    // cell-sorted records
+hipError_t launch_block_prefix(hipStream_t st, uint32_t* blk_cnt, int n_blocks, uint2* ranges);   // ranges[b] = {first, end} of block b in the sorted records; leaves blk_cnt zero
 hipError_t launch_block_walk(hipStream_t st, const WalkArgs& a, int flags, LaunchEvents ev);              // block-sorted records
 constexpr int kOnePassMaxBins = 2048;  // block-sorted: maps of up to this many blocks are sorted by ONE counting-sort pass
-hipError_t launch_block_ranges(hipStream_t st, const uint32_t* keys, const uint32_t* n_records, long long max_records, int id_bits, uint2* ranges);
 hipError_t launch_strip_bounds(hipStream_t st, const uint32_t* keys, const uint32_t* n_records, int id_bits, const uint32_t* ids, uint32_t* out, int n);
 constexpr int kSortChunkRecords = 4096, kSortSegsPerChunk = 4;   // records per counting-sort chunk; 1024-point wave segments per pass-1 chunk (seg_cnt words)
 constexpr int kSortMaxBins = 8000;     // bins per pass the sorted pipeline handles (LDS of k_sort_scatter)

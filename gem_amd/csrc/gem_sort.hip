@@ -135,8 +135,10 @@ __global__ __launch_bounds__(256, (SRC == 4 ? 4 : (SRC == 2 ? 3 : 1))) void k_so
     constexpr int NT = 256, CH = kSortChunk, K = CH / NT;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_sort[];
     uint32_t* hist = lds_sort;                                         // [bins0]
+    __shared__ uint32_t btag[NT], bcnt[NT];                            // the chunk's records per block, direct-mapped by the block id's low bits (a.blk_cnt)
     const int tid = (int)threadIdx.x, chunk = (int)blockIdx.x;
     for (int i = tid; i < a.dbins[0]; i += NT) hist[i] = 0u;
+    btag[tid] = 0xffffffffu; bcnt[tid] = 0u;
     if (chunk == 0 && tid == 0) *a.total = 0u;                         // k_sort_scan of this pass adds the column totals up
     ChunkRange cr = chunk_range<CH>(a.sweep_chunk0, a.sweep_first, a.sweep_orig0, a.n_sweeps, a.n, chunk);
     if (!a.sweep_chunk0) cr.orig0 = a.orig0_single;                    // (a single sweep whose head another device holds)
@@ -182,8 +184,11 @@ __global__ __launch_bounds__(256, (SRC == 4 ? 4 : (SRC == 2 ? 3 : 1))) void k_so
             // Histogram.  With a coarse digit (the blocks of the block-sorted form) consecutive points of a scan share their bin, and
             // 64 lanes adding 1 to one LDS word take 64 turns: a lane adds for its whole RUN of equal neighbours instead (the run's
             // first lane, found with one DPP shift and one ballot; a bin that comes back later in the wave simply adds twice).
+            // The runs are runs of one BLOCK (d0shift >= 8: the digit is part of the block id): the same lane also adds its run to the
+            // block's record count in HBM (a.blk_cnt, when the last pass's bins are not the blocks: launch_block_prefix turns the
+            // counts into every block's range in the sorted records, instead of a pass over the sorted keys).
             if (d0shift != 0u) {                                       // block-uniform
-                const uint32_t kb = b.valid ? bin : 0xffffffffu;
+                const uint32_t kb = b.valid ? (b.id >> 8) : 0xffffffffu;
                 const uint32_t pv = wave_prev(kb);
                 const bool head = (tid & 63) == 0 || kb != pv;
                 const uint64_t heads = __ballot(head);
@@ -191,6 +196,14 @@ __global__ __launch_bounds__(256, (SRC == 4 ? 4 : (SRC == 2 ? 3 : 1))) void k_so
                     const uint64_t later = (tid & 63) == 63 ? 0ull : heads >> ((tid & 63) + 1);
                     const uint32_t run = later ? (uint32_t)__ffsll((unsigned long long)later) : 64u - (uint32_t)(tid & 63);
                     atomicAdd(&hist[bin], run);
+                    if (a.blk_cnt) {
+                        // (through the LDS first: a chunk's 4096 points make hundreds of runs in a few dozen blocks -- C5: 2.5 M atomics
+                        //  to HBM cost the kernel 11 us of its 55)
+                        const uint32_t slot = kb & (uint32_t)(NT - 1);
+                        const uint32_t old = atomicCAS(&btag[slot], 0xffffffffu, kb);
+                        if (old == 0xffffffffu || old == kb) atomicAdd(&bcnt[slot], run);
+                        else __hip_atomic_fetch_add(a.blk_cnt + kb, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             } else if (b.valid) atomicAdd(&hist[bin], 1u);
             kept += (uint32_t)__popcll(m);
@@ -199,6 +212,7 @@ __global__ __launch_bounds__(256, (SRC == 4 ? 4 : (SRC == 2 ? 3 : 1))) void k_so
     if ((tid & 63) == 0) a.seg_cnt[(size_t)chunk * kSortSegsPerChunk + (tid >> 6)] = kept;
     __syncthreads();
     for (int i = tid; i < a.dbins[0]; i += NT) a.cnt[0][(size_t)chunk * a.dbins[0] + i] = hist[i];
+    if (a.blk_cnt && btag[tid] != 0xffffffffu) __hip_atomic_fetch_add(a.blk_cnt + btag[tid], bcnt[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -310,8 +324,26 @@ __global__ __launch_bounds__(NT) void k_sort_count(PassArgs a)
 #pragma unroll
     for (int k = 0; k < K; ++k) { const uint32_t i = base + k * 64; key[k] = a.key_in[i < M ? i : M - 1u]; }
     __syncthreads();
+    // (a lane adds for its whole run of equal neighbours, as in k_sort_project: the higher digit of a block id is the same for
+    //  hundreds of consecutive records of the pass before, and 64 lanes adding 1 to one LDS word take 64 turns -- C5: 23 -> 8 us)
+    if (a.coherent) {                                                  // block-uniform
 #pragma unroll
-    for (int k = 0; k < K; ++k) if (base + k * 64 < M) atomicAdd(&hist[(key[k] >> a.shift) & a.mask], 1u);
+        for (int k = 0; k < K; ++k) {
+            const bool on = base + k * 64 < M;
+            const uint32_t bin = (key[k] >> a.shift) & a.mask;
+            const uint32_t kb = on ? bin : 0xffffffffu;
+            const uint32_t pv = wave_prev(kb);                         // (every lane takes part: a DPP read of a lane that sits out is undefined)
+            const bool head = (tid & 63) == 0 || kb != pv;
+            const uint64_t heads = __ballot(head);
+            if (head && on) {
+                const uint64_t later = (tid & 63) == 63 ? 0ull : heads >> ((tid & 63) + 1);
+                atomicAdd(&hist[bin], later ? (uint32_t)__ffsll((unsigned long long)later) : 64u - (uint32_t)(tid & 63));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) if (base + k * 64 < M) atomicAdd(&hist[(key[k] >> a.shift) & a.mask], 1u);
+    }
     __syncthreads();
     for (int i = tid; i < a.bins; i += NT) a.cnt[(size_t)chunk * a.bins + i] = hist[i];
 }
@@ -1161,29 +1193,32 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
     }
 }
 
-// Where every block's records are in a device's BLOCK-sorted records: ranges[b] = {first record, one past the last}; a block without
-// records keeps {0, 0} (the array is zeroed before).  One look at every key and its predecessor's: a block ends and the next
-// begins where the block id changes.  Used when the last pass's bins are not the blocks (maps of more than kOnePassMaxBins blocks)
-// -- the multi-GPU strip owners get the ranges of every source with its records and never search.
-__global__ __launch_bounds__(256) void k_block_ranges(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ n_records, int id_bits,
-                                                      uint2* __restrict__ ranges)
+// Where every block's records are in a device's BLOCK-sorted records: ranges[b] = {first record, one past the last}, from the per-block
+// record counts k_sort_project left in blk_cnt: an exclusive prefix (the sorted order is the order of the block ids).  Used when the
+// last pass's bins are not the blocks (maps of more than kOnePassMaxBins blocks); the multi-GPU strip owners get the ranges of every
+// source with its records and never search.  (Before: a pass over the sorted keys looking for the places where the block id changes,
+// 12 us + a 4 us memset for C5.)  One workgroup; the counts are zeroed on the way out -- the buffer is zero between passes, like the tile pipeline's tables.
+__global__ __launch_bounds__(1024) void k_block_prefix(uint32_t* __restrict__ blk_cnt, int n_blocks, uint2* __restrict__ ranges)
 {
-    const uint32_t M = *n_records, idmask = (1u << id_bits) - 1u;
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= M) return;
-    const uint32_t b = (keys[i] & idmask) >> 8;
-    const uint32_t prev = i ? (keys[i - 1u] & idmask) >> 8 : 0xffffffffu;
-    if (b != prev) {
-        ranges[b].x = i;
-        if (i) ranges[prev].y = i;
+    __shared__ uint32_t scratch[16];
+    const int tid = (int)threadIdx.x, per = (n_blocks + 1023) / 1024;
+    const int b0 = min(tid * per, n_blocks), b1 = min(b0 + per, n_blocks);
+    uint32_t sum = 0;
+    for (int b = b0; b < b1; ++b) sum += blk_cnt[b];
+    uint32_t all;
+    uint32_t at = block_exclusive_scan<1024>(sum, scratch, &all);
+    for (int b = b0; b < b1; ++b) {
+        const uint32_t c = blk_cnt[b];
+        ranges[b] = make_uint2(at, at + c);
+        blk_cnt[b] = 0u;
+        at += c;
     }
-    if (i + 1u == M) ranges[b].y = M;
 }
 
-hipError_t launch_block_ranges(hipStream_t st, const uint32_t* keys, const uint32_t* n_records, long long max_records, int id_bits, uint2* ranges)
+hipError_t launch_block_prefix(hipStream_t st, uint32_t* blk_cnt, int n_blocks, uint2* ranges)
 {
-    if (max_records <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_block_ranges, dim3((unsigned)((max_records + 255) / 256)), dim3(256), 0, st, keys, n_records, id_bits, ranges);
+    if (n_blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_block_prefix, dim3(1), dim3(1024), 0, st, blk_cnt, n_blocks, ranges);
     return hipGetLastError();
 }
 
@@ -1306,6 +1341,7 @@ hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, co
     const bool last0 = a.n_passes == 1;
     p.bin_base = last0 ? a.bin_base : nullptr; p.counters = last0 ? a.counters : nullptr;
     const bool coherent = a.dshift[0] >= 8 || a.rank_by_ballot;                          // block-sorted form: coarse digits, few bins per wave instruction
+    p.coherent = coherent ? 1 : 0;
     if ((e = launch_pass(st, sh[0], p, attr, coherent, a.n_chunks1, false, ev[2])) != hipSuccess) return e;
     // ---- the higher digits: count, scan, scatter on the records of the pass before (ping-pong between the arrays); the
     //      live chunks are known on the device only
@@ -1353,9 +1389,22 @@ static hipError_t launch_block_walk_fmb(hipStream_t st, const WalkArgs& a, Launc
 constexpr int kBlkBatch = 2048;   // records of a block staged in LDS per round: three workgroups per CU (4096: two per CU, half the rounds
                                   // for the blocks under the sensor -- whose chains stay as long; C4 104 -> 116 us per batch)
 
+constexpr int kBlkBatchLight = 512;   // ... for passes whose blocks hold a few hundred records each (C5: 10 M points over 22 500 blocks): a quarter of the
+                                      // ranking / staging steps per round and five workgroups per CU
+
 template <int FLAGS>
 static hipError_t launch_block_walk_f(hipStream_t st, const WalkArgs& a, int mode, LaunchEvents ev)
 {
+    if constexpr (FLAGS == 0) {
+        if (a.light_blocks) {
+            switch (mode) {
+            case 0:  return launch_block_walk_fmb<FLAGS, 0, kBlkBatchLight>(st, a, ev);
+            case 1:  return launch_block_walk_fmb<FLAGS, 1, kBlkBatchLight>(st, a, ev);
+            case 2:  return launch_block_walk_fmb<FLAGS, 2, kBlkBatchLight>(st, a, ev);
+            default: return launch_block_walk_fmb<FLAGS, 3, kBlkBatchLight>(st, a, ev);
+            }
+        }
+    }
     switch (mode) {
     case 0:  return launch_block_walk_fmb<FLAGS, 0, kBlkBatch>(st, a, ev);
     case 1:  return launch_block_walk_fmb<FLAGS, 1, kBlkBatch>(st, a, ev);
