@@ -872,7 +872,7 @@ template <int B, bool KEYED, bool ATTR>
 __host__ __device__ constexpr size_t block_walk_lds()
 {
     return (size_t)B * 8 + (KEYED ? (size_t)B * 2 : 0) + (ATTR ? (size_t)B * 4 : 0)                     // staged batch
-           + (size_t)4 * 320 * 4 + (size_t)4 * 320 * 8 + (size_t)4 * 256 * 4;                           // cursors, masks, bases
+           + (size_t)4 * 320 * 4 + (B > 512 ? (size_t)4 * 320 * 8 : 0) + (size_t)4 * 256 * 4;           // cursors, masks (rounds of more than 512 records), bases
 }
 
 template <int FLAGS, int MODE, int B>
@@ -885,8 +885,13 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
     static_assert(NW == 4 && K >= 1 && K <= 32 && B <= 65536, "batch geometry");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_sort[];
     uint2* st_hv = reinterpret_cast<uint2*>(lds_sort);                                  // [B]   the batch, ordered by cell
-    unsigned long long* wpm = reinterpret_cast<unsigned long long*>(st_hv + B);         // [NW][320] who shares my cell in this wave instruction
-    uint32_t* wcur = reinterpret_cast<uint32_t*>(wpm + NW * 320);                       // [NW][320] records of (wave, cell) so far
+    // Light rounds (B <= 512: blocks of a few hundred records, one or two wave instructions per wave and round) match the lanes of
+    // equal cells by BALLOT, one per bit of the cell number -- 24 scalar / vector instructions per step instead of three LDS round
+    // trips -- and keep no mask table: 18 KB of LDS per workgroup instead of 28, eight workgroups per CU instead of five (C5's walk alone
+    // 114 -> 111 us, 153 -> 133 beside the sort chains; the call's period did not move: it is the sum of the kernels' work).
+    constexpr bool BALLOT = B <= 512;
+    unsigned long long* wpm = reinterpret_cast<unsigned long long*>(st_hv + B);         // [NW][320] who shares my cell in this wave instruction (!BALLOT)
+    uint32_t* wcur = reinterpret_cast<uint32_t*>(wpm + (BALLOT ? 0 : NW * 320));        // [NW][320] records of (wave, cell) so far
     uint32_t* cbase = wcur + NW * 320;                                                  // [NW][256] where the run of (wave, cell) starts in the batch
     uint32_t* st_src = cbase + NW * 256;                                                // [B] (ATTR)
     uint16_t* st_sw = reinterpret_cast<uint16_t*>(st_src + (ATTR ? B : 0));             // [B] (KEYED) the record's sweep
@@ -976,7 +981,7 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         __syncthreads();
         if (tid == 0) { uint32_t o = 0; for (int s = 0; s < n_src; ++s) { seg_off[s] = o; o += cbase[s]; } seg_off[n_src] = o; }
     }
-    for (int i = tid; i < NW * 320; i += NT) { wcur[i] = 0u; wpm[i] = 0ull; }
+    for (int i = tid; i < NW * 320; i += NT) { wcur[i] = 0u; if constexpr (!BALLOT) wpm[i] = 0ull; }
     __syncthreads();
     const uint32_t R = seg_off[n_src];                                 // records of this block, all sources
     if (R == 0 && !a.dense) return;                                    // block-uniform
@@ -1073,10 +1078,15 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
             peers[k] = 0ull;
             if ((uint32_t)k < steps) {
                 const bool valid = in_batch(k, steps, nb);
-                unsigned long long* m = wpm_w + (valid ? (key[k] & 255u) : 256u + (uint32_t)lane);   // no branch: a lane without a record has a slot of its own
-                __hip_atomic_fetch_or(m, mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                peers[k] = (uint64_t)__hip_atomic_load(m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store(m, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);           // for the next step (every lane of the group: the same value)
+                if constexpr (BALLOT) {
+                    const uint64_t p = wave_peers(valid, key[k] & 255u, 8);
+                    peers[k] = valid ? p : mybit;                      // (a lane without a record: a group of its own, as below)
+                } else {
+                    unsigned long long* m = wpm_w + (valid ? (key[k] & 255u) : 256u + (uint32_t)lane);   // no branch: a lane without a record has a slot of its own
+                    __hip_atomic_fetch_or(m, mybit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    peers[k] = (uint64_t)__hip_atomic_load(m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(m, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);       // for the next step (every lane of the group: the same value)
+                }
             }
         }
 #pragma unroll
