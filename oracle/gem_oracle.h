@@ -19,8 +19,11 @@
  *   (2) by the hand-derived known-answer tests in tests/test_oracle_kat.py;
  *   (3) by the golden fixtures it generated itself (tests/golden/, scripts committed).
  * Not covered by (1): Eigen's internal evaluation order (restated identically in the stand-in and here), nvcc's FMA
- * contraction (a build-flag effect; source-level arithmetic is what is replayed), the structured-light / stereo /
- * perfect sensor models and the motion updater (CPU-side C++ of the reference that needs kindr + ROS).
+ * contraction (a build-flag effect; source-level arithmetic is what is replayed).
+ *   (1b) the structured-light / stereo / perfect sensor models against the reference's OWN *SensorProcessor.cpp, and the
+ *       motion updater against its RobotMotionMapUpdater.cpp, each compiled where it lies against stand-ins for Eigen / kindr /
+ *       PCL / ROS / TF (oracle/ref_build/sensors, oracle/ref_build/motion -> oracle/_ref/libgem_ref_sensors.so,
+ *       libgem_ref_motion.so): tests/test_reference_sensor_models.py, tests/test_motion_update.py.
  *
  * Build with -ffp-contract=off: every float product and sum below is individually rounded.
  */

@@ -154,6 +154,45 @@ def motion_lib():
     return _motion_lib
 
 
+_sensor_lib = None
+
+
+def sensor_lib():
+    """oracle/_ref/libgem_ref_sensors.so: the reference's Perfect / Stereo / StructuredLight SensorProcessor.cpp (build_ref.build_sensors)."""
+    global _sensor_lib
+    if _sensor_lib is None:
+        import build_ref
+        path = build_ref.build_sensors()
+        if path is None:
+            return None
+        l = C.CDLL(str(path))
+        l.gemref_sensor_variances.restype = c_int
+        l.gemref_sensor_variances.argtypes = [c_int, POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double), POINTER(c_double),
+                                              c_int, POINTER(c_float), POINTER(c_float), POINTER(c_float), c_int, POINTER(c_int), POINTER(c_float)]
+        _sensor_lib = l
+    return _sensor_lib
+
+
+def sensor_variances(model: int, params, rotation_map_to_base, rotation_base_to_sensor, translation_base_to_sensor, pose_covariance,
+                     x, y, z, original_width: int = 0, indices=None) -> np.ndarray:
+    """What the reference's own computeVariances writes for a cloud (model: 1 structured light, 2 stereo, 3 perfect).  The rotations
+    are what SensorProcessorBase::updateTransformations stores (SPB.cpp:110-117); pose_covariance is the 6x6 robot pose covariance."""
+    l = sensor_lib()
+    dp = lambda a, n: np.ascontiguousarray(np.asarray(a, np.float64).reshape(-1)[:n] if n else np.asarray(a, np.float64).reshape(-1))
+    prm = np.zeros(8, np.float64); prm[:len(params)] = params
+    cbm, csb, t, cov = dp(rotation_map_to_base, 9), dp(rotation_base_to_sensor, 9), dp(translation_base_to_sensor, 3), dp(pose_covariance, 36)
+    xs, ys, zs = (np.ascontiguousarray(v, np.float32) for v in (x, y, z))
+    n = xs.size
+    idx = np.ascontiguousarray(np.arange(n) if indices is None else indices, np.int32)
+    out = np.empty(n, np.float32)
+    p = lambda a, t_: a.ctypes.data_as(POINTER(t_))
+    rc = l.gemref_sensor_variances(int(model), p(prm, c_double), p(cbm, c_double), p(csb, c_double), p(t, c_double), p(cov, c_double), n,
+                                   p(xs, c_float), p(ys, c_float), p(zs, c_float), int(original_width), p(idx, c_int), p(out, c_float))
+    if rc != n:
+        raise RuntimeError(f"gemref_sensor_variances returned {rc}")
+    return out
+
+
 def quaternion_from_matrix(R) -> np.ndarray:
     """Hamilton unit quaternion (w, x, y, z), w >= 0, of a rotation matrix."""
     R = np.asarray(R, np.float64)

@@ -100,6 +100,44 @@ def build_motion(reference: Path = Path("/root/reference"), force: bool = False,
     return OUT_MOTION
 
 
+OUT_SENSORS = HERE.parent / "_ref" / "libgem_ref_sensors.so"
+REL_SENSORS = "elevation_mapping/elevation_mapping/src/sensor_processors"
+SENSOR_FILES = ["PerfectSensorProcessor.cpp", "StereoSensorProcessor.cpp", "StructuredLightSensorProcessor.cpp"]
+
+
+def build_sensors(reference: Path = Path("/root/reference"), force: bool = False, verbose: bool = False) -> Path | None:
+    """oracle/_ref/libgem_ref_sensors.so: the reference's Perfect / Stereo / StructuredLight SensorProcessor.cpp (and their own
+    headers, point structs included) compiled where they lie against the stand-ins under sensors/ for what is not installed here --
+    Eigen, kindr, PCL, ROS, TF.  The noise models (computeVariances: the sensor covariance of every point, the Jacobians, the error
+    propagation) are the reference's text; nothing of it is copied.  (LaserSensorProcessor.cpp is left out: its CPU loop is commented
+    out in the reference, the laser model lives in gpu_process.cu -- libgem_ref.so.)  `private` / `protected` are lifted for the
+    reference's files so that the harness can set the transformation members TF would have filled."""
+    srcs = [reference / REL_SENSORS / f for f in SENSOR_FILES]
+    if not all(s.exists() for s in srcs):
+        return OUT_SENSORS if OUT_SENSORS.exists() else None
+    m = HERE / "sensors"
+    deps = srcs + [Path(__file__)] + [f for f in m.rglob("*") if f.is_file()]
+    if OUT_SENSORS.exists() and not force and all(OUT_SENSORS.stat().st_mtime >= d.stat().st_mtime for d in deps):
+        return OUT_SENSORS
+    OUT_SENSORS.parent.mkdir(exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        tu = Path(tmp) / "gem_ref_sensors_tu.cpp"
+        std = "\n".join(f"#include <{h}>" for h in ("cmath", "cstdint", "iostream", "limits", "memory", "string", "unordered_map", "vector",
+                                                    "Eigen/Core", "kindr/Core", "ros/ros.h", "tf/transform_listener.h", "pcl/point_cloud.h",
+                                                    "pcl/filters/filter.h", "pcl/filters/passthrough.h", "boost/shared_ptr.hpp"))
+        body = "\n".join(f'#include "{s}"' for s in srcs)
+        tu.write_text(f'{std}\n#define private public\n#define protected public\n{body}\n#undef private\n#undef protected\n'
+                      f'#include "{m / "sensor_exports.inc"}"\n')
+        cmd = ["g++", "-O2", "-ffp-contract=off", "-fno-fast-math", "-std=c++14", "-w", "-fPIC", "-shared",
+               f"-I{m}", f"-I{reference / REL_INCLUDE}", str(tu), "-o", str(OUT_SENSORS)]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("g++ failed on the reference's sensor processors:\n" + res.stderr[-6000:])
+    return OUT_SENSORS
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -109,3 +147,5 @@ if __name__ == "__main__":
     print(p if p else "reference not found and no prebuilt library", file=sys.stderr if not p else sys.stdout)
     p = build_motion(Path(a.reference), a.force, verbose=True)
     print(p if p else "reference not found and no prebuilt motion library", file=sys.stderr if not p else sys.stdout)
+    p = build_sensors(Path(a.reference), a.force, verbose=True)
+    print(p if p else "reference not found and no prebuilt sensor-model library", file=sys.stderr if not p else sys.stdout)

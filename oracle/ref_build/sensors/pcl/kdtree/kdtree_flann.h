@@ -1,0 +1,2 @@
+// pcl/kdtree/kdtree_flann.h -- stand-in, TEST INFRASTRUCTURE ONLY: nothing of it is used by the code under test.
+#pragma once

@@ -1,0 +1,2 @@
+// pcl/search/impl/kdtree.hpp -- stand-in, TEST INFRASTRUCTURE ONLY: nothing of it is used by the code under test.
+#pragma once

@@ -336,9 +336,9 @@ def test_all_core_oracle_equals_the_sequential_one(oracle_mod):
 
 
 # ---- the reference's CPU noise models (SL.cpp:121-153, Stereo.cpp:72-104, Perfect.cpp:74-102): closed forms ------------------
-# The reference never calls these on its GPU path and nothing in its tree pins their outputs; kindr / PCL / ROS are absent, so they
-# cannot be compiled here either.  What pins the oracle's restatement (and, in tests/test_parity_gpu.py, the kernel's) are these
-# hand-derived cases: with a level sensor (J_s = e_z, no rotation variance) the height variance IS the normal variance of the
+# The reference never calls these on its GPU path and nothing in its tree pins their outputs.  tests/test_reference_sensor_models.py
+# compares the oracle with the reference's own files compiled against stand-ins for Eigen / kindr / PCL / ROS; these hand-derived
+# cases are the independent check (of the oracle's restatement and, in tests/test_parity_gpu.py, of the kernel's): with a level sensor (J_s = e_z, no rotation variance) the height variance IS the normal variance of the
 # model, with the sensor's x axis along map z it is the lateral one -- each a closed formula of the point, evaluated here in
 # plain Python from the reference's source lines.
 def model_frame(kind, params, Js=(0, 0, 1), width=0):
