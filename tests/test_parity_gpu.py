@@ -581,7 +581,8 @@ def test_lowest_tracking_and_raytracing(oracle_mod, ref_mod, monkeypatch, L, res
     assert deleted > 20
 
 
-@pytest.mark.parametrize("L,res,pos", [(300, 0.05, (3.37, -2.11, 0.62)), (251, 0.1, (-7.05, 4.4, 1.3)), (64, 0.1, (0.0, 0.0, 0.4)), (33, 0.2, (1.0, 1.0, 0.9))])
+@pytest.mark.parametrize("L,res,pos", [(300, 0.05, (3.37, -2.11, 0.62)), (251, 0.1, (-7.05, 4.4, 1.3)), (64, 0.1, (0.0, 0.0, 0.4)), (33, 0.2, (1.0, 1.0, 0.9)),
+                                       (1201, 0.05, (11.3, -17.9, 0.8))])
 def test_raytracing_walks_split_over_lanes(oracle_mod, L, res, pos):
     """k_raytracing hands one walk to several lanes, each starting in the middle of it (closed-form state of the border-distance
     merge): every lane count / look-ahead depth must leave the map the oracle's one-thread-per-cell walk leaves.  Dense random
