@@ -97,6 +97,7 @@ struct gem_handle {
     long long sort_min_points = 200000, sort_min_points_batch = 390000;
     bool walk_permute = true;           // k_fuse_walk: blocks take the tile rows centre-first
     int  sort_passes = 0;               // 0 = by map size and form (sort_geometry); 1 / 2 / 3 force it
+    int few_bins = 0;                   // k_sort_scatter's ballots per wave instruction before the LDS way (0 = the built-in 8; debug knob)
     int blk_batch = 0;                  // k_fuse_block's round: 0 = by the pass's mean block load, 512 / 2048 forced (debug knob)
     int ray_depth = 4, ray_lanes = 16;  // k_raytracing: loads in flight per lane, lanes per ray (debug knobs; 16 x 4 measured best on C2)
     bool fast_laser = true;             // frames that qualify use the zero-rotation-variance form of the laser variance (fill_frame; debug knob)
@@ -580,7 +581,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     sa.f_index = in.f_index; sa.f_height = in.f_height; sa.f_var = in.f_var;
     sa.f_R = in.f_R; sa.f_G = in.f_G; sa.f_B = in.f_B; sa.f_I = in.f_I;
     sa.keep_sentinel = h->track_lowest ? 1 : 0;
-    sa.rank_by_ballot = h->rank_by_ballot ? 1 : 0;
+    sa.rank_by_ballot = h->rank_by_ballot ? 1 : 0; sa.few_bins = h->few_bins;
     sa.tiles_per_row = geo.tiles_per_row; sa.T = T;
     sa.id_bits = geo.id_bits; sa.n_passes = geo.n_passes;
     for (int i = 0; i < 3; ++i) { sa.dshift[i] = geo.dshift[i]; sa.dbits[i] = geo.dbits[i]; sa.dbins[i] = geo.dbins[i]; }
@@ -1758,6 +1759,7 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "rank_by_ballot")     h->rank_by_ballot = value != 0;
     else if (k == "lane_sort")          h->lane_sort = value != 0;
     else if (k == "blk_batch")          h->blk_batch = (int)value;
+    else if (k == "few_bins")           h->few_bins = (int)value;
     else if (k == "ray_depth")          h->ray_depth = (int)value;
     else if (k == "ray_lanes")          h->ray_lanes = (int)value;
     else if (k == "fast_laser")         h->fast_laser = value != 0;

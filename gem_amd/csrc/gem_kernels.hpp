@@ -114,6 +114,7 @@ struct SortArgs {
     const int* f_index; const float* f_height; const float* f_var;                    // SRC 1: Fuse()'s arrays (GPU:1154)
     const int* f_R; const int* f_G; const int* f_B; const float* f_I;
     int keep_sentinel;                 // keep records with h == -1 (GPU:482) for the LOWEST walk
+    int few_bins;                      // 0 = kFewBins (debug knob)
     int rank_by_ballot;                // k_sort_scatter matches equal bins by ballot in every pass (what coarse digits take anyway; debug knob:
                                        // the two ways of ranking -- through the LDS and by ballot -- are checked against each other by the tests)
     CameraConst cam;                   // SRC 3 (input colourisation): id = the pixel a point samples, record = {point index, 0}
@@ -145,6 +146,7 @@ struct PassArgs {
     const int* sweep_chunk0; const long long* sweep_first; int n_sweeps;   // pass 1 of a batched call: sweep-aligned chunks
     uint32_t* bin_base;                          // last pass: [bins + 1] published by workgroup 0
     unsigned long long* counters;
+    int few_bins;                                // COHERENT ranking: ballots per wave instruction before the LDS way takes over (kFewBins)
     int coherent;                                // coarse digits (block-sorted form): consecutive records mostly share their bin
 };
 

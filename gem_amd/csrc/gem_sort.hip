@@ -299,7 +299,7 @@ __global__ __launch_bounds__(1024) void k_sort_scan(uint32_t* __restrict__ cnt, 
 //   * BY BALLOT (COHERENT: the coarse digits of the block-sorted form, where the 64 consecutive records of a wave instruction
 //     fall into a handful of bins and 64 lanes hitting one LDS word would take 64 turns): one ballot per distinct bin, taken
 //     from the first lane still unmatched; a step with more than kFewBins distinct bins falls back to the LDS way.
-constexpr int kFewBins = 8;
+constexpr int kFewBins = 4;       // (C5's first pass: 8 ballots 68 us, 4 62, 16 84 -- past a few keys the LDS way is the cheaper one)
 
 // words of LDS the ranking phase of k_sort_scatter needs: per wave a cursor per bin, a name byte per bin (+ 64), 64 masks
 __host__ __device__ constexpr size_t slot_words(int bins) { return (size_t)((bins + 3) / 4) + 16; }   // name bytes of the bins + 64 spare ones (lanes without a record)
@@ -405,12 +405,19 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void k_sort_scatter(PassAr
 #pragma unroll
         for (int k = 0; k < K; ++k) { valid[k] = key[k] != kKeyInvalid; bin[k] = (key[k] >> a.shift) & a.mask; }
         if constexpr (COHERENT) {
+            // (tried: the steps the ballots do not settle going through the LDS together afterwards, phase by phase like the other way
+            //  below -- the flags and names of eight steps cost more registers than the overlapped round trips save: C5's first pass
+            //  62.9 -> 67.4 us)
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 uint64_t rem = __ballot(valid[k]);
                 peers[k] = 0ull;
+                // (few_bins < 0: one ballot per digit BIT instead -- no loop over the distinct bins, no LDS; the first of several passes
+                //  sees the records in input order, a dozen blocks in 64 lanes at long range: C5 62.8 -> 55.6 us; later passes see one
+                //  or two bins per instruction and keep the loop: 43.9 against 46.1; C4's single 11-bit pass is even)
+                if (a.few_bins < 0) { peers[k] = wave_peers(valid[k], bin[k], a.digit_bits); rem = 0ull; }
 #pragma unroll 1
-                for (int it = 0; it < kFewBins && rem != 0; ++it) {    // wave-uniform
+                for (int it = 0; it < a.few_bins && rem != 0; ++it) {  // wave-uniform
                     const uint32_t kb = (uint32_t)__builtin_amdgcn_readlane((int)bin[k], __ffsll((unsigned long long)rem) - 1);
                     const bool mine = valid[k] && bin[k] == kb;
                     const uint64_t same = __ballot(mine);
@@ -1368,6 +1375,7 @@ hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, co
     p.bin_base = last0 ? a.bin_base : nullptr; p.counters = last0 ? a.counters : nullptr;
     const bool coherent = a.dshift[0] >= 8 || a.rank_by_ballot;                          // block-sorted form: coarse digits, few bins per wave instruction
     p.coherent = coherent ? 1 : 0;
+    p.few_bins = a.few_bins != 0 ? a.few_bins : (a.n_passes > 1 && a.dbits[0] <= 8 ? -1 : kFewBins);
     if ((e = launch_pass(st, sh[0], p, attr, coherent, a.n_chunks1, false, ev[2])) != hipSuccess) return e;
     // ---- the higher digits: count, scan, scatter on the records of the pass before (ping-pong between the arrays); the
     //      live chunks are known on the device only
@@ -1380,6 +1388,7 @@ hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, co
         p.mask = (1u << a.dbits[i]) - 1u;
         p.n_dev = a.total; p.n_host = 0; p.sweep_chunk0 = nullptr; p.sweep_first = nullptr; p.n_sweeps = 1; p.seg_cnt = nullptr;
         p.bin_base = last ? a.bin_base : nullptr; p.counters = last ? a.counters : nullptr;
+        p.few_bins = a.few_bins != 0 ? a.few_bins : kFewBins;
         if ((e = launch_pass(st, sh[i], p, attr, coherent, grid, true, ev[3 * i])) != hipSuccess) return e;
         GEM_LAUNCH(k_sort_scan, dim3((a.dbins[i] + 63) / 64, kScanSegs), dim3(1024), 0, st, ev[3 * i + 1], a.cnt[i], a.segtot[i], a.dbins[i], 0,
                    (const uint32_t*)a.total, (uint32_t*)nullptr);

@@ -21,7 +21,8 @@ extern "C" {
  *       zero-rotation-variance form of the laser variance for frames that qualify), "rank_by_ballot" (0/1: k_sort_scatter matches equal bins by ballot in every pass instead
  *       of through the LDS), "lane_sort" (0/1: k_fuse_block hands the
  *       cells to the threads by record count), "blk_batch" (0 = by the pass's mean block load, 512 / 2048: records k_fuse_block
- *       stages per round), "ray_lanes" (1, 4, 8, 16: lanes of a wave that share one walk of gem_raytracing) and
+ *       stages per round), "few_bins" (0 = by pass; n > 0: ballots per wave instruction before k_sort_scatter's coherent ranking takes the
+ *       LDS way; < 0: one ballot per digit bit), "ray_lanes" (1, 4, 8, 16: lanes of a wave that share one walk of gem_raytracing) and
  *       "ray_depth" (4, 8: steps a lane walks ahead of the loads it waits for), "walk_permute" (0/1),
  *       "sort_streams" (1, 2: binning streams consecutive overlapped passes of the sorted pipeline alternate between), "sort_ring" (2..4: the buffer sets they rotate through),
  *       "trace" (0/1: one line on stderr per pass of the sorted pipeline), "stream_roles" (a permutation of 0123 as a decimal
