@@ -1,3 +1,6 @@
+#!/bin/bash
+# One consolidated validation / evidence run on the MI355X box (through gpurun): the GPU suite, the contract bench, every configuration,
+# the rocprofv3 summaries per configuration, the soak.  Outputs under gpurun_out/ (copy what should be judged into profiles/).
 set -u
 mkdir -p gpurun_out/final
 timeout -s KILL 900 python -m pytest tests -m gpu -x -q > gpurun_out/final/pytest_gpu.log 2>&1; tail -3 gpurun_out/final/pytest_gpu.log
@@ -8,4 +11,5 @@ timeout -s KILL 500 bash tools/profile_one.sh r03 c4 > gpurun_out/final/prof_c4.
 timeout -s KILL 500 bash tools/profile_one.sh r03 c5 > gpurun_out/final/prof_c5.log 2>&1
 timeout -s KILL 400 bash tools/profile_one.sh r03 c2 > gpurun_out/final/prof_c2.log 2>&1
 timeout -s KILL 100 python tools/block_phases.py c4 > gpurun_out/final/c4_block_phases.txt 2>/dev/null
-ls gpurun_out/profiles | head -40
+timeout -s KILL 100 python tools/fuzz_parity.py --seconds 60 --seed 2 > gpurun_out/final/fuzz2.log 2>&1; tail -1 gpurun_out/final/fuzz2.log
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final/smoke.log 2>&1; tail -2 gpurun_out/final/smoke.log
