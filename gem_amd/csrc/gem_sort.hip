@@ -22,9 +22,11 @@
 //                   its keys gives the cell boundaries, then every lane streams its own cell's run through the reference's
 //                   recurrence (GPU:480-531), the sweeps' variance increments (GPU:540-547) and floors (GPU:533-534) replayed
 //                   per cell in between.
-//   BLOCK-sorted: digits over the block id (id >> 8: eight rows of a tile) only -- ONE pass for maps of up to 2048 blocks;
-//     k_fuse_block  one workgroup per block: the block's records, in input order, a batch at a time: ordered by cell in LDS
-//                   (stable), then every thread runs its cell's records of the batch from LDS; the cell state stays in registers.
+//   BLOCK-sorted: digits over the block id (id >> 8: eight rows of a tile) only -- ONE pass for maps of up to 2048 blocks, two for
+//     bigger ones (k_sort_project then also counts every block's records, k_block_prefix turns the counts into the blocks' ranges);
+//     k_fuse_block  one workgroup per block: the block's records, in input order, a round of 2048 (512 for light blocks) at a time:
+//                   ordered by cell in LDS (stable), then every thread runs its cell's records of the round from LDS; the cell
+//                   state stays in registers.
 //
 // Stability of every pass keeps ascending input order inside every cell; no float atomics.  A wave takes the time of its LONGEST
 // cell chain.  Algorithmic bytes: 16 B per point (read) + 16 B per distinct touched cell (+ 8 L^2 per dense variance pass).  What
