@@ -60,6 +60,7 @@ struct gem_handle {
     struct PassBuffers {
         Arena rec, srt, seg, flag, gflag;   // records, descriptor table, touched stamps per (tile, sweep) and per (sweep, tile, 32 units)
         Arena s_hv1, s_hv2, s_key1, s_key2, s_src1, s_src2, s_cnt1, s_cnt2, s_misc;   // the sorted pipeline of big passes (gem_sort.hip)
+        bool blkcnt_dirty = false;     // k_sort_project has been asked to count into s_blkcnt and k_block_prefix has not cleared it yet
         Arena s_blkcnt;                // [4 T] records per block, zero between passes (k_sort_project adds, k_block_prefix reads and clears)
         Arena s_ranges, s_shard;       // multi-GPU shard: every block's range in the sorted records; strip ids [16] | strip bounds [16]
         Arena tables;                  // batched-call tables (frames, sweep_unit0, sweep_first, var_updates)
@@ -596,6 +597,10 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     if ((geo.block_form && geo.n_passes > 1) || shard) {             // the walk will want every block's range (the last pass's bins are not the blocks)
         if ((rc = ensure_zeroed(h, pb.s_blkcnt, (size_t)4 * T * sizeof(uint32_t))) || (rc = ensure(h, pb.s_ranges, (size_t)4 * T * sizeof(uint2)))) return rc;
         sa.blk_cnt = static_cast<uint32_t*>(pb.s_blkcnt.p);
+        // the counts are zero between passes because k_block_prefix leaves them so; a pass that failed between the two leaves them
+        // dirty: cleared here before the next one counts
+        if (pb.blkcnt_dirty) GEM_HIP(h, hipMemsetAsync(pb.s_blkcnt.p, 0, pb.s_blkcnt.cap, sbin));
+        pb.blkcnt_dirty = true;
     }
     sa.seg_cnt = reinterpret_cast<uint32_t*>(misc + o_segcnt);
     // arrays a: the projected records in input order, later the final order; arrays b: the order after pass 1
@@ -666,6 +671,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
         GEM_HIP(h, hipMemcpyAsync(d_ids, host, sizeof(uint32_t) * (shard->nstrips + 1), hipMemcpyHostToDevice, sbin));
         GEM_HIP(h, launch_strip_bounds(sbin, keys, sa.total, geo.id_bits, d_ids, d_bounds, shard->nstrips + 1));
         GEM_HIP(h, launch_block_prefix(sbin, sa.blk_cnt, 4 * T, static_cast<uint2*>(pb.s_ranges.p)));
+        pb.blkcnt_dirty = false;
         sd.hv = final_b ? sa.hv_b : sa.hv_a; sd.key = keys; sd.ranges = static_cast<const uint2*>(pb.s_ranges.p);
         sd.d_bounds = d_bounds; sd.nstrips = shard->nstrips; sd.slot = overlap ? (int)slot : -1;
         h->stats.points_in = in.n;
@@ -685,6 +691,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
         // the last digit's bins hold several blocks: where every block's records are (the prefix of the per-block counts
         // k_sort_project took), behind the sort on its stream, instead of a search by every workgroup of the walk
         GEM_HIP(h, launch_block_prefix(sbin, sa.blk_cnt, 4 * T, static_cast<uint2*>(pb.s_ranges.p)));
+        pb.blkcnt_dirty = false;
         wa.ranges = static_cast<const uint2*>(pb.s_ranges.p);
     }
     if (overlap) {
