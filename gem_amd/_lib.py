@@ -97,6 +97,7 @@ DEBUG_SIGNATURES = {
     "gem_debug_set": (c_int, [c_void_p, c_char_p, c_longlong]),
     "gem_debug_get": (c_int, [c_void_p, c_char_p, POINTER(c_longlong)]),
     "gem_debug_fuse_stamps": (c_int, [c_void_p, c_int, c_void_p, c_int]),
+    "gem_comm_init_loopback": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int]),
 }
 
 _lib = None

@@ -513,6 +513,11 @@ class ElevationMap:
         buf = C.create_string_buffer(unique_id, 128)
         self._check(self._lib.gem_comm_init_tiles(self._h, buf, int(nranks), int(rank)), "gem_comm_init_tiles")
 
+    def comm_init_loopback(self, world_id: int, nranks: int, rank: int, tile_strips: bool = True) -> None:
+        """Join a LOOPBACK communicator (include/gem_hip_debug.h): `nranks` handles of this process on one device, each driven by
+        a thread of its own, run the multi-GPU path's code with device-to-device copies in place of the RCCL calls."""
+        self._check(self._lib.gem_comm_init_loopback(self._h, int(world_id), int(nranks), int(rank), int(bool(tile_strips))), "gem_comm_init_loopback")
+
     def strip(self):
         r0, r1 = C.c_int(), C.c_int()
         self._check(self._lib.gem_get_strip(self._h, C.byref(r0), C.byref(r1)), "gem_get_strip")

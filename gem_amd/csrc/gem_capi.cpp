@@ -8,6 +8,7 @@
 #include "../../include/gem_hip.h"
 #include "../../include/gem_hip_debug.h"
 #include "gem_kernels.hpp"
+#include "gem_transport.hpp"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -16,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -121,11 +123,15 @@ struct gem_handle {
     gem_stats stats{};
     hipEvent_t copy_done = nullptr;
 
-    ncclComm_t comm = nullptr;
+    // ---- multi-GPU.  Two communicators, each with a stream of its own: `tp_x` carries a step's boundary
+    //      all-gather and record exchange on `comm_stream`, `tp_g` the all-gather of the fused layers on `gather_stream` -- step
+    //      p + 1's exchange does not queue behind step p's 46 MB of layers.  (RCCL over xGMI; W handles of one process on one
+    //      device through the loopback of gem_transport.hpp in the tests.)
+    std::unique_ptr<Transport> tp_x, tp_g;
     int nranks = 1, rank = 0;
     int strip_row[kMaxRanks + 1] = {0};  // storage rows [strip_row[k], strip_row[k+1]) belong to rank k (gem_comm_init / gem_comm_init_tiles)
     bool tile_strips = false;           // strips are whole rows of 32x32 tiles (needed by the sharded path)
-    // multi-GPU, points sharded (gem_shard_sort_device / gem_shard_fuse_device / gem_add_sharded_device)
+    // points sharded (gem_shard_sort_device / gem_shard_fuse_device / gem_add_sharded_device)
     struct Shard {
         bool valid = false;
         const uint2* hv = nullptr; const uint32_t* key = nullptr;     // this device's sorted records
@@ -136,19 +142,46 @@ struct gem_handle {
         long long points = 0;                                          // points this device sorted for the step
         int slot = -1;                                                 // pass-buffer set the sort ran in on a binning stream (its bin_done / fuse_done events), -1: on the handle's stream
     } shard;
-    Arena sh_dev, sh_recv_hv, sh_recv_key, sh_recv_rng, sh_ranges;  // ids / bounds / gathered bounds / variance increments; records and block ranges received from the other ranks; own block ranges
-    // RCCL traffic (record exchange, all-gather of the fused strips) runs on a stream of its own, in the same order on every rank: the
-    // all-gather of step p -- from a PUBLISHED COPY of this rank's strip -- then overlaps the sort of step p + 1 on the handle's stream
-    hipStream_t comm_stream = nullptr;
-    hipEvent_t ev_sorted = nullptr, ev_exchanged = nullptr, ev_walked = nullptr, ev_published = nullptr, ev_gathered = nullptr;
-    bool gather_pending = false, walk_recorded = false;
-    Arena published;                        // copy of this rank's strip of the gathered layers
+    // A step of gem_add_sharded_device whose SECOND HALF -- exchange, walk, all-gather of the layers if one was asked for -- is
+    // still to come: the call returns once the step's sort and the all-gather of its strip boundaries are enqueued; the next call
+    // (or whatever observes the map) finishes it.  That way the host never waits for a sort it has just enqueued: when it needs the
+    // boundaries of step p, the sort of step p + 1 is already queued behind it (shard_finish_locked).
+    struct Step {
+        bool valid = false;
+        int parity = 0;                                                // which of the two sets of staging / receive buffers
+        int n_global_sweeps = 0;
+        bool has_vu = false; float vu[512];
+        Shard sd;
+        bool gather = false; int gather_attrs = 0;                     // gem_allgather_layers was called behind it
+    } step;
+    unsigned step_seq = 0;                                             // steps begun so far (parity = step_seq & 1)
+    Arena sh_dev, sh_ranges;                                           // ids / bounds / gathered bounds / variance increments (two sets); an empty shard's block ranges
+    Arena sh_recv_hv[2], sh_recv_key[2], sh_recv_rng[2];               // records and block ranges received from the other ranks, one set per parity
+    hipStream_t comm_stream = nullptr, gather_stream = nullptr;
+    hipEvent_t ev_sorted = nullptr, ev_exchanged = nullptr;
+    hipEvent_t ev_bounds[2] = {nullptr, nullptr};                      // the gathered boundaries of that parity are on the host
+    hipEvent_t ev_walked[2] = {nullptr, nullptr};                      // the walk that read that parity's receive buffers is done
+    bool walk_recorded[2] = {false, false};
+    hipEvent_t ev_vu[2] = {nullptr, nullptr};                          // the upload of that variance-increment staging buffer is done
+    bool vu_recorded[2] = {false, false};
+    unsigned vu_seq = 0;
+    // all-gather of the layers: sends read a PUBLISHED COPY of this rank's strip (two, rotating), receives write the other ranks' strips
+    Arena published[2];
+    hipEvent_t ev_published[2] = {nullptr, nullptr}, ev_gathered[2] = {nullptr, nullptr};
+    bool gather_outstanding[2] = {false, false};                       // that gather has not been waited for by the handle's stream yet
+    bool gathered_recorded[2] = {false, false};
+    unsigned gather_seq = 0;
+    long long recv_bound = 0;                                          // gem_reserve on a communicator handle: records a step may bring to this rank at most
     void* sh_host = nullptr;            // pinned staging of the small tables (kShardHostBytes)
+    // optional time stamps of the last finished step's phases (gem_set_timing; gem_debug_get "step_*_ns")
+    hipEvent_t ev_t[10] = {};
+    bool step_timed = false;
 
     Arena dbg;          // optional k_fuse phase stamps
     Arena ray;          // gem_raytracing: the cells that walk + their number
     Arena color;        // gem_colorize: its own sort arrays and tables (never shared with a pass in flight on the binning stream)
     bool  dbg_on = false;
+    long long sort_fallbacks = 0;      // passes whose forced sorted form / pass count did not fit the map and took the other form (gem_debug_get)
     long long arena_allocations = 0;   // hipMalloc calls of ensure() so far (gem_debug_get: a stream of frames after gem_reserve must not add any)
     int   dbg_rows = 0;  // rows of `dbg` the last pass wrote, if it was a block-sorted one (else h->T rows)
     int fuse_variant = 12;
@@ -177,6 +210,7 @@ int ensure(gem_handle* h, Arena& a, size_t bytes)
     if (h->bin_stream2) GEM_HIP(h, hipStreamSynchronize(h->bin_stream2));
     if (h->tab_stream) GEM_HIP(h, hipStreamSynchronize(h->tab_stream));
     if (h->comm_stream) GEM_HIP(h, hipStreamSynchronize(h->comm_stream));
+    if (h->gather_stream) GEM_HIP(h, hipStreamSynchronize(h->gather_stream));
     if (a.p) GEM_HIP(h, hipFree(a.p));
     a.p = nullptr; a.cap = 0;
     size_t want = bytes + bytes / 4 + 4096;
@@ -299,21 +333,34 @@ int flush_deferred(gem_handle* h)
     return GEM_OK;
 }
 
-// standalone dense pass: queued Mapvar_update increments (+ optionally the variance floor)
-// an all-gather of the fused strips still in flight on the communication stream writes the other ranks' strips: whatever
-// observes or modifies the whole map on the handle's stream comes after it
+// An all-gather of the fused strips still in flight on the gather stream writes the other ranks' strips: whatever observes or
+// modifies the whole map on the handle's stream comes after it.
 int wait_gather(gem_handle* h)
 {
-    if (!h->gather_pending) return GEM_OK;
-    GEM_HIP(h, hipStreamWaitEvent(h->stream, h->ev_gathered, 0));
-    h->gather_pending = false;
+    for (int g = 0; g < 2; ++g) {
+        if (!h->gather_outstanding[g]) continue;
+        GEM_HIP(h, hipStreamWaitEvent(h->stream, h->ev_gathered[g], 0));
+        h->gather_outstanding[g] = false;
+    }
     return GEM_OK;
 }
 
+int shard_finish_locked(gem_handle* h);       // the second half of a pending gem_add_sharded_device step (below)
+int ensure_recv(gem_handle* h, int parity, size_t records);
+
+// Everything the handle has put off -- the second half of a sharded step (COLLECTIVE: every rank gets here with the same sequence
+// of calls), the fuse of the newest single sweep, the transfers of an all-gather -- before something observes or modifies the map.
+int settle(gem_handle* h)
+{
+    { const int rc = shard_finish_locked(h); if (rc) return rc; }
+    { const int rc = flush_deferred(h); if (rc) return rc; }
+    return wait_gather(h);
+}
+
+// standalone dense pass: queued Mapvar_update increments (+ optionally the variance floor)
 int flush_pending(gem_handle* h, bool with_floor)
 {
-    { const int rc = flush_deferred(h); if (rc) return rc; }
-    { const int rc = wait_gather(h); if (rc) return rc; }
+    { const int rc = settle(h); if (rc) return rc; }
     if (h->n_pending == 0 && !with_floor) return GEM_OK;
     GEM_HIP(h, launch_dense_variance(h->stream, h->layers.variance, h->cells, h->n_pending, h->pending, with_floor ? 1 : 0,
                                      h->cfg.variance_floor));
@@ -460,7 +507,9 @@ SortGeometry sort_geometry(const gem_handle* h, int n_sweeps, bool block_form)
 }
 
 // One pass through the sorted pipeline (gem_sort.hip): six sort kernels on the binning stream, k_fuse_walk on the handle's.
-constexpr size_t kShardHostBytes = 8192;
+// pinned host staging of the sharded path: per parity (4096 B each) strip ids at word 0, own bounds at word 32, the gathered bounds
+// [W][16] at word 64; the variance increments' two buffers at byte 8192 + 2048 b.  The device twin has the same layout.
+constexpr size_t kShardHostBytes = 8192 + 2 * 2048, kShardDevBytes = 8192 + 2 * 2048;
 struct ShardOpts { int sweep_id0; int nstrips; const int* strip_rows; bool bounds_stay_on_device; };   // sort only: the walk happens on the strip owners
 
 int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGeometry& geo, const ShardOpts* shard = nullptr)
@@ -735,7 +784,7 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
         //  passes, 333-340 block-sorted in two.)
         const bool block_form = h->sort_form == 2 || (h->sort_form == 0 && in0.n_sweeps > 1);
         SortGeometry geo = sort_geometry(h, in0.n_sweeps, block_form);
-        if (!geo.ok) geo = sort_geometry(h, in0.n_sweeps, !block_form);
+        if (!geo.ok) { geo = sort_geometry(h, in0.n_sweeps, !block_form); ++h->sort_fallbacks; }    // (a forced form / pass count that does not fit this map: counted, gem_debug_get)
         if (geo.ok) return run_sort_pipeline(h, in0, attr, geo);
     }
     // A big single cloud becomes a batch of sweeps with one frame: every tile then only reads the descriptor
@@ -1035,19 +1084,31 @@ void gem_destroy(gem_handle* h)
 {
     if (!h) return;
     hipSetDevice(h->device);
-    if (h->stream) { flush_deferred(h); hipStreamSynchronize(h->stream); }
+    if (h->step.valid) {
+        // a step whose second half never came (the caller did not synchronise): dropped, and the communicators go down with it so
+        // that peers that do finish theirs fail instead of waiting for this rank
+        h->step.valid = false;
+        if (h->tp_x) h->tp_x->abort();
+        if (h->tp_g) h->tp_g->abort();
+    }
+    if (h->stream) { settle(h); hipStreamSynchronize(h->stream); }
     if (h->bin_stream) hipStreamSynchronize(h->bin_stream);
     if (h->bin_stream2) hipStreamSynchronize(h->bin_stream2);
     if (h->tab_stream) hipStreamSynchronize(h->tab_stream);
     if (h->comm_stream) hipStreamSynchronize(h->comm_stream);
-    if (h->comm) ncclCommDestroy(h->comm);
+    if (h->gather_stream) hipStreamSynchronize(h->gather_stream);
+    h->tp_g.reset(); h->tp_x.reset();                  // (the gather communicator first: it may be a view of the exchange communicator)
     release_comm_stream(h->device, h->comm_stream);
-    for (hipEvent_t e : {h->ev_sorted, h->ev_exchanged, h->ev_walked, h->ev_published, h->ev_gathered}) if (e) hipEventDestroy(e);
+    release_comm_stream(h->device, h->gather_stream);
+    for (hipEvent_t e : {h->ev_sorted, h->ev_exchanged, h->ev_bounds[0], h->ev_bounds[1], h->ev_walked[0], h->ev_walked[1], h->ev_vu[0], h->ev_vu[1],
+                         h->ev_published[0], h->ev_published[1], h->ev_gathered[0], h->ev_gathered[1]}) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_t) if (e) hipEventDestroy(e);
     fold_events(h);
     for (auto& ep : h->pool) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
     if (h->layers.elevation) hipFree(h->layers.elevation);      // base of the single layer allocation
     if (h->d_counters) hipFree(h->d_counters);
-    for (Arena* a : {&h->stage, &h->scratch, &h->dbg, &h->color, &h->ray, &h->sh_dev, &h->sh_recv_hv, &h->sh_recv_key, &h->sh_recv_rng, &h->sh_ranges, &h->published}) if (a->p) hipFree(a->p);
+    for (Arena* a : {&h->stage, &h->scratch, &h->dbg, &h->color, &h->ray, &h->sh_dev, &h->sh_recv_hv[0], &h->sh_recv_key[0], &h->sh_recv_rng[0],
+                     &h->sh_recv_hv[1], &h->sh_recv_key[1], &h->sh_recv_rng[1], &h->sh_ranges, &h->published[0], &h->published[1]}) if (a->p) hipFree(a->p);
     if (h->sh_host) hipHostFree(h->sh_host);
     for (auto& b : h->pb) {
         for (Arena* a : {&b.rec, &b.srt, &b.seg, &b.flag, &b.gflag, &b.tables, &b.s_hv1, &b.s_hv2, &b.s_key1, &b.s_key2, &b.s_src1, &b.s_src2,
@@ -1068,7 +1129,7 @@ int gem_set_stream(gem_handle* h, void* hip_stream)
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
-    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
+    { const int rcd = settle(h); if (rcd) return rcd; }
     GEM_HIP(h, hipStreamSynchronize(h->stream));
     if (h->bin_stream) GEM_HIP(h, hipStreamSynchronize(h->bin_stream));
     if (h->bin_stream2) GEM_HIP(h, hipStreamSynchronize(h->bin_stream2));
@@ -1097,8 +1158,7 @@ int gem_synchronize(gem_handle* h)
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
-    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
-    { const int rcd = wait_gather(h); if (rcd) return rcd; }
+    { const int rcd = settle(h); if (rcd) return rcd; }
     GEM_HIP(h, hipStreamSynchronize(h->stream));
     return GEM_OK;
 }
@@ -1119,8 +1179,7 @@ int gem_move(gem_handle* h, const float position[3], float out_center[2], int ou
     if (!h || !position) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
-    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
-    { const int rcd = wait_gather(h); if (rcd) return rcd; }       // the clears below touch every rank's strip
+    { const int rcd = settle(h); if (rcd) return rcd; }            // (the clears below touch every rank's strip: behind an all-gather in flight)
     const int L = h->L; const float res = h->res;
     h->sensor_z = position[2];
     int shift[2]; float aligned[2];
@@ -1205,6 +1264,7 @@ int gem_fuse(gem_handle* h, int n, const int* index, const int* R, const int* G,
     if (!h || n < 0 || (n > 0 && (!index || !height || !var))) return h ? fail(h, GEM_ERR_INVALID, "gem_fuse: bad argument") : GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
+    { const int rcs = shard_finish_locked(h); if (rcs) return rcs; }
     const bool attr = R && G && B && intensity;
     const size_t S = (size_t)n * 4;
     PassInput in; in.src = 1; in.n = n;
@@ -1237,6 +1297,7 @@ int gem_add_device(gem_handle* h, const gem_frame_params* p, int n, const void* 
     if (!h || !p || n < 0 || (n > 0 && !d_xyzi)) return h ? fail(h, GEM_ERR_INVALID, "gem_add_device: bad argument") : GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
+    { const int rcs = shard_finish_locked(h); if (rcs) return rcs; }
     PassInput in; in.src = 0; in.n = n; in.params = p; in.device_input = true;
     in.xyzi = static_cast<const float4*>(d_xyzi); in.rgb = static_cast<const uint32_t*>(d_rgb); in.orig = static_cast<const int*>(d_orig_index);
     return run_pipeline(h, in);
@@ -1247,6 +1308,7 @@ int gem_add(gem_handle* h, const gem_frame_params* p, int n, const float* xyzi, 
     if (!h || !p || n < 0 || (n > 0 && !xyzi)) return h ? fail(h, GEM_ERR_INVALID, "gem_add: bad argument") : GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
+    { const int rcs = shard_finish_locked(h); if (rcs) return rcs; }
     PassInput in; in.src = 0; in.n = n; in.params = p;
     if (n > 0) {
         const size_t S = (size_t)n * 4;
@@ -1273,6 +1335,7 @@ int gem_add_aos(gem_handle* h, const gem_frame_params* p, int n, const void* poi
         return fail(h, GEM_ERR_INVALID, "gem_add_aos: fields must be 4-byte aligned inside point_step");
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
+    { const int rcs = shard_finish_locked(h); if (rcs) return rcs; }
     PassInput in; in.src = 0; in.n = n; in.params = p;
     if (n > 0) {
         const size_t raw = ((size_t)n * point_step + 15) & ~(size_t)15, S = (size_t)n * 4;
@@ -1296,6 +1359,7 @@ int gem_add_batch_device(gem_handle* h, int n_sweeps, const gem_frame_params* pa
     if (!h || n_sweeps <= 0 || !params || !offsets) return h ? fail(h, GEM_ERR_INVALID, "gem_add_batch_device: bad argument") : GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
+    { const int rcs = shard_finish_locked(h); if (rcs) return rcs; }
     for (int s = 0; s < n_sweeps; ++s) if (offsets[s + 1] < offsets[s]) return fail(h, GEM_ERR_INVALID, "gem_add_batch_device: offsets not monotone");
     if (n_sweeps == 1) {
         if (var_updates) {
@@ -1316,71 +1380,117 @@ int gem_add_batch_device(gem_handle* h, int n_sweeps, const gem_frame_params* pa
 // Arenas for the largest pass the caller is going to make, allocated NOW: the arenas only ever grow, but growing means waiting for
 // everything in flight, hipFree and hipMalloc -- in the middle of a stream of frames that is a stall of a millisecond or more the
 // first time a bigger cloud arrives (measured: tools/bench_configs.py --configs reserve).  max_points points in at most max_sweeps
-// sweeps per call (1 for gem_add*); colours as they will be passed.  Sizes follow run_pipeline / run_sort_pipeline.
+// sweeps per call (1 for gem_add*); colours as they will be passed.  Sizes follow run_pipeline / run_sort_pipeline, for EVERY
+// pipeline a pass within the bounds can take: the sorted forms (cell-sorted for single clouds, block-sorted for batches) from their
+// thresholds on, the tile pipeline below them.  On a handle that joined a communicator with tile strips, max_points / max_sweeps
+// bound the GLOBAL points / sweeps of a gem_add_sharded_device step: the shard's sort (its W-th of the points), both sets of
+// receive buffers (no strip gets more records than the step has points) and the published copies are sized as well.
 int gem_reserve(gem_handle* h, long long max_points, int max_sweeps, int with_colours)
 {
     if (!h || max_points < 0 || max_sweeps < 1 || max_points >= (1ll << 31)) return h ? fail(h, GEM_ERR_INVALID, "gem_reserve: bad argument") : GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
-    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
+    { const int rcd = settle(h); if (rcd) return rcd; }
     if (max_points == 0) return GEM_OK;
     int rc;
-    const size_t N = (size_t)max_points;
-    // staging of host-pointer inputs (gem_add: XYZI + rgb + orig; gem_fuse: seven arrays; gem_process_points: nine)
-    if ((rc = ensure(h, h->stage, N * 4 * 9))) return rc;
-    const long long sort_from = max_sweeps > 1 ? h->sort_min_points_batch : h->sort_min_points;
     const long long blocks = 4ll * ((h->L + 31) / 32) * ((h->L + 31) / 32);
-    bool sorted = false;
-    if (h->sort_path && max_points >= sort_from) {
-        const bool block_form = h->sort_form == 2 || (h->sort_form == 0 && max_sweeps > 1);
-        SortGeometry geo = sort_geometry(h, max_sweeps, block_form);
-        if (!geo.ok) geo = sort_geometry(h, max_sweeps, !block_form);
-        if (geo.ok) {
-            sorted = true;
-            const size_t chunk = (size_t)kSortChunkRecords;
-            const size_t NC1 = (N + chunk - 1) / chunk + (size_t)max_sweeps, nc2 = (N + chunk - 1) / chunk;
-            int bins_hi = 1;
-            for (int i = 1; i < geo.n_passes; ++i) bins_hi = std::max(bins_hi, geo.dbins[i]);
-            size_t misc = 0;
-            for (int i = 0; i < geo.n_passes; ++i) misc += (size_t)geo.dbins[i] * 16;
-            misc = ((misc + 4 + 15) & ~(size_t)15) + (((size_t)geo.dbins[geo.n_passes - 1] + 1) * 4 + 15) + NC1 * kSortSegsPerChunk * 4 + 64;
-            const size_t tables = sizeof(FrameConst) * max_sweeps + (sizeof(int) + sizeof(long long)) * (max_sweeps + 1) + (sizeof(float) + sizeof(int)) * max_sweeps + 64;
-            const int slots = std::max(1, std::min(h->sort_ring, 4));
-            for (int k = 0; k < slots; ++k) {
-                gem_handle::PassBuffers& pb = h->pb[k];
-                if ((rc = ensure(h, pb.s_hv1, N * 8 + 64)) || (rc = ensure(h, pb.s_hv2, N * 8 + 64)) ||
-                    (rc = ensure(h, pb.s_key1, N * 4 + 64)) || (rc = ensure(h, pb.s_key2, N * 4 + 64))) return rc;
-                if (with_colours && ((rc = ensure(h, pb.s_src1, N * 4 + 64)) || (rc = ensure(h, pb.s_src2, N * 4 + 64)))) return rc;
-                if ((rc = ensure(h, pb.s_cnt1, NC1 * geo.dbins[0] * 4)) || (rc = ensure(h, pb.s_cnt2, nc2 * bins_hi * 4 + 16)) ||
-                    (rc = ensure(h, pb.s_misc, misc))) return rc;
-                if (max_sweeps > 1 && (rc = ensure(h, pb.tables, tables))) return rc;
-                if (geo.block_form && geo.n_passes > 1 && ((rc = ensure(h, pb.s_ranges, (size_t)blocks * sizeof(uint2))) || (rc = ensure_zeroed(h, pb.s_blkcnt, (size_t)blocks * sizeof(uint32_t))))) return rc;
+    // staging of host-pointer inputs (gem_add: XYZI + rgb + orig; gem_fuse: seven arrays; gem_process_points: nine)
+    if ((rc = ensure(h, h->stage, (size_t)max_points * 4 * 9))) return rc;
+    auto reserve_tables = [&](int sweeps) -> int {                       // the batched calls' tables and their pinned staging copies
+        const size_t tables = sizeof(FrameConst) * sweeps + (sizeof(int) + sizeof(long long)) * (sweeps + 1) + (sizeof(float) + sizeof(int)) * sweeps + 64;
+        for (auto& pb : h->pb) {
+            int r;
+            if ((r = ensure(h, pb.tables, tables))) return r;
+            if (tables > pb.host_cap) {
+                if (pb.tables_recorded) GEM_HIP(h, hipEventSynchronize(pb.tables_done));
+                if (pb.host_tables) GEM_HIP(h, hipHostFree(pb.host_tables));
+                pb.host_tables = nullptr; pb.host_cap = 0;
+                GEM_HIP(h, hipHostMalloc(&pb.host_tables, tables * 2, hipHostMallocDefault));
+                pb.host_cap = tables * 2;
             }
         }
-    }
-    if (!sorted) {
-        // tile pipeline: units of 64 points, every sweep rounded up to 32 units; the descriptor table is [sweep][tile][units of the longest sweep]
-        const long long units1 = ((max_points + kUnit - 1) / kUnit + 31) & ~31ll;
-        const long long B = units1 + 32ll * (max_sweeps - 1);
+        return GEM_OK;
+    };
+    auto reserve_sorted = [&](long long points, int sweeps, bool block_form, bool shard) -> int {
+        SortGeometry geo = sort_geometry(h, sweeps, block_form);
+        if (!geo.ok) geo = sort_geometry(h, sweeps, !block_form);
+        if (!geo.ok) return GEM_OK;                                      // (such a pass takes the tile pipeline)
+        const size_t N = (size_t)points, chunk = (size_t)kSortChunkRecords;
+        const size_t NC1 = (N + chunk - 1) / chunk + (size_t)sweeps, nc2 = (N + chunk - 1) / chunk;
+        int bins_hi = 1;
+        for (int i = 1; i < geo.n_passes; ++i) bins_hi = std::max(bins_hi, geo.dbins[i]);
+        size_t misc = 0;
+        for (int i = 0; i < geo.n_passes; ++i) misc += (size_t)geo.dbins[i] * 16;
+        misc = ((misc + 4 + 15) & ~(size_t)15) + (((size_t)geo.dbins[geo.n_passes - 1] + 1) * 4 + 15) + NC1 * kSortSegsPerChunk * 4 + 64;
+        const int slots = std::max(1, std::min(h->sort_ring, 4));
+        for (int k = 0; k < slots; ++k) {
+            gem_handle::PassBuffers& pb = h->pb[k];
+            int r;
+            if ((r = ensure(h, pb.s_hv1, N * 8 + 64)) || (r = ensure(h, pb.s_hv2, N * 8 + 64)) ||
+                (r = ensure(h, pb.s_key1, N * 4 + 64)) || (r = ensure(h, pb.s_key2, N * 4 + 64))) return r;
+            if (with_colours && ((r = ensure(h, pb.s_src1, N * 4 + 64)) || (r = ensure(h, pb.s_src2, N * 4 + 64)))) return r;
+            if ((r = ensure(h, pb.s_cnt1, NC1 * geo.dbins[0] * 4)) || (r = ensure(h, pb.s_cnt2, nc2 * bins_hi * 4 + 16)) ||
+                (r = ensure(h, pb.s_misc, misc))) return r;
+            if (((geo.block_form && geo.n_passes > 1) || shard) &&
+                ((r = ensure(h, pb.s_ranges, (size_t)blocks * sizeof(uint2))) || (r = ensure_zeroed(h, pb.s_blkcnt, (size_t)blocks * sizeof(uint32_t))))) return r;
+            if (shard && (r = ensure(h, pb.s_shard, 64 * sizeof(uint32_t)))) return r;
+        }
+        return GEM_OK;
+    };
+    auto reserve_tiles = [&](long long points, int sweeps) -> int {
+        // units of 64 points, every sweep rounded up to 32 units; the descriptor table is [sweep][tile][units of the longest sweep].
+        // A single cloud beyond kSweepPoints is cut into sweeps of that size (run_pipeline); the sweeps of a batch are taken to be at
+        // most twice their mean length (or kSweepPoints) -- the table for "all points in one of 32 sweeps" would be 32 times the useful one.
+        auto units_of = [](long long pts) { return ((pts + kUnit - 1) / kUnit + 31) & ~31ll; };
+        long long units1, B;
+        if (sweeps == 1 && points > kSweepPoints) { sweeps = (int)((points + kSweepPoints - 1) / kSweepPoints); units1 = units_of(kSweepPoints); B = units1 * sweeps; }
+        else if (sweeps == 1) { units1 = units_of(points); B = units1; }
+        else { units1 = units_of(std::min(points, std::max(kSweepPoints, 2 * points / sweeps))); B = units_of(points) + 32ll * (sweeps - 1); }
         const int ts = h->ts ? h->ts : 4;
         const long long tpr = (h->L + (1 << ts) - 1) >> ts, T = tpr * tpr;
-        const size_t seg = (size_t)max_sweeps * T * units1 * sizeof(uint16_t);
-        if (seg > ((size_t)1 << 31)) return fail(h, GEM_ERR_INVALID, "gem_reserve: a tile-pipeline pass of this shape would need a descriptor table beyond 2 GiB");
+        const size_t seg = (size_t)sweeps * T * units1 * sizeof(uint16_t);
+        if (seg > ((size_t)1 << 31)) return GEM_OK;           // (not a shape the tile pipeline is meant for: such a pass sizes its own table, or fails there)
         for (int k = 0; k < 2; ++k) {
             gem_handle::PassBuffers& pb = h->pb[k];
-            if ((rc = ensure(h, pb.rec, (size_t)B * kUnit * sizeof(uint4))) || (rc = ensure(h, pb.srt, (size_t)B * kUnit * sizeof(uint4) + 16))) return rc;
+            int r;
+            if ((r = ensure(h, pb.rec, (size_t)B * kUnit * sizeof(uint4))) || (r = ensure(h, pb.srt, (size_t)B * kUnit * sizeof(uint4) + 16))) return r;
             if (seg > pb.seg.cap) {                          // (the table is all-zero between passes: cleared when it is (re)allocated)
-                if ((rc = ensure(h, pb.seg, seg))) return rc;
+                if ((r = ensure(h, pb.seg, seg))) return r;
                 GEM_HIP(h, hipMemsetAsync(pb.seg.p, 0, pb.seg.cap, h->stream));
             }
-            const size_t flag = (size_t)T * max_sweeps * sizeof(uint32_t), gflag = (size_t)max_sweeps * T * (units1 / 32) * sizeof(uint32_t);
+            const size_t flag = (size_t)T * sweeps * sizeof(uint32_t), gflag = (size_t)sweeps * T * (units1 / 32) * sizeof(uint32_t);
             if (flag > pb.flag.cap || gflag > pb.gflag.cap) {
-                if ((rc = ensure(h, pb.flag, flag)) || (rc = ensure(h, pb.gflag, gflag))) return rc;
+                if ((r = ensure(h, pb.flag, flag)) || (r = ensure(h, pb.gflag, gflag))) return r;
                 GEM_HIP(h, hipMemsetAsync(pb.flag.p, 0, pb.flag.cap, h->stream));
                 GEM_HIP(h, hipMemsetAsync(pb.gflag.p, 0, pb.gflag.cap, h->stream));
                 pb.epoch = 0;
             }
         }
+        return GEM_OK;
+    };
+    if (h->tp_x && h->tile_strips) {
+        // a step of the sharded path: this rank sorts its W-th of the points, block-sorted; every strip's owner receives at most all of them
+        const int W = h->nranks;
+        const long long share = (max_points + W - 1) / W + 1;
+        if ((rc = reserve_sorted(share, max_sweeps, true, true)) || (rc = reserve_tables(max_sweeps))) return rc;
+        if (!h->sh_host) GEM_HIP(h, hipHostMalloc(&h->sh_host, kShardHostBytes, hipHostMallocDefault));
+        if ((rc = ensure(h, h->sh_dev, kShardDevBytes)) || (rc = ensure(h, h->sh_ranges, (size_t)blocks * sizeof(uint2)))) return rc;
+        h->recv_bound = max_points;
+        if (W > 1 && ((rc = ensure_recv(h, 0, (size_t)max_points + 4 * W)) || (rc = ensure_recv(h, 1, (size_t)max_points + 4 * W)))) return rc;
+        GEM_HIP(h, hipStreamSynchronize(h->stream));
+        return GEM_OK;                                                   // (a handle of the sharded path: its steps are what the bounds describe)
+    }
+    const bool sorted_single = h->sort_path && max_points >= h->sort_min_points;
+    const bool sorted_batch = h->sort_path && max_sweeps > 1 && max_points >= h->sort_min_points_batch;
+    if (sorted_single && (rc = reserve_sorted(max_points, 1, h->sort_form == 2, false))) return rc;
+    if (sorted_batch && ((rc = reserve_sorted(max_points, max_sweeps, h->sort_form != 1, false)))) return rc;
+    if (max_sweeps > 1 && (rc = reserve_tables(max_sweeps))) return rc;
+    // the tile pipeline takes what stays below the thresholds (and everything when the sorted forms are off)
+    if ((rc = reserve_tiles(sorted_single ? std::min(max_points, h->sort_min_points - 1) : max_points, 1))) return rc;
+    if (max_sweeps > 1 && (rc = reserve_tiles(sorted_batch ? std::min(max_points, h->sort_min_points_batch - 1) : max_points, max_sweeps))) return rc;
+    if (h->track_lowest && !h->ray.p) {                                  // gem_raytracing's list of walking cells
+        if ((rc = ensure(h, h->ray, ((size_t)h->cells + 4) * sizeof(uint32_t)))) return rc;
+        GEM_HIP(h, hipMemsetAsync(static_cast<uint32_t*>(h->ray.p) + h->cells, 0, 4 * sizeof(uint32_t), h->stream));
     }
     GEM_HIP(h, hipStreamSynchronize(h->stream));
     return GEM_OK;
@@ -1391,6 +1501,7 @@ int gem_mapvar_update(gem_handle* h, float var_update)
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
+    { const int rcs = shard_finish_locked(h); if (rcs) return rcs; }       // (the increment belongs behind a pending step's walk)
     // queued and folded into the next fuse's single pass over the tiles; a negative (or NaN)
     // increment can push a variance under the floor, which the next Fuse must repair everywhere
     if (!(var_update >= 0.f)) h->floor_dirty = true;
@@ -1475,7 +1586,7 @@ int gem_map_optmove(gem_handle* h, const float opt_position[2], float height_upd
     if (!h || !opt_position) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
-    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
+    { const int rcd = settle(h); if (rcd) return rcd; }
     for (int i = 0; i < 2; ++i) {
         const float d = opt_position[i] - h->center[i];
         const int shift = static_cast<int>(static_cast<double>(d / h->res) + 0.5 * (d > 0 ? 1 : -1));     // :1210
@@ -1493,7 +1604,7 @@ int gem_map_closeloop(gem_handle* h, const float update_position[2], float heigh
     if (!h || !update_position) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
-    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
+    { const int rcd = settle(h); if (rcd) return rcd; }
     for (int i = 0; i < 2; ++i) {
         const float d = update_position[i] - h->center[i];
         const int shift = static_cast<int>(static_cast<double>(d / h->res) + 0.5 * (d > 0 ? 1 : -1));     // :897
@@ -1646,7 +1757,7 @@ int gem_colorize(gem_handle* h, const gem_camera* cam, int n, float* xyzi, const
     if (cam->width <= 0 || cam->height <= 0) return fail(h, GEM_ERR_INVALID, "gem_colorize: image size out of range");
     if (n == 0) return GEM_OK;
     if (row_stride == 0) row_stride = (size_t)cam->width * 3;
-    { const int rcd = flush_deferred(h); if (rcd) return rcd; }       // the staging arena may hold a deferred frame's cloud
+    { const int rcd = settle(h); if (rcd) return rcd; }       // the staging arena may hold a deferred frame's cloud
     const size_t N = (size_t)n, b_xyzi = (N * 16 + 255) & ~(size_t)255, b_rgb = (N * 4 + 255) & ~(size_t)255, b_img = row_stride * cam->height;
     int rc;
     if ((rc = ensure(h, h->stage, b_xyzi + b_rgb + b_img))) return rc;
@@ -1665,7 +1776,7 @@ int gem_set_lowest_tracking(gem_handle* h, int enabled)
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
-    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
+    { const int rcd = settle(h); if (rcd) return rcd; }
     h->track_lowest = enabled != 0;
     return GEM_OK;
 }
@@ -1694,8 +1805,9 @@ int gem_set_timing(gem_handle* h, int enabled)
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
-    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
+    { const int rcd = settle(h); if (rcd) return rcd; }
     h->timing = enabled != 0;
+    h->step_timed = h->timing && h->tp_x != nullptr && h->nranks > 1;
     return GEM_OK;
 }
 
@@ -1704,7 +1816,7 @@ int gem_set_counting(gem_handle* h, int enabled)
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
-    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
+    { const int rcd = settle(h); if (rcd) return rcd; }
     h->counting = enabled != 0;
     return GEM_OK;
 }
@@ -1714,7 +1826,7 @@ int gem_get_stats(gem_handle* h, gem_stats* out, int reset)
     if (!h || !out) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
-    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
+    { const int rcd = settle(h); if (rcd) return rcd; }
     GEM_HIP(h, hipStreamSynchronize(h->stream));
     fold_events(h);
     if (h->counting) {
@@ -1735,17 +1847,17 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     if (!h || !key) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
-    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
+    { const int rcd = settle(h); if (rcd) return rcd; }
     const std::string k(key);
     if (k == "fuse_variant")            { if (value < 10 || value > 12) return fail(h, GEM_ERR_INVALID, "fuse_variant: 10..12"); h->fuse_variant = (int)value; }
     else if (k == "tile_shift")         { if (value != 0 && value != 4 && value != 5) return fail(h, GEM_ERR_INVALID, "tile_shift: 0, 4 or 5"); h->ts = (int)value; }
     else if (k == "defer")              h->defer = value != 0;
-    else if (k == "dense_min")          h->dense_min = (unsigned)value;
+    else if (k == "dense_min")          { if (value < 0 || value > 0xffffffffll) return fail(h, GEM_ERR_INVALID, "dense_min: 0 .. 2^32 - 1"); h->dense_min = (unsigned)value; }
     else if (k == "dbg_sweep")          h->dbg_sweep = (int)value;
     else if (k == "overlap")            h->overlap = value != 0;
-    else if (k == "overlap_min_points") { h->overlap_min_points = value; h->sort_overlap_min_points = value; }
+    else if (k == "overlap_min_points") { if (value < 0) return fail(h, GEM_ERR_INVALID, "overlap_min_points: >= 0"); h->overlap_min_points = value; h->sort_overlap_min_points = value; }
     else if (k == "sort_path")          h->sort_path = value != 0;
-    else if (k == "sort_min_points")    { h->sort_min_points = value; h->sort_min_points_batch = value; }
+    else if (k == "sort_min_points")    { if (value < 0) return fail(h, GEM_ERR_INVALID, "sort_min_points: >= 0"); h->sort_min_points = value; h->sort_min_points_batch = value; }
     else if (k == "walk_permute")       h->walk_permute = value != 0;
     else if (k == "trace")              h->trace = value != 0;
     else if (k == "stream_roles") {
@@ -1765,10 +1877,10 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "sort_passes")        { if (value < 0 || value > 3) return fail(h, GEM_ERR_INVALID, "sort_passes: 0..3"); h->sort_passes = (int)value; }
     else if (k == "rank_by_ballot")     h->rank_by_ballot = value != 0;
     else if (k == "lane_sort")          h->lane_sort = value != 0;
-    else if (k == "blk_batch")          h->blk_batch = (int)value;
-    else if (k == "few_bins")           h->few_bins = (int)value;
-    else if (k == "ray_depth")          h->ray_depth = (int)value;
-    else if (k == "ray_lanes")          h->ray_lanes = (int)value;
+    else if (k == "blk_batch")          { if (value != 0 && value != 512 && value != 2048) return fail(h, GEM_ERR_INVALID, "blk_batch: 0 (by pass), 512 or 2048"); h->blk_batch = (int)value; }
+    else if (k == "few_bins")           { if (value < -1 || value > 64) return fail(h, GEM_ERR_INVALID, "few_bins: -1 (one ballot per digit bit), 0 (by pass), 1..64"); h->few_bins = (int)value; }
+    else if (k == "ray_depth")          { if (value != 4 && value != 8) return fail(h, GEM_ERR_INVALID, "ray_depth: 4 or 8"); h->ray_depth = (int)value; }
+    else if (k == "ray_lanes")          { if (value != 1 && value != 4 && value != 8 && value != 16) return fail(h, GEM_ERR_INVALID, "ray_lanes: 1, 4, 8 or 16"); h->ray_lanes = (int)value; }
     else if (k == "fast_laser")         h->fast_laser = value != 0;
     else if (k == "sort_form")          { if (value < 0 || value > 2) return fail(h, GEM_ERR_INVALID, "sort_form: 0 (by pass), 1 (cell-sorted), 2 (block-sorted)"); h->sort_form = (int)value; }
     else return fail(h, GEM_ERR_INVALID, "gem_debug_set: unknown key");
@@ -1781,6 +1893,23 @@ int gem_debug_get(gem_handle* h, const char* key, long long* out)
     std::lock_guard<std::mutex> lk(h->mu);
     const std::string k(key);
     if (k == "arena_allocations") *out = h->arena_allocations;
+    else if (k == "sort_fallbacks") *out = h->sort_fallbacks;
+    else if (k == "step_pending") *out = h->step.valid ? 1 : 0;
+    else if (k.rfind("step_", 0) == 0) {
+        // time stamps of the LAST finished step of gem_add_sharded_device on W > 1 ranks (recorded while gem_set_timing is on; read
+        // after gem_synchronize): nanoseconds between two of them
+        int a = -1, b = -1;
+        if (k == "step_exchange_ns") { a = 2; b = 3; }                 // the grouped send / recv of the sorted records
+        else if (k == "step_walk_ns") { a = 4; b = 5; }                // k_fuse_block over the strip, all sources
+        else if (k == "step_publish_ns") { a = 6; b = 7; }             // the copy of the own strip the all-gather's sends read (+ the hand-over to the gather stream)
+        else if (k == "step_gather_ns") { a = 7; b = 8; }              // the all-gather of the layers
+        else if (k == "step_exchange_to_walk_ns") { a = 3; b = 4; }    // hand-over communication stream -> handle's stream
+        else return fail(h, GEM_ERR_INVALID, "gem_debug_get: unknown key");
+        hipSetDevice(h->device);
+        float ms = 0.f;
+        if (!h->ev_t[a] || hipEventElapsedTime(&ms, h->ev_t[a], h->ev_t[b]) != hipSuccess) { (void)hipGetLastError(); *out = -1; return GEM_OK; }
+        *out = (long long)((double)ms * 1e6);
+    }
     else return fail(h, GEM_ERR_INVALID, "gem_debug_get: unknown key");
     return GEM_OK;
 }
@@ -1791,7 +1920,7 @@ int gem_debug_fuse_stamps(gem_handle* h, int enable, unsigned long long* out, in
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
-    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
+    { const int rcd = settle(h); if (rcd) return rcd; }
     h->dbg_on = enable != 0;
     if (out && h->dbg.p) {
         GEM_HIP(h, hipStreamSynchronize(h->stream));
@@ -1803,7 +1932,7 @@ int gem_debug_fuse_stamps(gem_handle* h, int enable, unsigned long long* out, in
     return 0;
 }
 
-// ---- RCCL: all-gather of the fused row strips over xGMI -------------------------------------------
+// ---- multi-GPU: the communicators and the all-gather of the fused row strips --------------------------------------------------
 int gem_comm_unique_id(void* out_128_bytes)
 {
     if (!out_128_bytes) return GEM_ERR_INVALID;
@@ -1814,29 +1943,60 @@ int gem_comm_unique_id(void* out_128_bytes)
     return GEM_OK;
 }
 
-static int comm_init_common(gem_handle* h, const void* unique_id_128_bytes, int nranks, int rank, bool tile_strips)
+} // extern "C"
+
+namespace {
+
+// streams, events and strips of a handle that has just been given its two transports
+int comm_attach(gem_handle* h, int nranks, int rank, bool tile_strips)
 {
-    if (!h || !unique_id_128_bytes || nranks <= 0 || nranks > kMaxRanks || rank < 0 || rank >= nranks) return GEM_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(h->mu);
-    hipSetDevice(h->device);
-    { const int rcd = flush_deferred(h); if (rcd) return rcd; }   // the strip changes below
-    ncclUniqueId id;
-    memcpy(&id, unique_id_128_bytes, sizeof(id));
-    ncclResult_t r = ncclCommInitRank(&h->comm, nranks, id, rank);
-    if (r != ncclSuccess) { h->comm = nullptr; return fail(h, GEM_ERR_COMM, ncclGetErrorString(r)); }
     h->nranks = nranks; h->rank = rank; h->tile_strips = tile_strips;
     if (!h->comm_stream) {
         GEM_HIP(h, acquire_comm_stream(h->device, &h->comm_stream));
-        for (hipEvent_t* e : {&h->ev_sorted, &h->ev_exchanged, &h->ev_walked, &h->ev_published, &h->ev_gathered})
+        GEM_HIP(h, acquire_comm_stream(h->device, &h->gather_stream));
+        for (hipEvent_t* e : {&h->ev_sorted, &h->ev_exchanged, &h->ev_bounds[0], &h->ev_bounds[1], &h->ev_walked[0], &h->ev_walked[1], &h->ev_vu[0], &h->ev_vu[1],
+                              &h->ev_published[0], &h->ev_published[1], &h->ev_gathered[0], &h->ev_gathered[1]})
             GEM_HIP(h, hipEventCreateWithFlags(e, hipEventDisableTiming));
+        for (hipEvent_t& e : h->ev_t) GEM_HIP(h, hipEventCreate(&e));
     }
     // row strips in STORAGE coordinates: Move never migrates data between devices
     const int tile_rows = (h->L + 31) / 32;
     for (int k = 0; k <= nranks; ++k)
         h->strip_row[k] = tile_strips ? std::min(h->L, 32 * (int)((long long)tile_rows * k / nranks)) : (int)((long long)h->L * k / nranks);
     h->row0 = h->strip_row[rank]; h->row1 = h->strip_row[rank + 1];
+    // the two published copies of this rank's strip the all-gathers send from (six layers each): no allocation inside a step
+    if (nranks > 1)
+        for (int g = 0; g < 2; ++g) { const int rc = ensure(h, h->published[g], (size_t)(h->row1 - h->row0) * h->L * 4 * 6 + 256); if (rc) return rc; }
     return GEM_OK;
 }
+
+int comm_init_common(gem_handle* h, const void* unique_id_128_bytes, int nranks, int rank, bool tile_strips)
+{
+    if (!h || !unique_id_128_bytes || nranks <= 0 || nranks > kMaxRanks || rank < 0 || rank >= nranks) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    { const int rcd = settle(h); if (rcd) return rcd; }   // the strip changes below
+    if (h->tp_x) return fail(h, GEM_ERR_COMM, "gem_comm_init: the handle already joined a communicator");
+    ncclUniqueId id;
+    memcpy(&id, unique_id_128_bytes, sizeof(id));
+    std::unique_ptr<RcclTransport> x(new RcclTransport()), g(new RcclTransport());
+    ncclResult_t r = ncclCommInitRank(&x->comm, nranks, id, rank);
+    if (r != ncclSuccess) { x->comm = nullptr; return fail(h, GEM_ERR_COMM, ncclGetErrorString(r)); }
+    // the layers' all-gather gets a communicator of its own (same ranks): together with its own stream, the 46 MB of step p
+    // then travel beside step p + 1's boundary all-gather and record exchange instead of in front of them.  Every rank issues the
+    // operations of the two communicators in the same order (exchange p, gather p, boundaries p + 1), as RCCL asks of
+    // communicators used side by side.
+    r = ncclCommSplit(x->comm, 0, rank, &g->comm, nullptr);
+    if (r != ncclSuccess || !g->comm) { g->comm = x->comm; g->owns = false; }          // (no split: one communicator carries both, in order)
+    x->nranks = g->nranks = nranks; x->rank = g->rank = rank;
+    // (destruction order: the borrowed communicator first -- tp_g is declared after tp_x, members die in reverse order)
+    h->tp_x = std::move(x); h->tp_g = std::move(g);
+    return comm_attach(h, nranks, rank, tile_strips);
+}
+
+} // namespace
+
+extern "C" {
 
 int gem_comm_init(gem_handle* h, const void* unique_id_128_bytes, int nranks, int rank)
 {
@@ -1848,6 +2008,25 @@ int gem_comm_init_tiles(gem_handle* h, const void* unique_id_128_bytes, int nran
     return comm_init_common(h, unique_id_128_bytes, nranks, rank, true);
 }
 
+// include/gem_hip_debug.h: W handles of THIS process on ONE device form a communicator whose collectives are device-to-device
+// copies (gem_transport.hpp); every handle is driven by a host thread of its own, like a rank.
+int gem_comm_init_loopback(gem_handle* h, long long world_id, int nranks, int rank, int tile_strips)
+{
+    if (!h || nranks <= 0 || nranks > kMaxRanks || rank < 0 || rank >= nranks) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    { const int rcd = settle(h); if (rcd) return rcd; }
+    if (h->tp_x) return fail(h, GEM_ERR_COMM, "gem_comm_init_loopback: the handle already joined a communicator");
+    std::string why;
+    std::shared_ptr<LoopWorld> w = loop_world(world_id, nranks, &why);
+    if (!w) return fail(h, GEM_ERR_COMM, why.c_str());
+    std::unique_ptr<LoopbackTransport> x(new LoopbackTransport()), g(new LoopbackTransport());
+    if (!x->join(w, 0, rank)) return fail(h, GEM_ERR_COMM, x->err.c_str());
+    if (!g->join(w, 1, rank)) return fail(h, GEM_ERR_COMM, g->err.c_str());
+    h->tp_x = std::move(x); h->tp_g = std::move(g);
+    return comm_attach(h, nranks, rank, tile_strips != 0);
+}
+
 int gem_get_strip(gem_handle* h, int* out_row0, int* out_row1)
 {
     if (!h) return GEM_ERR_INVALID;
@@ -1857,55 +2036,84 @@ int gem_get_strip(gem_handle* h, int* out_row0, int* out_row1)
     return GEM_OK;
 }
 
-// Every rank's strip to every other rank, DIRECT: one ncclSend / ncclRecv pair per peer and layer in one group (xGMI is
-// point-to-point: each peer has its own link; a ring would pass every strip through seven hops), strips of any sizes.  The sends
-// read a PUBLISHED COPY of the strip, taken on the handle's stream behind everything enqueued so far; the transfers run on the
-// communication stream and write the other ranks' strips only -- so the next pass's projection / sort / fusion of this rank's own
-// strip goes on beside them.  Whatever observes the whole map (gem_get_layer, gem_synchronize, gem_move, ...) waits for them.
-int gem_allgather_layers(gem_handle* h, int with_attributes)
+} // extern "C"
+
+namespace {
+
+// Every rank's strip to every other rank, DIRECT: one send / receive pair per peer and layer in one group (xGMI is point-to-point:
+// each peer has its own link; a ring would pass every strip through seven hops), strips of any sizes.  The sends read a PUBLISHED
+// COPY of the strip, taken on the handle's stream behind everything enqueued so far (two copies rotate: the copy for gather k + 2
+// waits for gather k's sends, not for gather k + 1's); the transfers run on the gather stream, through the gather communicator,
+// and write the other ranks' strips only -- so the next steps' sort / exchange / walk of this rank's own strip go on beside them.
+// Whatever observes the whole map (gem_get_layer, gem_synchronize, gem_move, ...) waits for them (wait_gather).
+int gather_layers_locked(gem_handle* h, int with_attributes)
 {
-    if (!h) return GEM_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(h->mu);
-    hipSetDevice(h->device);
-    if (!h->comm) return fail(h, GEM_ERR_COMM, "gem_allgather_layers: gem_comm_init not called");
-    int rc = flush_pending(h, false);               // (also: behind the previous gather)
-    if (rc) return rc;
     const int W = h->nranks;
     if (W == 1) return GEM_OK;
     const int nl = with_attributes ? 6 : 2;
     void* ptrs[6] = {h->layers.elevation, h->layers.variance, h->layers.intensity, h->layers.colorR, h->layers.colorG, h->layers.colorB};
     const size_t own = (size_t)(h->strip_row[h->rank + 1] - h->strip_row[h->rank]) * h->L;       // 4-byte elements of this rank's strip
-    if ((rc = ensure(h, h->published, own * 4 * 6 + 256))) return rc;
-    unsigned char* pub = static_cast<unsigned char*>(h->published.p);
+    const int g = (int)(h->gather_seq++ & 1u);
+    int rc;
+    if ((rc = ensure(h, h->published[g], own * 4 * 6 + 256))) { h->tp_x->abort(); h->tp_g->abort(); return rc; }    // (sized by gem_comm_init*: no allocation here)
+    unsigned char* pub = static_cast<unsigned char*>(h->published[g].p);
+    if (h->gathered_recorded[g]) GEM_HIP(h, hipStreamWaitEvent(h->stream, h->ev_gathered[g], 0));       // the gather before last has sent this copy
+    if (h->step_timed) GEM_HIP(h, hipEventRecord(h->ev_t[6], h->stream));
     if (own)
         for (int l = 0; l < nl; ++l)
             GEM_HIP(h, hipMemcpyAsync(pub + (size_t)l * own * 4, static_cast<unsigned char*>(ptrs[l]) + (size_t)h->strip_row[h->rank] * h->L * 4, own * 4,
                                       hipMemcpyDeviceToDevice, h->stream));
-    GEM_HIP(h, hipEventRecord(h->ev_published, h->stream));
-    GEM_HIP(h, hipStreamWaitEvent(h->comm_stream, h->ev_published, 0));
-    ncclResult_t r = ncclGroupStart();
-    for (int p = 0; p < W && r == ncclSuccess; ++p) {
+    GEM_HIP(h, hipEventRecord(h->ev_published[g], h->stream));
+    GEM_HIP(h, hipStreamWaitEvent(h->gather_stream, h->ev_published[g], 0));
+    if (h->step_timed) GEM_HIP(h, hipEventRecord(h->ev_t[7], h->gather_stream));
+    Transport& tp = *h->tp_g;
+    bool ok = tp.group_begin();
+    for (int p = 0; p < W && ok; ++p) {
         if (p == h->rank) continue;
         const size_t theirs = (size_t)(h->strip_row[p + 1] - h->strip_row[p]) * h->L;
-        for (int l = 0; l < nl && r == ncclSuccess; ++l) {
-            if (own) r = ncclSend(pub + (size_t)l * own * 4, own, ncclFloat, p, h->comm, h->comm_stream);
-            if (r == ncclSuccess && theirs)
-                r = ncclRecv(static_cast<unsigned char*>(ptrs[l]) + (size_t)h->strip_row[p] * h->L * 4, theirs, ncclFloat, p, h->comm, h->comm_stream);
+        for (int l = 0; l < nl && ok; ++l) {
+            if (own) ok = tp.send(pub + (size_t)l * own * 4, own, p, h->gather_stream);
+            if (ok && theirs) ok = tp.recv(static_cast<unsigned char*>(ptrs[l]) + (size_t)h->strip_row[p] * h->L * 4, theirs, p, h->gather_stream);
         }
     }
-    ncclResult_t r2 = ncclGroupEnd();
-    if (r != ncclSuccess || r2 != ncclSuccess) return fail(h, GEM_ERR_COMM, ncclGetErrorString(r != ncclSuccess ? r : r2));
-    GEM_HIP(h, hipEventRecord(h->ev_gathered, h->comm_stream));
-    h->gather_pending = true;
+    ok = tp.group_end(h->gather_stream) && ok;
+    if (!ok) return fail(h, GEM_ERR_COMM, tp.err.c_str());
+    GEM_HIP(h, hipEventRecord(h->ev_gathered[g], h->gather_stream));
+    if (h->step_timed) GEM_HIP(h, hipEventRecord(h->ev_t[8], h->gather_stream));
+    h->gathered_recorded[g] = true;
+    h->gather_outstanding[g] = true;
     return GEM_OK;
 }
+
+} // namespace
+
+extern "C" {
+
+int gem_allgather_layers(gem_handle* h, int with_attributes)
+{
+    if (!h) return GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    if (!h->tp_g) return fail(h, GEM_ERR_COMM, "gem_allgather_layers: gem_comm_init not called");
+    if (h->step.valid) {                              // behind a sharded step whose walk is still to come: part of that step's second half
+        h->step.gather = true; h->step.gather_attrs = with_attributes;
+        return GEM_OK;
+    }
+    { const int rc = flush_deferred(h); if (rc) return rc; }
+    if (h->n_pending) { const int rc = flush_pending(h, false); if (rc) return rc; }      // queued increments are part of what the peers get
+    return gather_layers_locked(h, with_attributes);
+}
+
+} // extern "C"
+
+namespace {
 
 // ---- multi-GPU with the POINTS sharded (SURVEY 8e stage B) ---------------------------------------------------------------------
 // Rank r holds a contiguous index range of the batch's points.  It projects, bins and sorts them for the WHOLE map
 // (gem_shard_sort_device); the sorted records of every strip go to the strip's owner, which walks its cells through the
 // sources in rank order -- ranks hold ascending index ranges, so rank order is input order and the result is the
 // single-device one bit for bit (gem_shard_fuse_device).  gem_add_sharded_device does both with an RCCL exchange in between.
-static int shard_checks(gem_handle* h, int n_global_sweeps, SortGeometry* geo)
+int shard_checks(gem_handle* h, int n_global_sweeps, SortGeometry* geo)
 {
     if (h->track_lowest) return fail(h, GEM_ERR_INVALID, "sharded path: lowest tracking is not supported (use the replicated path)");
     *geo = sort_geometry(h, n_global_sweeps, true);            // block-sorted: a strip's records are one contiguous range, a block's too
@@ -1913,7 +2121,7 @@ static int shard_checks(gem_handle* h, int n_global_sweeps, SortGeometry* geo)
     return GEM_OK;
 }
 
-static int shard_sort_locked(gem_handle* h, int n_local_sweeps, const gem_frame_params* params, const void* d_xyzi, const long long* offsets,
+int shard_sort_locked(gem_handle* h, int n_local_sweeps, const gem_frame_params* params, const void* d_xyzi, const long long* offsets,
                              int first_global_sweep, int n_global_sweeps, int first_point_in_sweep, int nstrips, const int* strip_rows,
                              uint32_t* out_bounds, const void** out_d_hv, const void** out_d_key, const void** out_d_ranges, bool bounds_stay_on_device)
 {
@@ -1936,7 +2144,7 @@ static int shard_sort_locked(gem_handle* h, int n_local_sweeps, const gem_frame_
     if (n == 0) {                                        // an empty shard contributes nothing to any strip: no records, empty ranges, zero bounds
         const size_t n_blocks = (size_t)4 * geo.T;
         if ((rc = ensure(h, h->sh_ranges, n_blocks * sizeof(uint2)))) return rc;
-        if ((rc = ensure(h, h->sh_dev, 4096 + sizeof(float) * 512))) return rc;
+        if ((rc = ensure(h, h->sh_dev, kShardDevBytes))) return rc;
         GEM_HIP(h, hipMemsetAsync(h->sh_ranges.p, 0, n_blocks * sizeof(uint2), h->stream));
         GEM_HIP(h, hipMemsetAsync(static_cast<uint32_t*>(h->sh_dev.p) + 16, 0, 16 * sizeof(uint32_t), h->stream));
         sd.valid = true; sd.hv = nullptr; sd.key = nullptr; sd.nstrips = nstrips; sd.slot = -1;
@@ -1966,6 +2174,10 @@ static int shard_sort_locked(gem_handle* h, int n_local_sweeps, const gem_frame_
     return GEM_OK;
 }
 
+} // namespace
+
+extern "C" {
+
 int gem_shard_sort_device(gem_handle* h, int n_local_sweeps, const gem_frame_params* params, const void* d_xyzi, const long long* offsets,
                           int first_global_sweep, int n_global_sweeps, int first_point_in_sweep, int nstrips, const int* strip_rows,
                           uint32_t* out_bounds, const void** out_d_hv, const void** out_d_key, const void** out_d_ranges)
@@ -1976,13 +2188,18 @@ int gem_shard_sort_device(gem_handle* h, int n_local_sweeps, const gem_frame_par
                              out_bounds, out_d_hv, out_d_key, out_d_ranges, false);
 }
 
+} // extern "C"
+
+namespace {
+
 // d_ranges / bases (both or neither): per source the block ranges of ITS sorted records, entry 0 = the first block of this handle's
 // strip, and the position d_hv[s] / d_key[s] point at in the source's own arrays; without them the walk searches every source.
 // own: this device's own sorted records are the ONLY source (one rank), taken in place through their block ranges.
 // slot: the pass-buffer set whose sort the walk reads (its fuse_done event lets the sort after next reuse the buffers), -1: none.
-static int shard_fuse_locked(gem_handle* h, int n_src, const void* const* d_hv, const void* const* d_key, const uint32_t* counts,
-                             const void* const* d_ranges, const uint32_t* bases, int n_global_sweeps, const float* var_updates_global,
-                             const gem_handle::Shard* own = nullptr, int slot = -1)
+// recv_parity: the set of receive buffers the sources live in (its ev_walked tells the exchange after next that they have been read), -1: none.
+int shard_fuse_locked(gem_handle* h, int n_src, const void* const* d_hv, const void* const* d_key, const uint32_t* counts,
+                      const void* const* d_ranges, const uint32_t* bases, int n_global_sweeps, const float* var_updates_global,
+                      const gem_handle::Shard* own = nullptr, int slot = -1, int recv_parity = -1, long long step_points = -1)
 {
     SortGeometry geo;
     int rc = shard_checks(h, n_global_sweeps, &geo);
@@ -2015,30 +2232,141 @@ static int shard_fuse_locked(gem_handle* h, int n_src, const void* const* d_hv, 
     wa.lane_sort = h->lane_sort ? 1 : 0;
     {   // rounds of 512 records when the strip's blocks are light: about as many records arrive as this rank sorted (its share of the step)
         const long long strip_blocks = 4ll * ((std::min(h->row1, h->L) - h->row0 + 31) / 32) * geo.tiles_per_row;
-        wa.light_blocks = h->blk_batch ? (h->blk_batch <= 512 ? 1 : 0) : (h->shard.valid && h->shard.points <= 768ll * strip_blocks ? 1 : 0);
+        const long long pts = step_points >= 0 ? step_points : (h->shard.valid ? h->shard.points : -1);
+        wa.light_blocks = h->blk_batch ? (h->blk_batch <= 512 ? 1 : 0) : (pts >= 0 && pts <= 768ll * strip_blocks ? 1 : 0);
         if (wa.light_blocks) wa.lane_sort = 0;
     }
     wa.center_tr = ((h->L / 2 + h->start[0]) % h->L) >> 5;
     if (var_updates_global) {
+        // staged in pinned memory, two buffers in turn: the upload from a buffer is long done when its turn comes again (the event
+        // is there for the caller who gets ahead), so no step waits for the handle's stream here
         if (n_global_sweeps > 512) return fail(h, GEM_ERR_INVALID, "sharded path: more than 512 sweeps");
         if (!h->sh_host) GEM_HIP(h, hipHostMalloc(&h->sh_host, kShardHostBytes, hipHostMallocDefault));
-        if ((rc = ensure(h, h->sh_dev, 4096 + sizeof(float) * 512))) return rc;
-        float* hostf = reinterpret_cast<float*>(static_cast<unsigned char*>(h->sh_host) + 4096);
-        GEM_HIP(h, hipStreamSynchronize(h->stream));     // the staging buffer's previous upload has been read
+        if ((rc = ensure(h, h->sh_dev, kShardDevBytes))) return rc;
+        const int b = (int)(h->vu_seq++ & 1u);
+        if (!h->ev_vu[b]) GEM_HIP(h, hipEventCreateWithFlags(&h->ev_vu[b], hipEventDisableTiming));
+        if (h->vu_recorded[b]) GEM_HIP(h, hipEventSynchronize(h->ev_vu[b]));
+        float* hostf = reinterpret_cast<float*>(static_cast<unsigned char*>(h->sh_host) + 8192 + 2048 * b);
         memcpy(hostf, var_updates_global, sizeof(float) * n_global_sweeps);
-        float* dv = reinterpret_cast<float*>(static_cast<unsigned char*>(h->sh_dev.p) + 4096);
+        float* dv = reinterpret_cast<float*>(static_cast<unsigned char*>(h->sh_dev.p) + 8192 + 2048 * b);
         GEM_HIP(h, hipMemcpyAsync(dv, hostf, sizeof(float) * n_global_sweeps, hipMemcpyHostToDevice, h->stream));
+        GEM_HIP(h, hipEventRecord(h->ev_vu[b], h->stream)); h->vu_recorded[b] = true;
         wa.var_updates = dv;
     }
     if (h->counting) GEM_HIP(h, hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
+    if (h->step_timed) GEM_HIP(h, hipEventRecord(h->ev_t[4], h->stream));
     { Timed t(h, 9); GEM_HIP(h, launch_block_walk(h->stream, wa, 0, t.events())); }
-    if (h->ev_walked) { GEM_HIP(h, hipEventRecord(h->ev_walked, h->stream)); h->walk_recorded = true; }    // (the receive buffers have been read)
+    if (h->step_timed) GEM_HIP(h, hipEventRecord(h->ev_t[5], h->stream));
+    if (recv_parity >= 0) { GEM_HIP(h, hipEventRecord(h->ev_walked[recv_parity], h->stream)); h->walk_recorded[recv_parity] = true; }    // (the receive buffers have been read)
     if (slot >= 0) { GEM_HIP(h, hipEventRecord(h->pb[slot].fuse_done, h->stream)); h->pb[slot].fuse_recorded = true; }
     else h->main_reads_pb = true;
     h->n_pending = 0;
     h->floor_dirty = false;
     return GEM_OK;
 }
+
+// a rank that cannot go on between two collectives of a step: the peers' pending calls fail instead of hanging
+int step_abort(gem_handle* h, int rc)
+{
+    if (h->tp_x) h->tp_x->abort();
+    if (h->tp_g) h->tp_g->abort();
+    return rc;
+}
+
+size_t strip_blocks_of(const gem_handle* h, int p)
+{
+    const int tpr = (h->L + 31) / 32;
+    return (size_t)4 * tpr * ((std::min(h->strip_row[p + 1], tpr * 32) + 31) / 32 - h->strip_row[p] / 32);
+}
+
+// receive buffers of one parity for up to `records` records (and the W tables of block ranges)
+int ensure_recv(gem_handle* h, int q, size_t records)
+{
+    int rc;
+    if ((rc = ensure(h, h->sh_recv_hv[q], records * 8 + 64 + 32 * kMaxRanks))) return rc;
+    if ((rc = ensure(h, h->sh_recv_key[q], records * 4 + 64 + 16 * kMaxRanks))) return rc;
+    return ensure(h, h->sh_recv_rng[q], (size_t)h->nranks * strip_blocks_of(h, h->rank) * sizeof(uint2) + 64);
+}
+
+// The SECOND HALF of a gem_add_sharded_device step on W > 1 ranks: the gathered strip boundaries (on the host by now: the sort
+// they waited for was enqueued a call ago) say what this rank sends and receives; one group of sends / receives moves every
+// strip's records and block ranges to its owner on the communication stream; the walk follows on the handle's stream, and the
+// all-gather of the layers, if gem_allgather_layers was called behind the step, on the gather stream.
+int shard_finish_locked(gem_handle* h)
+{
+    if (!h->step.valid) return GEM_OK;
+    gem_handle::Step& st = h->step;
+    st.valid = false;                                                 // (whatever happens below, the step is not retried)
+    hipSetDevice(h->device);
+    const int W = h->nranks, q = st.parity;
+    gem_handle::Shard& sd = st.sd;
+    uint32_t* host = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(h->sh_host) + 4096 * q);
+    GEM_HIP(h, hipEventSynchronize(h->ev_bounds[q]));
+    for (int k = 0; k <= W; ++k) sd.bounds[k] = host[64 + h->rank * 16 + k];
+    const int tpr = (h->L + 31) / 32;
+    const size_t my_blocks = strip_blocks_of(h, h->rank);
+    const uint32_t my_blk0 = (uint32_t)((h->row0 / 32) * tpr) << 2;
+    uint32_t cnt[kMaxRanks], off[kMaxRanks + 1], base[kMaxRanks];
+    off[0] = 0;
+    long long arriving = 0;
+    for (int s = 0; s < W; ++s) {
+        base[s] = host[64 + s * 16 + h->rank];
+        cnt[s] = host[64 + s * 16 + h->rank + 1] - base[s];
+        off[s + 1] = off[s] + (s == h->rank ? 0u : ((cnt[s] + 3u) & ~3u));      // (this rank's own records stay where they are)
+        arriving += cnt[s];
+    }
+    // sized before the step's first collective (gem_add_sharded_device); a step that brings more than was foreseen grows them here,
+    // and a rank that cannot takes the communicators down with it rather than leave the others waiting in their receives
+    int rc;
+    if ((rc = ensure_recv(h, q, off[W]))) return step_abort(h, rc);
+    uint2* rhv = static_cast<uint2*>(h->sh_recv_hv[q].p); uint32_t* rkey = static_cast<uint32_t*>(h->sh_recv_key[q].p);
+    uint2* rrng = static_cast<uint2*>(h->sh_recv_rng[q].p);
+    // the walk before last has read this parity's receive buffers
+    if (h->walk_recorded[q]) GEM_HIP(h, hipStreamWaitEvent(h->comm_stream, h->ev_walked[q], 0));
+    if (h->step_timed) GEM_HIP(h, hipEventRecord(h->ev_t[2], h->comm_stream));
+    // the exchange: every strip's records and their block ranges to the strip's owner
+    Transport& tp = *h->tp_x;
+    bool ok = tp.group_begin();
+    for (int p = 0; p < W && ok; ++p) {
+        if (p == h->rank) continue;
+        const uint32_t sc = sd.bounds[p + 1] - sd.bounds[p];
+        if (sc > 0) {
+            const uint32_t p_blk0 = (uint32_t)((h->strip_row[p] / 32) * tpr) << 2;
+            ok = tp.send(sd.hv + sd.bounds[p], (size_t)sc * 2, p, h->comm_stream) &&
+                 tp.send(sd.key + sd.bounds[p], sc, p, h->comm_stream) &&
+                 tp.send(sd.ranges + p_blk0, strip_blocks_of(h, p) * 2, p, h->comm_stream);
+        }
+        if (ok && cnt[p] > 0)
+            ok = tp.recv(rhv + off[p], (size_t)cnt[p] * 2, p, h->comm_stream) &&
+                 tp.recv(rkey + off[p], cnt[p], p, h->comm_stream) &&
+                 tp.recv(rrng + (size_t)p * my_blocks, my_blocks * 2, p, h->comm_stream);
+    }
+    ok = tp.group_end(h->comm_stream) && ok;
+    if (!ok) return fail(h, GEM_ERR_COMM, tp.err.c_str());
+    GEM_HIP(h, hipEventRecord(h->ev_exchanged, h->comm_stream));
+    if (h->step_timed) GEM_HIP(h, hipEventRecord(h->ev_t[3], h->comm_stream));
+    GEM_HIP(h, hipStreamWaitEvent(h->stream, h->ev_exchanged, 0));
+    const void* phv[kMaxRanks]; const void* pkey[kMaxRanks]; const void* prng[kMaxRanks];
+    for (int s = 0; s < W; ++s) {
+        const bool mine = s == h->rank;
+        phv[s] = cnt[s] ? (mine ? (const void*)(sd.hv + base[s]) : (const void*)(rhv + off[s])) : nullptr;
+        pkey[s] = cnt[s] ? (mine ? (const void*)(sd.key + base[s]) : (const void*)(rkey + off[s])) : nullptr;
+        prng[s] = cnt[s] ? (mine ? (const void*)(sd.ranges + my_blk0) : (const void*)(rrng + (size_t)s * my_blocks)) : nullptr;
+    }
+    if ((rc = shard_fuse_locked(h, W, phv, pkey, cnt, prng, base, st.n_global_sweeps, st.has_vu ? st.vu : nullptr, nullptr, sd.slot, q, arriving))) return rc;
+    if (st.gather) { st.gather = false; return gather_layers_locked(h, st.gather_attrs); }
+    return GEM_OK;
+}
+
+// would run_sort_pipeline put a shard's sort of n points on a binning stream, in a pass-buffer set of its own?
+bool shard_sort_rotates(const gem_handle* h, long long n)
+{
+    return n > 0 && h->overlap && n >= std::min(h->overlap_min_points, h->sort_overlap_min_points) && h->stream == h->own_stream && !h->counting;
+}
+
+} // namespace
+
+extern "C" {
 
 int gem_shard_fuse_device(gem_handle* h, int n_src, const void* const* d_hv, const void* const* d_key, const uint32_t* counts,
                           const void* const* d_ranges, const uint32_t* bases, int n_global_sweeps, const float* var_updates_global)
@@ -2047,38 +2375,59 @@ int gem_shard_fuse_device(gem_handle* h, int n_src, const void* const* d_hv, con
         return h ? fail(h, GEM_ERR_INVALID, "gem_shard_fuse_device: bad argument") : GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
+    { const int rcs = shard_finish_locked(h); if (rcs) return rcs; }
     if (h->tile_strips == false && (h->row0 % 32 != 0)) return fail(h, GEM_ERR_INVALID, "gem_shard_fuse_device: the handle's strip must start at a tile row");
     return shard_fuse_locked(h, n_src, d_hv, d_key, counts, d_ranges, bases, n_global_sweeps, var_updates_global);
 }
 
+// One step of the map tiled over the ranks.  W > 1, in the order things are enqueued by call p:
+//   sort p            binning streams   this rank's points, block-sorted for the whole map (a pass-buffer set of its own, three rotate)
+//   [second half of step p - 1: shard_finish_locked]
+//       exchange p-1  communication stream / exchange communicator
+//       walk p-1      the handle's stream
+//       gather p-1    gather stream / gather communicator          (when gem_allgather_layers followed the step)
+//   boundaries p      communication stream: all-gather of the W + 1 strip boundaries of every rank's sorted records, copied to the host
+// and the call returns.  Nothing in it waits for work the same call enqueued: the host's one wait -- for the boundaries of step
+// p - 1 -- has the sort of step p queued behind it.  Per stream the steady state is sort | exchange + boundaries | walk | gather,
+// each on its own queue: a step takes as long as the slowest of them, not their sum.
+// Every rank issues the same sequence of collectives on each communicator: the calls, their order and the flush points
+// (settle) are the same on all ranks by the API's contract.
 int gem_add_sharded_device(gem_handle* h, int n_local_sweeps, const gem_frame_params* params, const void* d_xyzi, const long long* offsets,
                            int first_global_sweep, int n_global_sweeps, int first_point_in_sweep, const float* var_updates_global)
 {
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
-    if (!h->comm || !h->tile_strips) return fail(h, GEM_ERR_COMM, "gem_add_sharded_device: gem_comm_init_tiles not called");
+    if (!h->tp_x || !h->tile_strips) return fail(h, GEM_ERR_COMM, "gem_add_sharded_device: gem_comm_init_tiles not called");
     const int W = h->nranks;
-    // Everything that can fail on this rank alone -- arguments, geometry, allocations -- fails HERE, before the first collective:
-    // a rank that returned early would leave the others waiting in ncclRecv.  (An error after this point means the communicator
-    // has to be aborted.)
+    hipSetDevice(h->device);
+    // Everything that can fail on this rank alone -- arguments, geometry, allocations -- fails HERE, before the step's first
+    // collective: a rank that returned early would leave the others waiting in theirs.
+    const long long n_local = (n_local_sweeps > 0 && offsets) ? offsets[n_local_sweeps] - offsets[0] : 0;
     {
         SortGeometry geo;
         int rc0 = shard_checks(h, n_global_sweeps, &geo);
         if (rc0) return rc0;
         if (n_local_sweeps < 0 || first_global_sweep < 0 || first_global_sweep + n_local_sweeps > n_global_sweeps || first_point_in_sweep < 0 ||
-            (n_local_sweeps > 0 && (!params || !offsets || !d_xyzi)))
+            (n_local_sweeps > 0 && (!params || !offsets || !d_xyzi)) || n_local < 0 || n_local >= (1ll << 31) || n_global_sweeps > 512)
             return fail(h, GEM_ERR_INVALID, "gem_add_sharded_device: bad argument");
-        hipSetDevice(h->device);
         if (!h->sh_host) GEM_HIP(h, hipHostMalloc(&h->sh_host, kShardHostBytes, hipHostMallocDefault));
-        if ((rc0 = ensure(h, h->sh_dev, 4096 + sizeof(float) * 512))) return rc0;
+        if ((rc0 = ensure(h, h->sh_dev, kShardDevBytes))) return rc0;
+        if (W > 1) {
+            // both sets of receive buffers, for what a step can bring at most: gem_reserve's bound when there is
+            // one, else W shares like this rank's (the ranks hold N / W points each, and no strip gets more records than there are points)
+            const long long bound = h->recv_bound > 0 ? h->recv_bound : (n_local + 1) * W;
+            if ((rc0 = ensure_recv(h, 0, (size_t)bound + 4 * W)) || (rc0 = ensure_recv(h, 1, (size_t)bound + 4 * W))) return rc0;
+        }
     }
+    // A pending step's sorted records live in a pass-buffer set of their own only if its sort rotated (big shards on the handle's
+    // own streams); a sort that does not -- small shards, a caller's stream -- would overwrite them: finish the pending step first.
+    if (h->step.valid && !(h->step.sd.slot >= 0 && shard_sort_rotates(h, n_local))) { const int rcs = shard_finish_locked(h); if (rcs) return rcs; }
     // the sort leaves this rank's strip boundaries on the device (k_strip_bounds' output, 16 words reserved) ...
     int rc = shard_sort_locked(h, n_local_sweeps, params, d_xyzi, offsets, first_global_sweep, n_global_sweeps, first_point_in_sweep, W, h->strip_row,
                                nullptr, nullptr, nullptr, nullptr, true);
-    if (rc) return rc;
+    if (rc) return W > 1 ? step_abort(h, rc) : rc;
     hipSetDevice(h->device);
     gem_handle::Shard& sd = h->shard;
-    const uint32_t my_blk0 = (uint32_t)((h->row0 / 32) * ((h->L + 31) / 32)) << 2;
     hipStream_t sorted_on = sd.slot >= 0 ? nullptr : h->stream;
     if (W == 1) {
         // one rank: its own sorted records, in place, through their block ranges -- no exchange, nothing returns to the host
@@ -2088,63 +2437,24 @@ int gem_add_sharded_device(gem_handle* h, int n_local_sweeps, const gem_frame_pa
         if (!sd.hv) return shard_fuse_locked(h, 1, none, none, cnt, nullptr, nullptr, n_global_sweeps, var_updates_global);
         return shard_fuse_locked(h, 1, none, none, cnt, nullptr, nullptr, n_global_sweeps, var_updates_global, &sd, sd.slot);
     }
-    // ... and every rank learns what it receives from whom -- and what it sends -- from ONE all-gather of them (W + 1 words per
-    // rank) and one host round trip, on the communication stream: behind the previous step's all-gather of the layers, which
-    // meanwhile overlapped this step's sort
-    uint32_t* host = static_cast<uint32_t*>(h->sh_host);
-    const uint32_t* d_mine = sd.d_bounds; uint32_t* d_all = static_cast<uint32_t*>(h->sh_dev.p) + 64;   // [W][16]
+    // the second half of the step before (its boundaries are on the host, or will be as soon as its sort is through)
+    if ((rc = shard_finish_locked(h))) return rc;
+    // ... and every rank learns what it receives from whom -- and what it sends -- from ONE all-gather of them (16 words per rank),
+    // copied to the host behind it on the communication stream; the next call (or settle) picks them up
+    const int q = (int)(h->step_seq++ & 1u);
+    uint32_t* host = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(h->sh_host) + 4096 * q);
+    uint32_t* d_all = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(h->sh_dev.p) + 4096 * q) + 64;   // [W][16]
     if (sorted_on) { GEM_HIP(h, hipEventRecord(h->ev_sorted, sorted_on)); GEM_HIP(h, hipStreamWaitEvent(h->comm_stream, h->ev_sorted, 0)); }
     else GEM_HIP(h, hipStreamWaitEvent(h->comm_stream, h->pb[sd.slot].bin_done, 0));
-    if (h->walk_recorded) GEM_HIP(h, hipStreamWaitEvent(h->comm_stream, h->ev_walked, 0));          // the previous walk has read the receive buffers
-    ncclResult_t r = ncclAllGather(d_mine, d_all, 16, ncclUint32, h->comm, h->comm_stream);
-    if (r != ncclSuccess) return fail(h, GEM_ERR_COMM, ncclGetErrorString(r));
+    if (h->step_timed) { GEM_HIP(h, hipEventRecord(h->ev_t[1], h->comm_stream)); }
+    if (!h->tp_x->all_gather(sd.d_bounds, d_all, 16, h->comm_stream)) return fail(h, GEM_ERR_COMM, h->tp_x->err.c_str());
     GEM_HIP(h, hipMemcpyAsync(host + 64, d_all, (size_t)W * 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->comm_stream));
-    GEM_HIP(h, hipStreamSynchronize(h->comm_stream));
-    for (int k = 0; k <= W; ++k) sd.bounds[k] = host[64 + h->rank * 16 + k];
-    const int tpr = (h->L + 31) / 32;
-    auto strip_blocks = [&](int p) { return (size_t)4 * tpr * ((std::min(h->strip_row[p + 1], tpr * 32) + 31) / 32 - h->strip_row[p] / 32); };
-    const size_t my_blocks = strip_blocks(h->rank);
-    uint32_t cnt[kMaxRanks], off[kMaxRanks + 1], base[kMaxRanks];
-    off[0] = 0;
-    for (int s = 0; s < W; ++s) {
-        base[s] = host[64 + s * 16 + h->rank];
-        cnt[s] = host[64 + s * 16 + h->rank + 1] - base[s];
-        off[s + 1] = off[s] + (s == h->rank ? 0u : ((cnt[s] + 3u) & ~3u));      // (this rank's own records stay where they are)
-    }
-    if ((rc = ensure(h, h->sh_recv_hv, (size_t)off[W] * 8 + 64))) return rc;
-    if ((rc = ensure(h, h->sh_recv_key, (size_t)off[W] * 4 + 64))) return rc;
-    if ((rc = ensure(h, h->sh_recv_rng, (size_t)W * my_blocks * sizeof(uint2) + 64))) return rc;
-    uint2* rhv = static_cast<uint2*>(h->sh_recv_hv.p); uint32_t* rkey = static_cast<uint32_t*>(h->sh_recv_key.p);
-    uint2* rrng = static_cast<uint2*>(h->sh_recv_rng.p);
-    // the exchange: every strip's records and their block ranges to the strip's owner
-    r = ncclGroupStart();
-    for (int p = 0; p < W && r == ncclSuccess; ++p) {
-        if (p == h->rank) continue;
-        const uint32_t sc = sd.bounds[p + 1] - sd.bounds[p];
-        if (sc > 0) {
-            const uint32_t p_blk0 = (uint32_t)((h->strip_row[p] / 32) * tpr) << 2;
-            r = ncclSend(sd.hv + sd.bounds[p], (size_t)sc * 2, ncclUint32, p, h->comm, h->comm_stream);
-            if (r == ncclSuccess) r = ncclSend(sd.key + sd.bounds[p], sc, ncclUint32, p, h->comm, h->comm_stream);
-            if (r == ncclSuccess) r = ncclSend(sd.ranges + p_blk0, strip_blocks(p) * 2, ncclUint32, p, h->comm, h->comm_stream);
-        }
-        if (r == ncclSuccess && cnt[p] > 0) {
-            r = ncclRecv(rhv + off[p], (size_t)cnt[p] * 2, ncclUint32, p, h->comm, h->comm_stream);
-            if (r == ncclSuccess) r = ncclRecv(rkey + off[p], cnt[p], ncclUint32, p, h->comm, h->comm_stream);
-            if (r == ncclSuccess) r = ncclRecv(rrng + (size_t)p * my_blocks, my_blocks * 2, ncclUint32, p, h->comm, h->comm_stream);
-        }
-    }
-    ncclResult_t r2 = ncclGroupEnd();
-    if (r != ncclSuccess || r2 != ncclSuccess) return fail(h, GEM_ERR_COMM, ncclGetErrorString(r != ncclSuccess ? r : r2));
-    GEM_HIP(h, hipEventRecord(h->ev_exchanged, h->comm_stream));
-    GEM_HIP(h, hipStreamWaitEvent(h->stream, h->ev_exchanged, 0));
-    const void* phv[kMaxRanks]; const void* pkey[kMaxRanks]; const void* prng[kMaxRanks];
-    for (int s = 0; s < W; ++s) {
-        const bool mine = s == h->rank;
-        phv[s] = cnt[s] ? (mine ? (const void*)(sd.hv + base[s]) : (const void*)(rhv + off[s])) : nullptr;
-        pkey[s] = cnt[s] ? (mine ? (const void*)(sd.key + base[s]) : (const void*)(rkey + off[s])) : nullptr;
-        prng[s] = cnt[s] ? (mine ? (const void*)(sd.ranges + my_blk0) : (const void*)(rrng + (size_t)s * my_blocks)) : nullptr;
-    }
-    return shard_fuse_locked(h, W, phv, pkey, cnt, prng, base, n_global_sweeps, var_updates_global, nullptr, sd.slot);
+    GEM_HIP(h, hipEventRecord(h->ev_bounds[q], h->comm_stream));
+    gem_handle::Step& st = h->step;
+    st.valid = true; st.parity = q; st.n_global_sweeps = n_global_sweeps; st.sd = sd; st.gather = false; st.gather_attrs = 0;
+    st.has_vu = var_updates_global != nullptr;
+    if (st.has_vu) memcpy(st.vu, var_updates_global, sizeof(float) * n_global_sweeps);
+    return GEM_OK;
 }
 
 } // extern "C"

@@ -6,8 +6,10 @@ devices.  Every rank bins the whole cloud but fuses only the cells of its strip 
 independent given their ordered point lists, so the result is exactly the single-device one);
 the fused strips are then exchanged with an all-gather:
 
-  exchange="rccl"   gem_allgather_layers(): RCCL ncclAllGather / grouped ncclBroadcast over xGMI,
-                    issued by the C ABI on the handle's stream (the product path)
+  exchange="rccl"   gem_allgather_layers(): grouped ncclSend / ncclRecv over xGMI, issued by the C ABI on the handle's
+                    gather stream (the product path)
+  exchange="loopback"  the same C code with the RCCL calls replaced by device-to-device copies: `world` handles of ONE
+                    process on ONE device, one thread per handle (include/gem_hip_debug.h; how the GPU suite covers W > 1)
   exchange="torch"  torch.distributed collectives on tensors aliasing the layers (NCCL == RCCL on
                     ROCm; gloo on CPU, which is how the host logic is tested without GPUs)
 """
@@ -99,7 +101,7 @@ class TiledElevationMap:
     rank bins only ITS share of the points; the sorted records travel to the strip owners)."""
 
     def __init__(self, length: int, resolution: float, rank: int, world: int, make_map: Optional[Callable] = None,
-                 exchange: str = "rccl", unique_id: Optional[bytes] = None, tile_strips: bool = False, **map_kwargs):
+                 exchange: str = "rccl", unique_id: Optional[bytes] = None, tile_strips: bool = False, world_id: int = 0, **map_kwargs):
         self.length, self.resolution, self.rank, self.world = int(length), float(resolution), int(rank), int(world)
         self.tile_strips = bool(tile_strips)
         self.strip_rows = tile_strip_rows(length, world) if tile_strips else [strip_bounds(length, world, r)[0] for r in range(world)] + [length]
@@ -114,8 +116,10 @@ class TiledElevationMap:
             if unique_id is None:
                 raise ValueError("exchange='rccl' needs the ncclUniqueId created by rank 0 (ElevationMap.comm_unique_id())")
             (self.map.comm_init_tiles if tile_strips else self.map.comm_init)(unique_id, world, rank)
+        elif exchange == "loopback":
+            self.map.comm_init_loopback(world_id, world, rank, tile_strips)
         elif exchange != "torch":
-            raise ValueError("exchange must be 'rccl' or 'torch'")
+            raise ValueError("exchange must be 'rccl', 'loopback' or 'torch'")
 
     # -- stage B: the points sharded, the sorted records routed to the strip owners -----------------------------------------------
     def add_sharded(self, frames, xyzi, offsets, var_updates=None, group=None) -> None:
@@ -129,7 +133,7 @@ class TiledElevationMap:
         local_frames = [frames[first + i] for i in range(len(local) - 1)]
         pb = self.map.pack_batch(local_frames, local, None)
         fp = first_point_in_sweep(offsets, first, local)
-        if self.exchange == "rccl":
+        if self.exchange in ("rccl", "loopback"):
             self.map.add_sharded(pb, xyzi, first, n_global, var_updates, fp)
             return
         # the exchange carried by torch.distributed (gloo on CPU stand-ins, NCCL == RCCL on devices)
@@ -183,7 +187,7 @@ class TiledElevationMap:
 
     def allgather(self, with_attributes: bool = False, group=None) -> None:
         """Make every rank's copy of the fused layers complete."""
-        if self.exchange == "rccl":
+        if self.exchange in ("rccl", "loopback"):
             self.map.allgather_layers(with_attributes)
             return
         names = ("elevation", "variance") + (("intensity", "color_r", "color_g", "color_b") if with_attributes else ())

@@ -29,8 +29,21 @@ extern "C" {
  *       number: which of the handle's current own / bin / bin2 / upload streams takes each role; tools/dbg/roles.py).  Returns GEM_ERR_INVALID for an unknown key or a value out of range. */
 int gem_debug_set(gem_handle* h, const char* key, long long value);
 
-/* read-outs: "arena_allocations" (device allocations the handle's arenas have made so far: none may follow gem_reserve) */
+/* read-outs: "arena_allocations" (device allocations the handle's arenas have made so far: none may follow gem_reserve),
+ *            "sort_fallbacks" (passes whose forced sorted form / pass count did not fit the map and took the other form),
+ *            "step_pending" (1: the second half of a gem_add_sharded_device step is still to come),
+ *            "step_exchange_ns", "step_walk_ns", "step_publish_ns", "step_gather_ns", "step_exchange_to_walk_ns": device time stamps of
+ *            the last finished multi-rank step (recorded while gem_set_timing is on; read after gem_synchronize; -1 = not recorded) */
 int gem_debug_get(gem_handle* h, const char* key, long long* out);
+
+/* LOOPBACK communicator: nranks handles of THIS process, on ONE device, join the world `world_id` (any number the caller picks,
+ * unique per group of handles) as ranks 0 .. nranks - 1, with row strips (tile_strips = 0, like gem_comm_init) or strips of whole
+ * tile rows (1, like gem_comm_init_tiles).  From then on gem_add_sharded_device / gem_allgather_layers run the very code of the
+ * multi-GPU path -- boundaries, counts, offsets, buffer rotation, stream order -- with the RCCL calls replaced by device-to-device
+ * copies ordered by events (csrc/gem_transport.hpp).  Every handle must be driven by a host thread of its own (a collective waits
+ * for all ranks, as on real ranks); a send that meets no receive of the same size is an error instead of a hang.  Test
+ * infrastructure for one-GPU boxes: it is how the W > 1 code is covered where only one device exists. */
+int gem_comm_init_loopback(gem_handle* h, long long world_id, int nranks, int rank, int tile_strips);
 
 /* per-tile cycle stamps of the last fuse launch ([tile][16] 64-bit counters); enable != 0 turns the stamps on for the
  * following passes; with out != NULL copies up to max_tiles rows and returns their number */
