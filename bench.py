@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU-oracle leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary (batched C4) measurement")
+    ap.add_argument("--workload", choices=["c2", "c5"], default=None,
+                    help="default: c2 (the headline configuration) at --gpus 1, c5 at --gpus N > 1; `--workload c5 --gpus 1` times C5 through the "
+                         "same sharded entry points on one rank -- the like-for-like N = 1 point of the scaling curve")
     return ap.parse_args()
 
 
@@ -406,72 +409,107 @@ def c2_variants(emap_cls, dev, torch, reps: int = 400):
     return out
 
 
-# ---- N > 1: C5, strong scaling ------------------------------------------------------------------------------------------------
+# ---- C5 through the sharded entry points: N > 1 (strong scaling), or N = 1 with --workload c5 -----------------------------------
 def run_c5_distributed(args, torch, dist, world, rank, local_rank, dev):
-    from gem_amd import ElevationMap
+    """BASELINE configs[4] on `world` ranks: gem_add_sharded_device + gem_allgather_layers per step.  With one rank (--workload c5
+    --gpus 1) the same entry points run without an exchange: the like-for-like N = 1 point of the scaling curve."""
+    from gem_amd import ElevationMap, synth
     from gem_amd.tiling import first_point_in_sweep, shard_batch, tile_strip_rows
-    wl, cat, off = c5_cloud()
+    off = synth.c5_offsets()
     n_total = int(off[-1])
     first, local = shard_batch(off, world, rank)
     fp = first_point_in_sweep(off, first, local)
-    # only this rank's share of the cloud has to be resident
-    d_share = torch.from_numpy(cat[local[0]:local[-1]]).to(dev)
+    # only this rank's share of the cloud is generated and made resident (every sweep has its own seed)
+    mine = list(range(first, first + len(local) - 1))
+    wl = synth.config_c5(sweeps=mine)
+    share = np.concatenate([wl.clouds[k] for k in mine])[local[0] - int(off[first]):][: local[-1] - local[0]] if mine else np.zeros((0, 4), np.float32)
+    d_share = torch.from_numpy(np.ascontiguousarray(share)).to(dev)
+    n_sweeps = len(wl.frames)
+
+    def bcast_uid(n):
+        uid = [ElevationMap.comm_unique_id() if rank == 0 else None for _ in range(n)]
+        if dist is not None:
+            dist.broadcast_object_list(uid, src=0)
+        return uid
+
+    def barrier(*maps):
+        if dist is not None:
+            dist.barrier()
+        for m in maps:
+            m.synchronize()
+        torch.cuda.synchronize()
+
+    def all_max(v):
+        if dist is None:
+            return float(v)
+        t = torch.tensor([v], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    uid = bcast_uid(2)                                       # one communicator for the timed map, one for the checked map
     emap = ElevationMap(wl.length, wl.resolution, device=local_rank)
-    uid = [ElevationMap.comm_unique_id() if rank == 0 else None, ElevationMap.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(uid, src=0)                  # one communicator for the timed map, one for the checked map
     emap.comm_init_tiles(uid[0], world, rank)
+    emap.reserve(n_total, n_sweeps)                          # the step's arenas, both sets of receive buffers: nothing allocates inside the timed loop
     pb = emap.pack_batch([wl.frames[first + i] for i in range(len(local) - 1)], [v - local[0] for v in local], None)
 
-    def step():
-        emap.add_sharded(pb, d_share, first, len(wl.frames), None, fp)
-        emap.allgather_layers(False)
+    def step(gather=True):
+        emap.add_sharded(pb, d_share, first, n_sweeps, None, fp)
+        if gather:
+            emap.allgather_layers(False)
 
-    def barrier():
-        dist.barrier()
-        emap.synchronize()
-        torch.cuda.synchronize()
+    def timed(k, gather=True):
+        barrier(emap)
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step(gather)
+        barrier(emap)
+        return all_max(time.perf_counter() - t0)
 
     for _ in range(args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = timed(args.steps)
+    # the same steps without the all-gather of the layers (what the exchange + walk pipeline does on its own)
+    elapsed_nogather = timed(args.steps, gather=False)
     # what every rank holds after the all-gather is the whole map: check it against the committed digest of ONE pass
     chk = ElevationMap(wl.length, wl.resolution, device=local_rank)
     chk.comm_init_tiles(uid[1], world, rank)
-    chk.add_sharded(pb, d_share, first, len(wl.frames), None, fp)
+    chk.add_sharded(pb, d_share, first, n_sweeps, None, fp)
     chk.allgather_layers(False)
     d = golden()["c5_full"]
     ok = sha(chk.layer("elevation")) == d["elevation"] and sha(chk.layer("variance")) == d["variance"]
-    okt = torch.tensor([1 if ok else 0], device=dev); dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-    # per-phase kernel times of this rank
+    if dist is not None:
+        okt = torch.tensor([1 if ok else 0], device=dev); dist.all_reduce(okt, op=dist.ReduceOp.MIN); ok = bool(okt.item() == 1)
+    # per-phase device times of this rank: kernel dispatch stamps (sort, walk) and, on W > 1, events on the streams the phases run on
     emap.set_timing(True); emap.stats(reset=True)
-    for _ in range(max(args.steps // 4, 2)):
+    n_ph = max(args.steps // 4, 2)
+    for _ in range(n_ph):
         step()
-    st = emap.stats(); emap.set_timing(False)
-    reps = max(st["launches_walk"], 1)
-    us_sort = 1e3 * sum(st["ms_sort"]) / reps; us_walk = 1e3 * st["ms_walk"] / reps
+    st = emap.stats()                                        # (synchronises: the last step's second half included)
+    phases = {"sort_kernels_sum": 1e3 * sum(st["ms_sort"]) / max(st["launches_walk"], 1), "k_fuse_block": 1e3 * st["ms_walk"] / max(st["launches_walk"], 1)}
+    if world > 1:
+        for key in ("exchange", "exchange_to_walk", "walk", "publish", "gather"):
+            ns = emap.debug_get(f"step_{key}_ns")
+            phases[key] = None if ns < 0 else ns / 1e3
+    emap.set_timing(False)
     us_step = 1e6 * elapsed / args.steps
+    us_step_nogather = 1e6 * elapsed_nogather / args.steps
     rows = tile_strip_rows(wl.length, world)
-    barrier()
+    barrier(emap, chk)
     emap.close(); chk.close()
     del d_share
-    # the SAME workload on one GPU, by rank 0 in this process while the other ranks wait: what the speed-up is measured against
+    # the SAME workload through the plain one-GPU call, by rank 0 in this process while the other ranks wait: what the speed-up is measured against
     one = cpu = None
     if rank == 0:
-        one = c5_one_gpu(ElevationMap, dev, torch, reps=max(6, min(args.steps, 20)), wl=wl, cat=cat, off=off)
+        wl_full, cat, off_full = c5_cloud()
+        one = c5_one_gpu(ElevationMap, dev, torch, reps=max(6, min(args.steps, 20)), wl=wl_full, cat=cat, off=off_full)
         if not args.no_cpu_baseline:
-            cpu = cpu_baseline_c5(wl, cat, off, args.cpu_seconds)
-    dist.barrier()
+            cpu = cpu_baseline_c5(wl_full, cat, off_full, args.cpu_seconds)
+    if dist is not None:
+        dist.barrier()
     out = None
     if rank == 0:
         alg = 16.0 * n_total + 16.0 * one["cells_touched"]
+        gathered_bytes = 8.0 * wl.length * wl.length * (world - 1) / world          # elevation + variance of the other ranks' strips, received per rank and step
         out = {
             "metric": "fused points/sec into 2400x2400 grid (BASELINE configs[4]); achieved HBM GB/s vs roofline",
             "value": n_total * args.steps / elapsed, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -479,15 +517,20 @@ def run_c5_distributed(args, torch, dist, world, rank, local_rank, dev):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C5 (BASELINE configs[4]): single 10 M-point aggregated cloud (77 sweeps) -> 2400x2400 @ 0.05 m grid per step, "
                                    "points sharded by index range over the ranks, sorted records routed to tile-row strip owners (RCCL send/recv), "
-                                   "RCCL all-gather of the fused elevation + variance layers",
+                                   "RCCL all-gather of the fused elevation + variance layers" + (" -- ONE rank: no exchange, no all-gather" if world == 1 else ""),
                        "points_per_step": n_total, "grid": "2400x2400@0.05m", "parallelism": f"shard{world}+strips{world}", "strip_rows": rows},
             "one_gpu_us_per_step": one["us_per_step"], "speedup_vs_one_gpu": one["us_per_step"] / us_step, "c5_one_gpu": one,
-            "phases_us_rank0": {"sort_kernels": us_sort, "k_fuse_block": us_walk, "exchange_allgather_and_gaps": max(us_step - us_sort - us_walk, 0.0),
-                                "step": us_step},
+            "value_without_allgather": n_total * args.steps / elapsed_nogather, "us_per_step_without_allgather": us_step_nogather,
+            "allgather_us": phases.get("gather"), "allgather_bytes_received_per_rank": gathered_bytes if world > 1 else 0.0,
+            "allgather_GBps_per_rank": (gathered_bytes / (phases["gather"] * 1e-6) / 1e9) if world > 1 and phases.get("gather") else None,
+            "phases_us_rank0": dict(phases, step=us_step,
+                                    note="device time of each phase of ONE step on the stream it runs on (sort on the binning streams, exchange on the "
+                                         "communication stream, walk + publish on the handle's stream, gather on the gather stream); consecutive steps "
+                                         "overlap them, so the step's period is about the longest phase, not their sum (DESIGN.md section 7)"),
             "roofline": {"bound": "hbm", "kernel": "pipeline (per rank)", "achieved": alg / world / (us_step * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": alg / world / (us_step * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "note": "SURVEY 8d algorithmic bytes of the whole cloud / ranks / step time; the all-gather adds 46 MB received per rank and step"},
-            "parity_checked": bool(okt.item() == 1 and one["parity_checked"]),
+                         "note": "SURVEY 8d algorithmic bytes of the whole cloud / ranks / step time; the all-gather adds 46 MB x (W - 1) / W received per rank and step"},
+            "parity_checked": bool(ok and one["parity_checked"]),
             "parity": "every rank's all-gathered map after one pass == tests/golden/digests.json c5_full (elevation, variance); so is the one-GPU map",
         }
         if cpu is not None:
@@ -565,22 +608,29 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1 or bool(os.environ.get("GEM_BENCH_FORCE_DIST"))      # the env var exercises the N > 1 code path with one rank
+    workload = args.workload or ("c5" if world > 1 else "c2")
+    if workload == "c2" and world > 1:
+        raise SystemExit("--workload c2 is a single-GPU configuration (BASELINE configs[1]); N > 1 runs C5 (configs[4])")
+    distributed = workload == "c5" or bool(os.environ.get("GEM_BENCH_FORCE_DIST"))      # (the env var: the N > 1 code path with one rank, kept for older scripts)
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
-        if "MASTER_ADDR" not in os.environ:
-            os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ.setdefault("MASTER_PORT", "29655")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        out = run_c5_distributed(args, torch, dist, world, rank, local_rank, dev)
+        use_dist = world > 1
+        if use_dist:
+            if "MASTER_ADDR" not in os.environ:
+                os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ.setdefault("MASTER_PORT", "29655")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        out = run_c5_distributed(args, torch, dist if use_dist else None, world, rank, local_rank, dev)
         if rank == 0:
             emit(out)
             if not out["parity_checked"]:
-                dist.destroy_process_group()
+                if use_dist:
+                    dist.destroy_process_group()
                 raise SystemExit("parity check FAILED: the tiled map differs from the committed digest")
-        dist.destroy_process_group()
+        if use_dist:
+            dist.destroy_process_group()
         return
 
     wl = synth.config_c4(n_sweeps=N_DISTINCT, seed0=100)

@@ -139,23 +139,36 @@ def config_c4(n_sweeps: int = 32, seed0: int = 100) -> Workload:
     return Workload("C4", 600, 0.05, clouds, frames, var_updates=upd)
 
 
-def config_c5(n_points: int = 10_000_000, seed: int = 5, length: int = 2400) -> Workload:
-    """aggregated cloud: 76 C2-style sweeps from a Lissajous path over 100 m x 100 m, concatenated in
-    sweep order -> 2400 x 2400 @ 0.05 m.  Each sweep keeps its own transform (the aggregation is a batch)."""
+def c5_offsets(n_points: int = 10_000_000) -> np.ndarray:
+    """offsets[n_sweeps + 1] of config_c5's concatenated cloud (every sweep 64 x 2048 points, the last one cut)."""
     per = 64 * 2048
     n_sweeps = (n_points + per - 1) // per
+    return np.minimum(np.arange(n_sweeps + 1, dtype=np.int64) * per, n_points)
+
+
+def config_c5(n_points: int = 10_000_000, seed: int = 5, length: int = 2400, sweeps=None) -> Workload:
+    """aggregated cloud: 76 C2-style sweeps from a Lissajous path over 100 m x 100 m, concatenated in
+    sweep order -> 2400 x 2400 @ 0.05 m.  Each sweep keeps its own transform (the aggregation is a batch).
+    sweeps: generate only these sweeps' clouds (the others are None; every sweep has its own seed) -- a rank of the multi-GPU
+    bench needs its share only; the frames are always complete."""
+    per = 64 * 2048
+    n_sweeps = (n_points + per - 1) // per
+    want = None if sweeps is None else set(int(k) for k in sweeps)
     clouds, frames = [], []
     for k in range(n_sweeps):
-        rng = np.random.default_rng(seed * 1000 + k)
         ph = 2 * np.pi * k / n_sweeps
         x, y = 50.0 * np.sin(3 * ph), 50.0 * np.sin(2 * ph + 0.5)
         yaw = np.arctan2(2 * np.cos(2 * ph + 0.5), 3 * np.cos(3 * ph))
         T = pose_matrix(x, y, 1.73, yaw, np.deg2rad(1.0), np.deg2rad(-0.5))
+        frames.append(_frame_for(T, SensorModel.velodyne()))
+        if want is not None and k not in want:
+            clouds.append(None)
+            continue
+        rng = np.random.default_rng(seed * 1000 + k)
         c = lidar_sweep(rng, T)
         if k == n_sweeps - 1:
             c = c[: n_points - per * (n_sweeps - 1)]
         clouds.append(c)
-        frames.append(_frame_for(T, SensorModel.velodyne()))
     return Workload("C5", length, 0.05, clouds, frames)
 
 
