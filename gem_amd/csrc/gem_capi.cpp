@@ -106,6 +106,9 @@ struct gem_handle {
     bool fast_laser = true;             // frames that qualify use the zero-rotation-variance form of the laser variance (fill_frame; debug knob)
     bool rank_by_ballot = false;        // k_sort_scatter ranks by ballot in every pass (debug knob)
     bool lane_sort = true;              // k_fuse_block: cells to threads by record count (debug knob)
+    int  walk_lds_pad = 0;              // k_fuse_block: extra dynamic LDS per workgroup (debug knob: fewer workgroups per CU)
+    int  walk_prio = 4096;              // k_fuse_block: blocks of at least this many records run at raised issue priority (debug knob, 0 = off)
+    bool plain_loop = true;             // the walks' plain chain loop for blocks whose values are in range (debug knob: 0 = the guarded loop everywhere)
     int  sort_form = 0;                 // 0 = batches of sweeps BLOCK-sorted (k_fuse_block), single clouds CELL-sorted (k_fuse_walk); 1 / 2 force cell / block
     int dbg_sweep = 0;                  // debug stamps of the dense path: which sweep (GEM_DBG_SWEEP)
     bool track_lowest = false;          // also maintain map_lowest in the fuse kernels (gem_set_lowest_tracking, for gem_raytracing)
@@ -675,6 +678,8 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     wa.dense = dense ? 1 : 0;
     wa.n_pending = h->n_pending;
     for (int i = 0; i < kMaxPending; ++i) wa.pending[i] = h->pending[i];
+    wa.plain_env = h->plain_loop ? walk_plain_env(wa.var_floor, wa.mahal, h->pending, h->n_pending, batched ? in.var_updates : nullptr, in.n_sweeps) : 0;
+    wa.prio_records = h->walk_prio; wa.lds_pad = h->walk_lds_pad;
     wa.elevation = h->layers.elevation; wa.variance = h->layers.variance; wa.lowest = h->layers.lowest;
     wa.start0 = h->start[0]; wa.start1 = h->start[1];
     wa.intensity = h->layers.intensity; wa.colorR = h->layers.colorR; wa.colorG = h->layers.colorG; wa.colorB = h->layers.colorB;
@@ -1877,6 +1882,9 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "sort_passes")        { if (value < 0 || value > 3) return fail(h, GEM_ERR_INVALID, "sort_passes: 0..3"); h->sort_passes = (int)value; }
     else if (k == "rank_by_ballot")     h->rank_by_ballot = value != 0;
     else if (k == "lane_sort")          h->lane_sort = value != 0;
+    else if (k == "plain_loop")         h->plain_loop = value != 0;
+    else if (k == "walk_lds_pad")       { if (value < 0 || value > 100 * 1024) return fail(h, GEM_ERR_INVALID, "walk_lds_pad: 0 .. 102400 bytes"); h->walk_lds_pad = (int)value; }
+    else if (k == "walk_prio")          { if (value < 0 || value > (1 << 30)) return fail(h, GEM_ERR_INVALID, "walk_prio: 0 (off) or a record count"); h->walk_prio = (int)value; }
     else if (k == "blk_batch")          { if (value != 0 && value != 512 && value != 2048) return fail(h, GEM_ERR_INVALID, "blk_batch: 0 (by pass), 512 or 2048"); h->blk_batch = (int)value; }
     else if (k == "few_bins")           { if (value < -1 || value > 64) return fail(h, GEM_ERR_INVALID, "few_bins: -1 (one ballot per digit bit), 0 (by pass), 1..64"); h->few_bins = (int)value; }
     else if (k == "ray_depth")          { if (value != 4 && value != 8) return fail(h, GEM_ERR_INVALID, "ray_depth: 4 or 8"); h->ray_depth = (int)value; }
@@ -2224,6 +2232,8 @@ int shard_fuse_locked(gem_handle* h, int n_src, const void* const* d_hv, const v
     wa.dense = (h->n_pending > 0 || h->floor_dirty || var_updates_global != nullptr) ? 1 : 0;
     wa.n_pending = h->n_pending;
     for (int i = 0; i < kMaxPending; ++i) wa.pending[i] = h->pending[i];
+    wa.plain_env = h->plain_loop ? walk_plain_env(wa.var_floor, wa.mahal, h->pending, h->n_pending, var_updates_global, n_global_sweeps) : 0;
+    wa.prio_records = h->walk_prio; wa.lds_pad = h->walk_lds_pad;
     wa.elevation = h->layers.elevation; wa.variance = h->layers.variance; wa.lowest = h->layers.lowest;
     wa.start0 = h->start[0]; wa.start1 = h->start[1];
     wa.counters = h->counting ? h->d_counters : nullptr;

@@ -172,6 +172,9 @@ struct WalkArgs {
     int   lane_sort;                   // 1: the block's cells are handed to the threads in descending order of their record count in the first batch
     int light_blocks;                  // k_fuse_block: rounds of 512 records instead of 2048 (blocks of a few hundred records)
     int   exact_bins;                  // 1: the last pass's bins ARE the blocks (one-pass sort): bin_base gives a block's records without a search
+    int   lds_pad;                     // k_fuse_block: unused dynamic LDS on top of what the kernel needs (debug knob)
+    int   prio_records;                // k_fuse_block: blocks of at least this many records raise their waves' issue priority (0 = off)
+    int   plain_env;                   // 1: floor, threshold and every variance increment of the pass lie in the range the walks' plain chain loop assumes (walk_plain_env)
     // multi-GPU strip owner (gem_add_sharded_device): the block-sorted records received from every rank, taken in rank order
     int   n_src;                       // <= 1: the single source above (hv / key / src, searched through bin_base)
     const uint2* src_hv[kMaxRanks]; const uint32_t* src_key[kMaxRanks]; uint32_t src_n[kMaxRanks];
@@ -179,6 +182,17 @@ struct WalkArgs {
     // in the source's own arrays, src_hv / src_key point at position src_base.  NULL: the block's records are found by search.
     const uint2* src_ranges[kMaxRanks]; uint32_t src_base[kMaxRanks]; uint32_t blk0;
 };
+
+// Are the pass's constants inside the range the plain chain loops assume (gem_sort.hip, k_fuse_block): floor in [2^-28, 2^28], a
+// finite positive threshold, every increment in [0, 2^18] (at most 512 + 4 of them: their sum stays below 2^28)?
+inline int walk_plain_env(float var_floor, float mahal, const float* pending, int n_pending, const float* var_updates, int n_sweeps)
+{
+    auto inc_ok = [](float u) { return u >= 0.0f && u <= 262144.0f; };
+    bool ok = var_floor >= 3.7252902984619140625e-9f && var_floor <= 268435456.0f && mahal > 0.0f && mahal <= 268435456.0f && n_sweeps <= 512;
+    for (int i = 0; i < n_pending; ++i) ok = ok && inc_ok(pending[i]);
+    if (var_updates) for (int i = 0; i < n_sweeps && ok; ++i) ok = ok && inc_ok(var_updates[i]);
+    return ok ? 1 : 0;
+}
 
 struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };   // optional dispatch time-stamps
 struct SortShape { int nt, chunk; size_t lds; };

@@ -884,7 +884,9 @@ __host__ __device__ constexpr size_t block_walk_lds()
            + (size_t)4 * 320 * 4 + (B > 512 ? (size_t)4 * 320 * 8 : 0) + (size_t)4 * 256 * 4;           // cursors, masks (rounds of more than 512 records), bases
 }
 
-template <int FLAGS, int MODE, int B>
+// MULTI: several sources (a multi-GPU strip owner).  A kernel of its own: with both forms in one, the values the next batch's loads
+// bring were copied between the two forms' registers where the paths join -- behind an `s_waitcnt vmcnt(0)`, right after the loads.
+template <int FLAGS, int MODE, int B, bool MULTI>
 __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
 {
     constexpr int ATTR = FLAGS & 3;
@@ -910,7 +912,19 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
     __shared__ float vu[HAS_VU ? kWalkMaxSweeps + 8 : 1];
     __shared__ uint32_t seg_first[kMaxRanks], seg_off[kMaxRanks + 1];                  // per source: first record of the block; prefix of the counts
     __shared__ unsigned long long seg_key[kMaxRanks], seg_hv[kMaxRanks];
+    __shared__ uint32_t blk_odd;                                                       // some record or cell state of this block is outside the plain range (below)
     const int tid = (int)threadIdx.x, lane = lane_id(), w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // The PLAIN chain loop (the blocks of every LiDAR pass): one step of the recurrence is a single wave issuing ~90 instructions in
+    // order, a third of them guards -- the exponent ranges that let both Kalman quotients share one reciprocal (fuse_step<true>), the
+    // subnormal test of the Mahalanobis shortcut, the increments' replay with a ballot and a branch per sweep.  All of that is
+    // decidable OUTSIDE the chain: if every record of the block has |h| <= 2^28 and 2^-28 <= v <= 2^28 (checked where the records
+    // are placed, in parallel), every cell starts with |e| <= 2^28 and s <= 2^28 (checked here), and the pass's floor / threshold /
+    // increments are in range (a.plain_env, checked by the host), then at every step sf = max(s, floor) lies in [2^-28, 2^30],
+    // D = sf + v in [2^-28, 2^31], N2 = v sf in [2^-56, 2^58], |N1| <= 2^59, |e| stays <= 2^28 -- and a step only has to look at
+    // |N1| >= 2^-60 (a cancellation) and at the threshold band.  Anything else takes the loop as it was.
+    constexpr bool PLAIN_OK = FLAGS == 0 && !COUNT_SWEEPS;
+    constexpr float kPlainHi = 268435456.0f, kPlainLo = 3.7252902984619140625e-9f;      // 2^28, 2^-28
+    if (tid == 0) blk_odd = 0u;
 
     // workgroup -> block of 256 cells: tile rows centre-first when all workgroups are resident at once (see k_fuse_walk), else memory
     // order.  (Tried: the blocks sorted by record count on the device and dealt out heavy / middle / light to consecutive
@@ -930,7 +944,7 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
     if ((tr << 5) >= a.row1 || (tr << 5) + 32 <= a.row0) return;       // a tile row outside this device's strip
     const uint32_t idmask = (1u << a.id_bits) - 1u;
     const uint32_t id0 = ((uint32_t)tile << 10) | ((uint32_t)q4 << 8); // the cell ids of this block: id0 .. id0 + 255
-    const int n_src = a.n_src <= 1 ? 1 : a.n_src;
+    const int n_src = MULTI ? (a.n_src <= 1 ? 1 : a.n_src) : 1;
     if (a.dbg && tid == 0) a.dbg[(size_t)blockIdx.x * 16] = __builtin_readcyclecounter();
 
     // ---- cell tid of the block: its map values are fetched now, coalesced, in flight behind the search; which cell the thread
@@ -939,12 +953,15 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
     const int row_t = (tr << 5) + (q4 << 3) + (tid >> 5), col_t = (tc << 5) + (tid & 31);
     const bool owned_t = row_t >= a.row0 && row_t < a.row1 && col_t < L;
     const size_t g_t = owned_t ? (size_t)row_t * L + col_t : 0;
-    sh_e[tid] = a.elevation[g_t]; sh_s[tid] = a.variance[g_t];
+    const float e_in = a.elevation[g_t], s_in = a.variance[g_t];
+    sh_e[tid] = e_in; sh_s[tid] = s_in;
     if constexpr (LOWEST) {                                            // map_lowest is indexed by the GEOGRAPHIC cell (GPU:430)
         int gr = row_t - a.start0, gc = col_t - a.start1;
         gr += gr < 0 ? L : 0; gc += gc < 0 ? L : 0;
         sh_l[tid] = a.lowest[owned_t ? (size_t)gr * L + gc : 0];
     }
+    bool odd = false;                                                  // this thread has seen a value outside the plain range
+    if constexpr (PLAIN_OK) odd = !(fabsf(e_in) <= kPlainHi) || !(s_in <= kPlainHi);
     if (tid < 128) phist[tid] = 0u;
     perm[tid] = (uint16_t)tid;
     if constexpr (HAS_VU) for (int i = tid; i < kWalkMaxSweeps + 8; i += NT) vu[i] = i < a.n_sweeps ? a.var_updates[i] : 0.0f;
@@ -968,7 +985,7 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         end = (uint32_t)__shfl((int)lo, 32, 64);
     };
     uint32_t first0 = 0;                                               // single source: the block's first record (block-uniform)
-    if (a.n_src <= 1) {
+    if constexpr (!MULTI) {
         uint32_t end;
         if (a.ranges) { const uint2 r = a.ranges[id0 >> 8]; first0 = r.x; end = r.y; }
         else { const uint32_t bin = id0 >> a.bin_shift; first0 = a.bin_base[bin]; end = a.bin_base[bin + 1]; }
@@ -994,6 +1011,11 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
     __syncthreads();
     const uint32_t R = seg_off[n_src];                                 // records of this block, all sources
     if (R == 0 && !a.dense) return;                                    // block-uniform
+    // The kernel ends with its heaviest block, and that block's time is its chains: a wave issuing one instruction after the
+    // other.  VALU issue on a SIMD is arbitrated by priority, then age (MI355X_MICROARCH.md): the waves of a heavy block take
+    // precedence over whatever shares their SIMDs -- lighter blocks of this kernel, the next pass's sort kernels.
+    if (a.prio_records && R >= (uint32_t)a.prio_records) __builtin_amdgcn_s_setprio(3);
+    else if (a.prio_records && R >= (uint32_t)a.prio_records / 4u) __builtin_amdgcn_s_setprio(1);
 
     // record q of the block's sequence -> its source arrays (global memory: the pointers kept in LDS are cast back to that address
     // space, a generic pointer would make every load a FLAT one that also counts as an LDS operation) and its place in them
@@ -1005,7 +1027,7 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
     typedef const uint2* ghv_t;
 #endif
     auto locate = [&](uint32_t q, gkey_t& kp, ghv_t& hp) -> uint32_t {
-        if (n_src <= 1) { kp = (gkey_t)a.key; hp = (ghv_t)a.hv; return first0 + q; }
+        if constexpr (!MULTI) { kp = (gkey_t)a.key; hp = (ghv_t)a.hv; return first0 + q; }
         int s = 0;
         while (s + 1 < n_src && q >= seg_off[s + 1]) ++s;
         kp = (gkey_t)(uintptr_t)seg_key[s]; hp = (ghv_t)(uintptr_t)seg_hv[s];
@@ -1047,29 +1069,59 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
     unsigned long long* wpm_w = wpm + w * 320;
     uint32_t* wcur_w = wcur + w * 320;
     uint2 hv[K]; uint32_t key[K], src[K];
+    uint2 nhv[K]; uint32_t nkey[K], nsrc[K];                           // the NEXT batch's records, in flight behind this batch's chains (see load_batch)
+#pragma unroll
+    for (int k = 0; k < K; ++k) { nhv[k] = make_uint2(0u, 0u); nkey[k] = 0u; nsrc[k] = 0u; }
     // The wave's share of a batch of nb records: `steps` wave instructions of 64 consecutive records.  load_batch only ISSUES the
     // loads (clamped addresses, nothing looks at the values): the next batch's records are in flight behind the chains of this one.
     auto in_batch = [&](int k, uint32_t steps, uint32_t nb) -> bool {
         return (uint32_t)k < steps && ((uint32_t)w * steps + (uint32_t)k) * 64u + (uint32_t)lane < nb;
     };
+    // (Into registers of their OWN, copied at the top of the next round: when the loads went straight into the registers the ranking
+    //  reads, those were dead in between, the compiler used them as temporaries of the address arithmetic, and -- a register with a
+    //  load possibly still pending from the round before -- put an `s_waitcnt vmcnt` in front of every pair: eight serialised memory
+    //  round trips per batch, 40-47 k of the heaviest C4 block's 175 k cycles.  All addresses first, then all loads back to back.)
     auto load_batch = [&](uint32_t P, uint32_t nb) {
         const uint32_t steps = (nb + (uint32_t)NT - 1u) / (uint32_t)NT;
+        if constexpr (!MULTI) {
+            // one source: a uniform base and a 32-bit byte offset per lane (the loads' scalar-base form: no 64-bit address arithmetic in VGPRs)
+#if defined(__HIP_DEVICE_COMPILE__)
+            typedef const __attribute__((address_space(1))) char* gbytes_t;
+#else
+            typedef const char* gbytes_t;
+#endif
+            const gbytes_t kb = (gbytes_t)a.key, hb = (gbytes_t)a.hv, sb = (gbytes_t)a.src;
+            const uint32_t at0 = first0 + P, last = nb - 1u, j0 = (uint32_t)w * steps * 64u + (uint32_t)lane;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if ((uint32_t)k < steps) {                             // block-uniform
+                    const uint32_t at = at0 + min(j0 + (uint32_t)k * 64u, last);
+                    nkey[k] = *(gkey_t)(kb + (uint32_t)(at * 4u));
+                    nhv[k] = *(ghv_t)(hb + (uint32_t)(at * 8u));
+                    if (ATTR) nsrc[k] = *(gkey_t)(sb + (uint32_t)(at * 4u));
+                }
+            }
+            return;
+        }
+        uint32_t at[K]; gkey_t kps[K]; ghv_t hps[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
+            at[k] = 0u; kps[k] = (gkey_t)a.key; hps[k] = (ghv_t)a.hv;
             if ((uint32_t)k < steps) {                                 // block-uniform
                 const uint32_t j = ((uint32_t)w * steps + (uint32_t)k) * 64u + (uint32_t)lane;
-                gkey_t kp; ghv_t hp;
-                const uint32_t at = locate(P + min(j, nb - 1u), kp, hp);
-                key[k] = kp[at]; hv[k] = hp[at];
-                if (ATTR) src[k] = ((gkey_t)a.src)[at];
+                at[k] = locate(P + min(j, nb - 1u), kps[k], hps[k]);
             }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if ((uint32_t)k < steps) { nkey[k] = kps[k][at[k]]; nhv[k] = hps[k][at[k]]; }
         }
     };
 
     // profiling aid (gem_debug_fuse_stamps): cycle stamps of thread 0 -- start, set-up done, then the sums over the batches of
     // {ranking + waiting for the slowest wave's chains, bases, placement, own chains}, end; records, batches, sum of wave 0's longest chains
     unsigned long long* dbg = a.dbg ? a.dbg + (size_t)blockIdx.x * 16 : nullptr;
-    unsigned long long t_prev = 0, acc_rank = 0, acc_base = 0, acc_place = 0, acc_walk = 0, acc_nmax = 0, n_batches = 0;
+    unsigned long long t_prev = 0, acc_rank = 0, acc_base = 0, acc_place = 0, acc_walk = 0, acc_nmax = 0, n_batches = 0, acc_rare = 0, acc_pre = 0;
     if (dbg && tid == 0) { t_prev = __builtin_readcyclecounter(); dbg[1] = t_prev; dbg[7] = R; }
     auto lap = [&](unsigned long long& acc) {
         if (dbg && tid == 0) { const unsigned long long t = __builtin_readcyclecounter(); acc += t - t_prev; t_prev = t; }
@@ -1079,6 +1131,17 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
     if (R) load_batch(0u, min(R, (uint32_t)B));
     for (uint32_t P = 0; P < R; P += (uint32_t)B) {                    // block-uniform
         const uint32_t nb = min(R - P, (uint32_t)B), steps = (nb + (uint32_t)NT - 1u) / (uint32_t)NT;
+        // (every prefetch register is USED here, also those of steps this round does not have: a register whose load of the round before
+        //  "may still be pending" as far as the compiler can tell costs an s_waitcnt vmcnt(0) wherever it is written next -- in the
+        //  middle of the next prefetch, see load_batch)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(nkey[k]), "+v"(nhv[k].x), "+v"(nhv[k].y));
+            if (ATTR) asm volatile("" : "+v"(nsrc[k]));
+#endif
+            key[k] = nkey[k]; hv[k] = nhv[k]; if (ATTR) src[k] = nsrc[k];
+        }
         // ---- 1. stable rank of every record among the records of its cell in the wave's share.  Phase by phase: a wave's LDS
         //         operations execute in order, so the K steps' round trips overlap.
         uint32_t rk[K]; uint64_t peers[K];
@@ -1143,8 +1206,13 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
                 st_hv[at] = hv[k];
                 if constexpr (KEYED) st_sw[at] = (uint16_t)(key[k] >> a.id_bits);
                 if constexpr (ATTR != 0) st_src[at] = src[k];
+                if constexpr (PLAIN_OK) {
+                    const float hh = __uint_as_float(hv[k].x), vv = __uint_as_float(hv[k].y);
+                    odd = odd || !(fabsf(hh) <= kPlainHi) || !(vv >= kPlainLo) || !(vv <= kPlainHi);
+                }
             }
         }
+        if constexpr (PLAIN_OK) { if (odd) blk_odd = 1u; }            // (sticky: once a block has seen such a value it stays on the guarded loop)
         __syncthreads();
         lap(acc_place);
         // the next batch's records: in flight behind the chains
@@ -1159,6 +1227,80 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         uint32_t nx_sw = 0, nx_src = 0;
         if constexpr (KEYED) nx_sw = st_sw[min(cf, lastp)];
         if constexpr (ATTR != 0) nx_src = st_src[min(cf, lastp)];
+        lap(acc_pre);
+        bool plain = false;
+        if constexpr (PLAIN_OK) plain = a.plain_env != 0 && blk_odd == 0u;   // block-uniform
+        if (plain) {
+            // ---- the PLAIN loop: straight-line, one rarely-taken branch per step
+            if constexpr (PLAIN_OK) {
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                const float fl_ = a.var_floor, thr = a.mahal, band = 1e-5f * fabsf(a.mahal);
+                float un1 = 0.0f, un2 = 0.0f, un3 = 0.0f;              // increments of sweeps cur + 1 .. cur + 3, fetched a step ahead
+                if constexpr (HAS_VU) { un1 = vu[rp.cur + 1u]; un2 = vu[rp.cur + 2u]; un3 = vu[rp.cur + 3u]; }
+                // (the reads run past a lane's last record -- into the next cell's, or the tables behind the stage: LDS reads do not
+                //  fault and a lane that is not `live` discards what it computes -- so the addresses are plain increments)
+                const uint2* ph = st_hv + cf + 1u;
+                const uint16_t* ps = st_sw + cf + 1u;
+                for (uint32_t i = 0; i < nmax; ++i) {                  // wave-uniform
+                    const uint2 r = nx; const uint32_t swr = nx_sw;
+                    nx = *ph++;
+                    if constexpr (KEYED) nx_sw = *ps++;
+                    const bool live = i < cn;
+                    const float h = __uint_as_float(r.x), v = __uint_as_float(r.y);
+                    bool rare = false;
+                    uint32_t sw = 0;
+                    if constexpr (HAS_VU) {
+                        // Between two records of sweeps s < t the cell lives through (t - s) x {floor (GPU:533-534); next sweep's increment
+                        // (GPU:540-547)}.  The floor is positive, so a floored variance is never the -10 of an empty cell and the increment
+                        // always applies; the increments are not negative (plain_env), so after the first floor the later ones change
+                        // nothing: a gap of g sweeps is one floor and g rounded additions.  Gaps of up to three sweeps -- 99.98 % of them
+                        // on a LiDAR batch, and with 64 lanes per step the rest still matters -- are predicated straight-line code on
+                        // increments fetched a step ahead; wider ones take the rare branch.  (The guarded loop's way -- a ballot and a
+                        // branch per sweep of the widest gap in the wave -- was a third of its step.)
+                        sw = live ? swr : rp.cur;
+                        const uint32_t gap = sw - rp.cur;
+                        const float c1 = (cs < fl_ ? fl_ : cs) + un1;
+                        cs = gap >= 1u ? c1 : cs;
+                        const float c2 = cs + un2;
+                        cs = gap >= 2u ? c2 : cs;
+                        const float c3 = cs + un3;
+                        cs = gap >= 3u ? c3 : cs;
+                        rp.cur += min(gap, 3u);
+                        rare = gap > 3u;
+                        un1 = vu[rp.cur + 1u]; un2 = vu[rp.cur + 2u]; un3 = vu[rp.cur + 3u];
+                    }
+                    const float sf = cs < fl_ ? fl_ : cs;                              // GPU:500-501
+                    const float m = fabsf(h - ce) * __builtin_amdgcn_rsqf(sf);         // GPU:502, see fuse_step
+                    const float D = sf + v;                                            // GPU:518, 519
+                    v2f N; N.x = sf * h + v * ce; N.y = v * sf;
+                    rare = (rare | (fabsf(m - thr) <= band) | !(fabsf(N.x) >= 8.673617379884035e-19f)) & live;   // 2^-60
+                    // both quotients from one refined reciprocal (fuse_step<true>), as a pair
+                    const float r0 = __builtin_amdgcn_rcpf(D);
+                    const float rr = __builtin_fmaf(__builtin_fmaf(-D, r0, 1.0f), r0, r0);
+                    const v2f rr2 = {rr, rr}, nD2 = {-D, -D};
+                    v2f q = N * rr2;
+                    v2f t = __builtin_elementwise_fma(nD2, q, N);
+                    q = __builtin_elementwise_fma(t, rr2, q);
+                    t = __builtin_elementwise_fma(nD2, q, N);
+                    q = __builtin_elementwise_fma(t, rr2, q);
+                    const bool outlier = m > thr;
+                    const bool replace = (ce == kEmptyElevation) | (outlier & (ce < h));   // GPU:484-486, 505-507
+                    float e2 = replace ? h : (outlier ? ce : q.x);
+                    float s2 = replace ? v : (outlier ? sf : q.y);
+                    if (__builtin_expect(__ballot(rare) != 0, 0)) {                    // wave-uniform: the step as the guarded loop takes it
+                        if (dbg && tid == 0) ++acc_rare;
+                        if constexpr (HAS_VU) {
+                            while (__ballot(rp.cur < sw) != 0) { if (rp.cur < sw) rp.one(cs, vu[rp.cur + 1u], fl_); }
+                            un1 = vu[rp.cur + 1u]; un2 = vu[rp.cur + 2u]; un3 = vu[rp.cur + 3u];
+                        }
+                        e2 = ce; s2 = cs;
+                        fuse_step<true>(e2, s2, h, v, thr, fl_);
+                    }
+                    ce = live ? e2 : ce; cs = live ? s2 : cs;
+                }
+            }
+        } else {
+        if constexpr (HAS_VU) rp.refill(vu);                           // (the plain loop of an earlier batch keeps only rp.cur)
         for (uint32_t i = 0; i < nmax; ++i) {                          // wave-uniform
             const uint2 r = nx; const uint32_t sw = nx_sw, sr = nx_src;
             const uint32_t pn = min(cf + i + 1u, lastp);
@@ -1176,13 +1318,14 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
             if constexpr (LOWEST) { const float l2 = lowest_step(lw, h, v); lw = live ? l2 : lw; }
             if constexpr (ATTR != 0) { if (fl && taken && (sr & 0x80000000u)) wlast = sr & 0x7fffffffu; }
         }
+        }
         lap(acc_walk);
         acc_nmax += nmax; ++n_batches;
         // (the next round's ranking touches the cursors and masks only; its stores into the stage come after two barriers)
     }
     if (dbg && tid == 0) {
         dbg[2] = acc_rank; dbg[3] = acc_base; dbg[4] = acc_place; dbg[5] = acc_walk; dbg[6] = __builtin_readcyclecounter();
-        dbg[8] = n_batches; dbg[9] = acc_nmax;
+        dbg[8] = n_batches; dbg[9] = acc_nmax; dbg[10] = acc_rare; dbg[11] = acc_pre;
     }
     if (__ballot(n_total != 0) == 0 && !a.dense) return;               // nothing reached this wave's cells and nothing is pending
     if constexpr (HAS_VU) rp.finish(cs, last_sw, vu, a.var_floor);
@@ -1412,15 +1555,22 @@ static hipError_t launch_walk_f(hipStream_t st, const WalkArgs& a, int mode, Lau
     return hipGetLastError();
 }
 
+template <int FLAGS, int MODE, int B, bool MULTI>
+static hipError_t launch_block_walk_fmbm(hipStream_t st, const WalkArgs& a, LaunchEvents ev)
+{
+    constexpr bool KEYED = (MODE & 3) != 0, ATTR = (FLAGS & 3) != 0;
+    const size_t lds = block_walk_lds<B, KEYED, ATTR>() + (size_t)std::max(0, a.lds_pad);      // (lds_pad: an experiment's way to cap the workgroups per CU)
+    const hipError_t e = lds_opt_in((const void*)k_fuse_block<FLAGS, MODE, B, MULTI>, lds);
+    if (e != hipSuccess) return e;
+    GEM_LAUNCH((k_fuse_block<FLAGS, MODE, B, MULTI>), dim3(a.T * 4), dim3(kBlkNT), lds, st, ev, a);
+    return hipGetLastError();
+}
+
 template <int FLAGS, int MODE, int B>
 static hipError_t launch_block_walk_fmb(hipStream_t st, const WalkArgs& a, LaunchEvents ev)
 {
-    constexpr bool KEYED = (MODE & 3) != 0, ATTR = (FLAGS & 3) != 0;
-    const size_t lds = block_walk_lds<B, KEYED, ATTR>();
-    const hipError_t e = lds_opt_in((const void*)k_fuse_block<FLAGS, MODE, B>, lds);
-    if (e != hipSuccess) return e;
-    GEM_LAUNCH((k_fuse_block<FLAGS, MODE, B>), dim3(a.T * 4), dim3(kBlkNT), lds, st, ev, a);
-    return hipGetLastError();
+    if constexpr (FLAGS == 0) { if (a.n_src > 1) return launch_block_walk_fmbm<FLAGS, MODE, B, true>(st, a, ev); }
+    return launch_block_walk_fmbm<FLAGS, MODE, B, false>(st, a, ev);
 }
 
 constexpr int kBlkBatch = 2048;   // records of a block staged in LDS per round: three workgroups per CU (4096: two per CU, half the rounds

@@ -48,6 +48,7 @@ print("records/block: mean %.0f max %d; batches: mean %.2f max %d; sum of longes
       (s[:, 7].mean(), s[:, 7].max(), s[:, 8].mean(), s[:, 8].max(), s[:, 9].mean(), s[:, 9].max()))
 order = np.argsort(-tot)
 for i in order[:8]:
+    print(f"  ticks per chain step {vals[i][4] / max(s[i, 9], 1):.0f} rare steps {s[i, 10]} before-the-loops {s[i, 11]}", end=" ")
     print(f"slow block: total {tot[i]:7d} start@{s[i, 0] - t0:7d} end@{s[i, 6] - t0:7d} R {s[i, 7]:6d} batches {s[i, 8]:3d} chains {s[i, 9]:4d} | " +
           " ".join(f"{k} {v}" for k, v in zip(names, vals[i])))
 late = np.argsort(-s[:, 6])[:5]
