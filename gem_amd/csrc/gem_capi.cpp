@@ -81,6 +81,7 @@ struct gem_handle {
         uint32_t epoch = 0;            // touched-flag stamp of the last pass (0 = the flag table holds no live stamps)
     } pb[4];            // the tile pipeline alternates between the first two; the sorted pipeline's overlapped passes rotate through all four
     unsigned pass = 0, sort_pass = 0;
+    uint32_t sort_epoch = 0;            // a number per sorted pass (SortArgs::epoch)
     int sort_streams = 2;               // binning streams the overlapped passes of the sorted pipeline alternate between (debug knob)
     bool trace = false;                 // debug knob: one line on stderr per pass of the sorted pipeline (which streams / buffers it took)
     int sort_ring = 3;                  // buffer sets they rotate through (debug knob, 2..4).  The sort of pass p may start once the walk of pass p - ring has
@@ -401,6 +402,7 @@ struct PassInput {
     const int* f_R = nullptr; const int* f_G = nullptr; const int* f_B = nullptr; const float* f_I = nullptr;
 };
 
+constexpr unsigned  kDeviceEventFlags = hipEventDisableTiming | hipEventDisableSystemFence;
 constexpr int       kUnit = 64;                      // points per unit (one wave of k_bin_wave)
 constexpr long long kSweepPoints = 2048ll * kUnit;   // a single cloud longer than this is processed as a batch of sweeps of this size
 
@@ -691,6 +693,10 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
         sa.segtot[i] = reinterpret_cast<uint32_t*>(misc + o_seg[i]);
     }
     sa.total = reinterpret_cast<uint32_t*>(misc + o_total); sa.bin_base = reinterpret_cast<uint32_t*>(misc + o_base);
+    // (word 1 behind the record count: k_sort_project stores the pass's epoch there when a record is outside the plain range of
+    //  the walks' chain loops; epochs never repeat, so the word needs no clearing)
+    sa.odd_flag = sa.total + 1; sa.epoch = ++h->sort_epoch; if (sa.epoch == 0u) sa.epoch = ++h->sort_epoch;
+    wa.odd_flag = sa.odd_flag; wa.epoch = sa.epoch;
     sa.blk_cnt = nullptr;
     if ((geo.block_form && geo.n_passes > 1) || shard) {             // the walk will want every block's range (the last pass's bins are not the blocks)
         if ((rc = ensure_zeroed(h, pb.s_blkcnt, (size_t)4 * T * sizeof(uint32_t))) || (rc = ensure(h, pb.s_ranges, (size_t)4 * T * sizeof(uint2)))) return rc;
@@ -1098,9 +1104,11 @@ int gem_create(const gem_map_config* cfg, gem_handle** out)
     if ((e = hipEventCreateWithFlags(&h->switch_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     // (the handle's four streams come from the process-wide pool as a set, see acquire_streams: ROCm maps streams onto a few
     //  hardware queues, and streams that share one serialise)
+    // (the events between the handle's own streams order device work on device memory only: no system-scope fence -- the cache
+    //  write-back and invalidation it stands for sat between consecutive walks, debug knob "event_fence")
     for (auto& b : h->pb) {
-        if ((e = hipEventCreateWithFlags(&b.bin_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-        if ((e = hipEventCreateWithFlags(&b.fuse_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreateWithFlags(&b.bin_done, kDeviceEventFlags)) != hipSuccess) return bail("hipEventCreate", e);
+        if ((e = hipEventCreateWithFlags(&b.fuse_done, kDeviceEventFlags)) != hipSuccess) return bail("hipEventCreate", e);
     }
     // one allocation for the 8 layers (gpu_process.cu:954-961 uses 8 cudaMalloc)
     void* base = nullptr;
@@ -1924,6 +1932,16 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "lane_sort")          h->lane_sort = value != 0;
     else if (k == "plain_loop")         h->plain_loop = value != 0;
     else if (k == "cache_tables")       h->cache_tables = value != 0;
+    else if (k == "event_fence") {                                     // 1: the per-buffer-set events with the default system-scope fence (A/B)
+        for (hipStream_t st : {h->own_stream, h->bin_stream, h->bin_stream2, h->tab_stream}) if (st) hipStreamSynchronize(st);
+        for (auto& b : h->pb) {
+            for (hipEvent_t* ev : {&b.bin_done, &b.fuse_done}) {
+                if (*ev) hipEventDestroy(*ev);
+                GEM_HIP(h, hipEventCreateWithFlags(ev, value ? (unsigned)hipEventDisableTiming : kDeviceEventFlags));
+            }
+            b.fuse_recorded = false;
+        }
+    }
     else if (k == "walk_lds_pad")       { if (value < 0 || value > 100 * 1024) return fail(h, GEM_ERR_INVALID, "walk_lds_pad: 0 .. 102400 bytes"); h->walk_lds_pad = (int)value; }
     else if (k == "walk_prio")          { if (value < 0 || value > (1 << 30)) return fail(h, GEM_ERR_INVALID, "walk_prio: 0 (off) or a record count"); h->walk_prio = (int)value; }
     else if (k == "blk_batch")          { if (value != 0 && value != 512 && value != 2048) return fail(h, GEM_ERR_INVALID, "blk_batch: 0 (by pass), 512 or 2048"); h->blk_batch = (int)value; }

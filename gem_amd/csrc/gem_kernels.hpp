@@ -132,6 +132,7 @@ struct SortArgs {
     uint2 *hv_a, *hv_b;                // {h, var}: a = input order, then after the even passes; b = after the odd passes (the passes ping-pong)
     uint32_t *key_a, *key_b, *src_a, *src_b;      // keys; source point | colour flag << 31 (src only when colours are fused)
     unsigned long long* counters;      // optional: [0] += records
+    uint32_t* odd_flag; uint32_t epoch; // k_sort_project stores `epoch` here when a record's h or v lies outside the plain range of the walks' chain loops
 };
 
 // one counting-sort pass over a digit of the key
@@ -172,6 +173,7 @@ struct WalkArgs {
     int   lane_sort;                   // 1: the block's cells are handed to the threads in descending order of their record count in the first batch
     int light_blocks;                  // k_fuse_block: rounds of 512 records instead of 2048 (blocks of a few hundred records)
     int   exact_bins;                  // 1: the last pass's bins ARE the blocks (one-pass sort): bin_base gives a block's records without a search
+    const uint32_t* odd_flag; uint32_t epoch;   // k_fuse_walk: *odd_flag == epoch: some record of the pass is outside the plain range (k_sort_project)
     int   lds_pad;                     // k_fuse_block: unused dynamic LDS on top of what the kernel needs (debug knob)
     int   prio_records;                // k_fuse_block: blocks of at least this many records raise their waves' issue priority (0 = off)
     int   plain_env;                   // 1: floor, threshold and every variance increment of the pass lie in the range the walks' plain chain loop assumes (walk_plain_env)

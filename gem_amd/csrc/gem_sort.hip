@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256, (SRC == 4 ? 4 : (SRC == 2 ? 3 : 1))) void k_so
     const long long seg0 = cr.first + (long long)(tid >> 6) * (K * 64);
     const uint64_t lt = lanemask_lt();
     uint32_t kept = 0;                                                 // wave-uniform
+    bool odd = false;                                                  // a record outside the plain range of the walks' chain loops (k_fuse_walk)
     const uint32_t sweep_bits = (uint32_t)(cr.sweep + a.sweep_id0) << a.id_bits;   // (a shard of a multi-GPU batch numbers its sweeps globally)
     const uint32_t d0mask = (1u << a.dbits[0]) - 1u, d0shift = (uint32_t)a.dshift[0];
     __syncthreads();
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(256, (SRC == 4 ? 4 : (SRC == 2 ? 3 : 1))) void k_so
             const uint64_t m = __ballot(b.valid);
             const uint32_t bin = (b.id >> d0shift) & d0mask;
             if (b.valid) {
+                if constexpr (SRC != 3) odd = odd | !(fabsf(b.h) <= 268435456.0f) | !(b.v >= 3.7252902984619140625e-9f) | !(b.v <= 268435456.0f);
                 const long long at = seg0 + kept + (uint32_t)__popcll(m & lt);
                 a.key_a[at] = b.id | sweep_bits;
                 a.hv_a[at] = make_uint2(__float_as_uint(b.h), __float_as_uint(b.v));
@@ -212,6 +214,7 @@ __global__ __launch_bounds__(256, (SRC == 4 ? 4 : (SRC == 2 ? 3 : 1))) void k_so
         }
     }
     if ((tid & 63) == 0) a.seg_cnt[(size_t)chunk * kSortSegsPerChunk + (tid >> 6)] = kept;
+    if (odd && a.odd_flag) *a.odd_flag = a.epoch;                      // (every writer stores the same value)
     __syncthreads();
     for (int i = tid; i < a.dbins[0]; i += NT) a.cnt[0][(size_t)chunk * a.dbins[0] + i] = hist[i];
     if (a.blk_cnt && btag[tid] != 0xffffffffu) __hip_atomic_fetch_add(a.blk_cnt + btag[tid], bcnt[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -679,6 +682,21 @@ __global__ __launch_bounds__(kWalkNT) void k_fuse_walk(WalkArgs a)
         cstart[tid] = 0u; cend[tid] = 0u;
         __syncthreads();
         if (rb == re) return false;
+        if (re - rb > 4096u) {
+            // a long run (the cells under a depth camera hold hundreds of points each: 75 k records in one workgroup's run): every
+            // thread bisects for the start of ITS cell -- 17 dependent loads, all 256 cells at once -- instead of the four waves
+            // scanning the run's keys round by round (10 us of the depth image's 74 us walk)
+            uint32_t lo = rb, hi = re;                                     // first record whose cell is >= tid
+            while (lo < hi) {
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if ((keys[mid] & (uint32_t)(NT - 1)) < (uint32_t)tid) lo = mid + 1u; else hi = mid;
+            }
+            cstart[tid] = lo;
+            __syncthreads();
+            cend[tid] = tid + 1 < NT ? cstart[tid + 1] : re;
+            __syncthreads();
+            return true;
+        }
         // cell boundaries of the workgroup's run: the records are sorted by cell, so a cell starts -- and the one before it
         // ends -- where the key's cell changes.  The waves take the rounds in turn; rounds of sixteen loads for long runs: the run
         // of the cells under the sensor is thousands of records long, and one load per round made this loop a chain of memory
@@ -825,11 +843,73 @@ __global__ __launch_bounds__(kWalkNT) void k_fuse_walk(WalkArgs a)
         }
     };
 
+    // ---- the same run through the PLAIN chain loop (k_fuse_block has the reasoning): every record of the pass has |h| <= 2^28 and
+    //      2^-28 <= v <= 2^28 (k_sort_project says so), every cell of the wave starts in range, the pass's constants are in range --
+    //      then a step looks at |N1| >= 2^-60 and at the threshold band only, both quotients share one refined reciprocal, and the
+    //      records come through a pipeline of three groups of four whose waits the compiler can count: the guarded loop's rotating
+    //      groups sit behind conditional loads, and it waits for EVERY load in flight at the head of each group (`s_waitcnt vmcnt(0)`:
+    //      a memory round trip per four steps, half of a depth image's 248 ns per step).  Long runs only: the pipeline always runs
+    //      whole rounds of twelve steps.
+    auto walk_run_plain = [&](const uint2* __restrict__ hvs) {
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        struct __attribute__((packed, aligned(4))) Quad { uint32_t x, y, z, w; };
+        const uint32_t first = cstart[c], n = cend[c] - first;
+        n_total += n;
+        const uint32_t nmax = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_max(n), 63);
+        const uint32_t glast = n ? (n - 1u) >> 2 : 0u;
+        const uint2* hp = hvs + (n ? first : rb);
+        const float fl_ = a.var_floor, thr = a.mahal, band = 1e-5f * fabsf(a.mahal);
+        auto load2 = [&](uint32_t gi, Quad& q01, Quad& q23) {
+            const uint32_t r = 4u * min(gi, glast);
+            q01 = *reinterpret_cast<const Quad*>(hp + r);
+            q23 = *reinterpret_cast<const Quad*>(hp + r + 2u);
+        };
+        auto step = [&](uint32_t idx, uint32_t hb, uint32_t vb) {
+            const bool live = idx < n;
+            const float h = __uint_as_float(hb), v = __uint_as_float(vb);
+            const float sf = cs < fl_ ? fl_ : cs;                              // GPU:500-501
+            const float m = fabsf(h - ce) * __builtin_amdgcn_rsqf(sf);         // GPU:502, see fuse_step
+            const float D = sf + v;                                            // GPU:518, 519
+            v2f N; N.x = sf * h + v * ce; N.y = v * sf;
+            const bool rare = ((fabsf(m - thr) <= band) | !(fabsf(N.x) >= 8.673617379884035e-19f)) & live;   // 2^-60
+            const float r0 = __builtin_amdgcn_rcpf(D);
+            const float rr = __builtin_fmaf(__builtin_fmaf(-D, r0, 1.0f), r0, r0);
+            const v2f rr2 = {rr, rr}, nD2 = {-D, -D};
+            v2f q = N * rr2;
+            v2f t = __builtin_elementwise_fma(nD2, q, N);
+            q = __builtin_elementwise_fma(t, rr2, q);
+            t = __builtin_elementwise_fma(nD2, q, N);
+            q = __builtin_elementwise_fma(t, rr2, q);
+            const bool outlier = m > thr;
+            const bool replace = (ce == kEmptyElevation) | (outlier & (ce < h));   // GPU:484-486, 505-507
+            float e2 = replace ? h : (outlier ? ce : q.x);
+            float s2 = replace ? v : (outlier ? sf : q.y);
+            if (__builtin_expect(__ballot(rare) != 0, 0)) { e2 = ce; s2 = cs; fuse_step<true>(e2, s2, h, v, thr, fl_); }
+            ce = live ? e2 : ce; cs = live ? s2 : cs;
+        };
+        auto run4 = [&](uint32_t i0, const Quad& q01, const Quad& q23) {
+            step(i0, q01.x, q01.y); step(i0 + 1u, q01.z, q01.w); step(i0 + 2u, q23.x, q23.y); step(i0 + 3u, q23.z, q23.w);
+        };
+        Quad a01, a23, b01, b23, c01, c23;
+        load2(0u, a01, a23); load2(1u, b01, b23); load2(2u, c01, c23);
+        for (uint32_t gi = 0; 4u * gi < nmax; gi += 3u) {              // wave-uniform; every load unconditional (clamped), every wait countable
+            run4(4u * gi, a01, a23);        load2(gi + 3u, a01, a23);
+            run4(4u * gi + 4u, b01, b23);   load2(gi + 4u, b01, b23);
+            run4(4u * gi + 8u, c01, c23);   load2(gi + 5u, c01, c23);
+        }
+    };
+
     __syncthreads();                                                   // vu is in LDS
     // Mapvar_update increments queued before this pass, then the one of sweep 0 (GPU:540-547)
     for (int k = 0; k < a.n_pending; ++k) if (cs != kInitVariance) cs += a.pending[k];
     if constexpr (HAS_VU) { if (cs != kInitVariance) cs += vu[0]; rp.refill(vu); }
-    if (have) walk_run(a.key, a.hv, a.src);
+    bool plain = false;
+    if constexpr (FLAGS == 0 && MODE == 0) {
+        const bool state_ok = (fabsf(ce) <= 268435456.0f) & (cs <= 268435456.0f);
+        const uint32_t longest = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_max(have ? cend[c] - cstart[c] : 0u), 63);
+        plain = a.plain_env != 0 && a.odd_flag != nullptr && *a.odd_flag != a.epoch && __ballot(!state_ok) == 0 && longest >= 24u;   // wave-uniform
+    }
+    if (have) { if (plain) walk_run_plain(a.hv); else walk_run(a.key, a.hv, a.src); }
     if (__ballot(n_total != 0) == 0 && !a.dense) return;               // nothing reached this wave's cells and nothing is pending
     if constexpr (HAS_VU) rp.finish(cs, last_sw, vu, a.var_floor);
     if (cs < a.var_floor) cs = a.var_floor;                            // GPU:533-534, on every cell
@@ -953,15 +1033,17 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
     const int row_t = (tr << 5) + (q4 << 3) + (tid >> 5), col_t = (tc << 5) + (tid & 31);
     const bool owned_t = row_t >= a.row0 && row_t < a.row1 && col_t < L;
     const size_t g_t = owned_t ? (size_t)row_t * L + col_t : 0;
+    // (only REQUESTED here: the block's range, its first batch of records and these are three memory round trips -- for the light
+    //  blocks of a big map, a few hundred records each, most of the block's time -- so they are all put in flight before anything
+    //  waits: the values go to LDS behind the first batch's loads, below)
     const float e_in = a.elevation[g_t], s_in = a.variance[g_t];
-    sh_e[tid] = e_in; sh_s[tid] = s_in;
+    float l_in = 0.0f;
     if constexpr (LOWEST) {                                            // map_lowest is indexed by the GEOGRAPHIC cell (GPU:430)
         int gr = row_t - a.start0, gc = col_t - a.start1;
         gr += gr < 0 ? L : 0; gc += gc < 0 ? L : 0;
-        sh_l[tid] = a.lowest[owned_t ? (size_t)gr * L + gc : 0];
+        l_in = a.lowest[owned_t ? (size_t)gr * L + gc : 0];
     }
     bool odd = false;                                                  // this thread has seen a value outside the plain range
-    if constexpr (PLAIN_OK) odd = !(fabsf(e_in) <= kPlainHi) || !(s_in <= kPlainHi);
     if (tid < 128) phist[tid] = 0u;
     perm[tid] = (uint16_t)tid;
     if constexpr (HAS_VU) for (int i = tid; i < kWalkMaxSweeps + 8; i += NT) vu[i] = i < a.n_sweeps ? a.var_updates[i] : 0.0f;
@@ -984,14 +1066,14 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         first = (uint32_t)__shfl((int)lo, 0, 64);
         end = (uint32_t)__shfl((int)lo, 32, 64);
     };
-    uint32_t first0 = 0;                                               // single source: the block's first record (block-uniform)
+    uint32_t first0 = 0, r_single = 0;                                 // single source: the block's first record, its records (block-uniform)
     if constexpr (!MULTI) {
         uint32_t end;
         if (a.ranges) { const uint2 r = a.ranges[id0 >> 8]; first0 = r.x; end = r.y; }
         else { const uint32_t bin = id0 >> a.bin_shift; first0 = a.bin_base[bin]; end = a.bin_base[bin + 1]; }
         if (first0 == end && !a.dense) return;
         if (!a.ranges && !a.exact_bins && first0 != end) search(a.key, first0, end, first0, end);
-        if (tid == 0) { seg_off[0] = 0u; seg_off[1] = end - first0; }
+        r_single = end - first0;
     } else {
         for (int s = w; s < n_src; s += NW) {                          // wave-uniform
             uint32_t first = 0, end = 0;
@@ -1007,9 +1089,12 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         __syncthreads();
         if (tid == 0) { uint32_t o = 0; for (int s = 0; s < n_src; ++s) { seg_off[s] = o; o += cbase[s]; } seg_off[n_src] = o; }
     }
-    for (int i = tid; i < NW * 320; i += NT) { wcur[i] = 0u; if constexpr (!BALLOT) wpm[i] = 0ull; }
-    __syncthreads();
-    const uint32_t R = seg_off[n_src];                                 // records of this block, all sources
+    auto zero_tables = [&]() {
+        for (int i = tid; i < NW * 320; i += NT) { wcur[i] = 0u; if constexpr (!BALLOT) wpm[i] = 0ull; }
+        __syncthreads();
+    };
+    if constexpr (MULTI) zero_tables();                                // (and seg_off is complete)
+    const uint32_t R = MULTI ? seg_off[n_src] : r_single;              // records of this block, all sources
     if (R == 0 && !a.dense) return;                                    // block-uniform
     // The kernel ends with its heaviest block, and that block's time is its chains: a wave issuing one instruction after the
     // other.  VALU issue on a SIMD is arbitrated by priority, then age (MI355X_MICROARCH.md): the waves of a heavy block take
@@ -1062,7 +1147,6 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         for (int k = 0; k < a.n_pending; ++k) if (cs != kInitVariance) cs += a.pending[k];
         if constexpr (HAS_VU) { if (cs != kInitVariance) cs += vu[0]; rp.refill(vu); }
     };
-    if (R == 0) take_cell();                                           // (a dense pass over a block without records: every thread keeps cell tid)
 
     const uint64_t lt = lanemask_lt();
     const unsigned long long mybit = 1ull << lane;
@@ -1129,6 +1213,11 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
 
     uint32_t parity = 0;
     if (R) load_batch(0u, min(R, (uint32_t)B));
+    if constexpr (!MULTI) zero_tables();
+    sh_e[tid] = e_in; sh_s[tid] = s_in;                                // (the first wait for memory: the map values, with the first batch in flight behind them)
+    if constexpr (LOWEST) sh_l[tid] = l_in;
+    if constexpr (PLAIN_OK) odd = !(fabsf(e_in) <= kPlainHi) || !(s_in <= kPlainHi);
+    if (R == 0) take_cell();                                           // (a dense pass over a block without records: every thread keeps cell tid)
     for (uint32_t P = 0; P < R; P += (uint32_t)B) {                    // block-uniform
         const uint32_t nb = min(R - P, (uint32_t)B), steps = (nb + (uint32_t)NT - 1u) / (uint32_t)NT;
         // (every prefetch register is USED here, also those of steps this round does not have: a register whose load of the round before
