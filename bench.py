@@ -283,11 +283,19 @@ def batched_c4(emap_cls, dev, torch, reps: int = 60):
     else:
         kern = {"k_bin_wave": 1e3 * st["ms_bin"] / max(st["launches_bin"], 1), "k_fuse_list": 1e3 * st["ms_fuse"] / max(st["launches_fuse"], 1)}
         roof = None
+    moved_total = sum(moved[k] for k in kern if k in moved) if st["launches_walk"] else None
+    per_kernel = {k: {"us_alone": kern[k], "bytes": moved[k], "frac_of_hbm_peak": moved[k] / (kern[k] * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                  for k in kern if st["launches_walk"] and k in moved and kern[k] > 0}
     return {"workload": "C4: 32 consecutive 131072-pt sweeps + Mapvar_update before each, one batched call, 600x600 map",
             "value": n / dt, "unit": "points/s", "us_per_batch": dt * 1e6, "records_kept": int(records), "cells_touched": int(cells),
-            "algorithmic_bytes": alg, "achieved_GBps": alg / dt / 1e9, "frac_of_hbm_peak": alg / dt / 1e9 / HBM_PEAK_GBS,
-            "frac_of_6300": alg / dt / 1e9 / HBM_ACHIEVABLE_GBS, "must_move_bytes": must_move, "frac_of_hbm_peak_must_move": must_move / dt / 1e9 / HBM_PEAK_GBS,
-            "us_per_kernel": kern, "roofline": roof, "parity_checked": bool(ok)}
+            # the bytes, from the most to the least demanding reading:
+            "must_move_bytes": must_move, "frac_of_hbm_peak_must_move": must_move / dt / 1e9 / HBM_PEAK_GBS,
+            "bytes_moved_by_construction": moved_total, "frac_moved": (moved_total / dt / 1e9 / HBM_PEAK_GBS) if moved_total else None,
+            "algorithmic_bytes": alg, "achieved_GBps": alg / dt / 1e9, "frac_of_hbm_peak": alg / dt / 1e9 / HBM_PEAK_GBS, "frac_of_6300": alg / dt / 1e9 / HBM_ACHIEVABLE_GBS,
+            "bytes_note": "must_move = the cloud + the two layers once (what ONE call has to move at least); bytes_moved_by_construction = what the four kernels "
+                          "read + write (records of 12 B written once, moved once by the scatter, read once by the walk); algorithmic_bytes = SURVEY 8d's figure, "
+                          "which counts 32 dense variance passes (92 MB) that the implementation folds into the walk and never performs",
+            "per_kernel": per_kernel, "us_per_kernel": kern, "roofline": roof, "parity_checked": bool(ok)}
 
 
 def c5_cloud():
@@ -317,12 +325,31 @@ def c5_one_gpu(emap_cls, dev, torch, reps: int = 12, wl=None, cat=None, off=None
     m.synchronize()
     dt = (time.perf_counter() - t0) / reps
     m.set_counting(True); m.add_batch(pb, d_cat)
-    cells = m.stats()["cells_touched"]
+    cells = m.stats()["cells_touched"]; records = m.stats()["points_binned"]
     m.close()
+    # every kernel alone on the GPU (second map, the passes' overlap switched off)
+    m1 = emap_cls(wl.length, wl.resolution, device=dev.index, debug={"overlap": 0})
+    for _ in range(2):
+        m1.add_batch(pb, d_cat)
+    m1.set_timing(True); m1.stats(reset=True)
+    for _ in range(4):
+        m1.add_batch(pb, d_cat)
+    st = m1.stats(); m1.close()
     del d_cat
     n = int(off[-1])
     alg = 16.0 * n + 16.0 * cells
+    names = ["k_sort_project", "k_sort_scan", "k_sort_scatter", "k_sort_count", "k_sort_scan(2)", "k_sort_scatter(2)"]
+    ls = max(st["launches_sort"], 1)
+    kern = {nm: 1e3 * v / ls for nm, v in zip(names, st["ms_sort"]) if v > 0}
+    kern["k_fuse_block"] = 1e3 * st["ms_walk"] / max(st["launches_walk"], 1)
+    moved = {"k_sort_project": 16.0 * n + 12.0 * records, "k_sort_scatter": 24.0 * records, "k_sort_count": 4.0 * records,
+             "k_sort_scatter(2)": 24.0 * records, "k_fuse_block": 12.0 * records + 16.0 * cells}
+    moved_total = sum(moved[k] for k in kern if k in moved)
+    must_move = 16.0 * n + 16.0 * cells
+    per_kernel = {k: {"us_alone": kern[k], "bytes": moved[k], "frac_of_hbm_peak": moved[k] / (kern[k] * 1e-6) / 1e9 / HBM_PEAK_GBS} for k in kern if k in moved and kern[k] > 0}
     return {"workload": "C5: 10 M-point aggregated cloud (77 sweeps, no variance increments) -> 2400x2400 @ 0.05 m, one gem_add_batch_device call per step, ONE GPU",
+            "records_kept": int(records), "must_move_bytes": must_move, "frac_of_hbm_peak_must_move": must_move / dt / 1e9 / HBM_PEAK_GBS,
+            "bytes_moved_by_construction": moved_total, "frac_moved": moved_total / dt / 1e9 / HBM_PEAK_GBS, "per_kernel": per_kernel,
             "value": n / dt, "unit": "points/s", "us_per_step": dt * 1e6, "cells_touched": int(cells), "algorithmic_bytes": alg,
             "achieved_GBps": alg / dt / 1e9, "frac_of_hbm_peak": alg / dt / 1e9 / HBM_PEAK_GBS, "frac_of_6300": alg / dt / 1e9 / HBM_ACHIEVABLE_GBS,
             "parity_checked": bool(ok), "parity": "first pass into a fresh map == tests/golden/digests.json c5_full"}
@@ -406,7 +433,48 @@ def c2_variants(emap_cls, dev, torch, reps: int = 400):
     out["e2e_with_h2d"] = {"workload": "C2 sweep handed over as a HOST array (gem_add: staging copy + H2D + the same kernels)", "value": n / dt, "unit": "points/s",
                            "us_per_step": dt * 1e6, "parity_checked": bool(ok), "parity": "first sweep into a fresh map == tests/golden/digests.json c2"}
     m.close()
+    out["node_host_arrays"] = node_host_arrays(emap_cls, dev)
     return out
+
+
+def node_host_arrays(emap_cls, dev, reps: int = 40):
+    """The path the UNMODIFIED node drives, with its caller-owned host arrays (never `value`): per frame Mapvar_update, Process_points
+    (3 arrays up, 5 down: gpu_process.cu:1096-1141), Fuse (7 arrays up: :1165-1192), Map_feature (nine L x L layers down: :1283-1291)
+    and Raytracing, through the C ABI entry points the nine-symbol adapter calls (include/gem/gem_compat_eigen.hpp), arrays
+    allocated once like the node's.  PCIe and the runtime's handling of pageable memory set this rate; the arrays are pinned for
+    the duration of each call (gem_capi.cpp, HostPins)."""
+    import ctypes as C
+    from gem_amd import synth, _lib
+    wl = synth.config_c2(reference_filter=True)
+    c = wl.clouds[0]; f = wl.frames[0]; n = c.shape[0]; L = wl.length
+    x, y, z = (np.ascontiguousarray(c[:, k]) for k in range(3))
+    idx = np.empty(n, np.int32); var, xt, yt, zt = (np.empty(n, np.float32) for _ in range(4))
+    col = [np.full(n, 120, np.int32) for _ in range(3)]; inten = np.full(n, 7.0, np.float32)
+    layers_f = [np.empty(L * L, np.float32) for _ in range(6)]; layers_i = [np.empty(L * L, np.int32) for _ in range(3)]
+    m = emap_cls(L, wl.resolution, device=dev.index)
+    m.set_lowest_tracking(True)
+    lib, h, P = m._lib, m._h, f.to_struct()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    t = {"mapvar_update": [], "process_points": [], "fuse": [], "map_feature": [], "raytracing": []}
+    for r in range(reps + 4):
+        t0 = time.perf_counter(); lib.gem_mapvar_update(h, 1e-6)
+        t1 = time.perf_counter(); rc1 = lib.gem_process_points(h, C.byref(P), n, vp(x), vp(y), vp(z), None, 0, vp(idx), vp(var), vp(xt), vp(yt), vp(zt))
+        t2 = time.perf_counter(); rc2 = lib.gem_fuse(h, n, vp(idx), vp(col[0]), vp(col[1]), vp(col[2]), vp(inten), vp(zt), vp(var))
+        t3 = time.perf_counter(); rc3 = lib.gem_map_feature(h, vp(layers_f[0]), vp(layers_f[1]), vp(layers_i[0]), vp(layers_i[1]), vp(layers_i[2]),
+                                                            vp(layers_f[2]), vp(layers_f[3]), vp(layers_f[4]), vp(layers_f[5]))
+        t4 = time.perf_counter(); rc4 = lib.gem_raytracing(h)
+        t5 = time.perf_counter()
+        assert rc1 == 0 and rc2 == 0 and rc3 == 0 and rc4 == 0
+        if r >= 4:
+            for k, v in zip(t, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
+                t[k].append(v * 1e6)
+    m.synchronize(); m.close()
+    us = {k: float(np.median(v)) for k, v in t.items()}
+    total = sum(us.values())
+    return {"workload": "the node's frame with caller-owned HOST arrays: Mapvar_update + Process_points + Fuse (colours) + Map_feature (nine layers to the host) + "
+                        "Raytracing, C2 sweep with the reference's reject filter, 600 x 600 map",
+            "us_per_frame": total, "us_per_call": us, "bytes_over_pcie_per_frame": 12.0 * n + 20.0 * n + 28.0 * n + 36.0 * L * L,
+            "value": n / (total * 1e-6), "unit": "points/s"}
 
 
 # ---- C5 through the sharded entry points: N > 1 (strong scaling), or N = 1 with --workload c5 -----------------------------------
@@ -733,7 +801,7 @@ def main():
         out["c5_one_gpu"] = c5_one_gpu(ElevationMap, dev, torch)
         out["c3"] = c3_stream(ElevationMap, dev, torch)
         out.update(c2_variants(ElevationMap, dev, torch))
-        extras = ("batched_c4", "c5_one_gpu", "c3", "c2_reference_filter_on", "e2e_with_h2d")
+        extras = ("batched_c4", "c5_one_gpu", "c3", "c2_reference_filter_on", "e2e_with_h2d")       # (node_host_arrays carries no digest: the same entry points are parity-tested in tests/)
         out["parity_checked"] = bool(out["parity_checked"] and all(out[k]["parity_checked"] for k in extras))
         out["parity"] += "; C4 batch (twice into a fresh map) vs c4_32 / c4_32_twice; C5 on one GPU vs c5_full; C3 vs c3; C2 with the reference filter vs c2_filter; host-array C2 vs c2"
         failed = failed or not out["parity_checked"]

@@ -115,6 +115,8 @@ struct gem_handle {
     bool lane_sort = true;              // k_fuse_block: cells to threads by record count (debug knob)
     int  walk_lds_pad = 0;              // k_fuse_block: extra dynamic LDS per workgroup (debug knob: fewer workgroups per CU)
     int  walk_prio = 4096;              // k_fuse_block: blocks of at least this many records run at raised issue priority (debug knob, 0 = off)
+    bool pin_host = true;               // caller-owned host arrays of at least pin_host_min_bytes are pinned for the call (HostPins; debug knob)
+    size_t pin_host_min_bytes = 256 * 1024;
     bool cache_tables = true;           // batched calls: skip building / uploading tables equal to the ones the buffer set already holds (debug knob)
     std::vector<unsigned char> key_scratch;
     bool plain_loop = true;             // the walks' plain chain loop for blocks whose values are in range (debug knob: 0 = the guarded loop everywhere)
@@ -190,7 +192,8 @@ struct gem_handle {
     bool step_timed = false;
 
     Arena dbg;          // optional k_fuse phase stamps
-    Arena ray;          // gem_raytracing: the cells that walk + their number
+    Arena ray;          // gem_raytracing: the cells that walk, their number (two counters in turn), the snapshot of the lowest scan points
+    unsigned ray_calls = 0;
     Arena color;        // gem_colorize: its own sort arrays and tables (never shared with a pass in flight on the binning stream)
     bool  dbg_on = false;
     long long sort_fallbacks = 0;      // passes whose forced sorted form / pass count did not fit the map and took the other form (gem_debug_get)
@@ -315,6 +318,26 @@ struct Timed {
     }
     LaunchEvents events() const { LaunchEvents e; if (on) { e.start = ep.a; e.stop = ep.b; } return e; }
     ~Timed() { if (on) h->events.push_back(ep); }
+};
+
+// Caller-owned PAGEABLE host arrays (the reference's interface hands over stack arrays, valid for the call only): a copy from or
+// to pageable memory is staged by the runtime through its own pinned buffers with CPU copies in between -- 0.5 MB arrays move at a
+// few GB/s, and the nine 1.44 MB layers of Map_feature take over a millisecond.  Pinned for the duration of the call instead
+// (hipHostRegister ... hipHostUnregister, never cached: the caller's memory may be a thread's stack that is gone after the call),
+// the same copies are plain DMA.  Small arrays are not worth the two system calls.
+struct HostPins {
+    gem_handle* h;
+    std::vector<void*> pinned;
+    explicit HostPins(gem_handle* hh) : h(hh) {}
+    void pin(const void* p, size_t bytes)
+    {
+        if (!p || !h->pin_host || bytes < h->pin_host_min_bytes) return;
+        // whole pages: two arrays of one call may share a page, which can be registered only once
+        const uintptr_t page = 4096, a = reinterpret_cast<uintptr_t>(p) & ~(page - 1), b = (reinterpret_cast<uintptr_t>(p) + bytes + page - 1) & ~(page - 1);
+        if (hipHostRegister(reinterpret_cast<void*>(a), b - a, hipHostRegisterDefault) == hipSuccess) pinned.push_back(reinterpret_cast<void*>(a));
+        else (void)hipGetLastError();                                   // (already registered by the caller, overlapping an earlier array, ...: the copy is staged as before)
+    }
+    ~HostPins() { for (void* p : pinned) if (hipHostUnregister(p) != hipSuccess) (void)hipGetLastError(); }
 };
 
 void fold_events(gem_handle* h)
@@ -1291,6 +1314,9 @@ int gem_process_points(gem_handle* h, const gem_frame_params* p, int n, float* x
     int* didx = reinterpret_cast<int*>(d + 4 * S);     float* dvar = reinterpret_cast<float*>(d + 5 * S);
     float* dxt = reinterpret_cast<float*>(d + 6 * S);  float* dyt = reinterpret_cast<float*>(d + 7 * S);
     float* dzt = reinterpret_cast<float*>(d + 8 * S);
+    HostPins pins(h);
+    for (const void* a : {(const void*)x, (const void*)y, (const void*)z, (const void*)orig_index, (const void*)map_index, (const void*)var,
+                          (const void*)x_ts, (const void*)y_ts, (const void*)z_ts}) pins.pin(a, S);
     GEM_HIP(h, hipMemcpyAsync(dx, x, S, hipMemcpyHostToDevice, h->stream));
     GEM_HIP(h, hipMemcpyAsync(dy, y, S, hipMemcpyHostToDevice, h->stream));
     GEM_HIP(h, hipMemcpyAsync(dz, z, S, hipMemcpyHostToDevice, h->stream));
@@ -1325,6 +1351,9 @@ int gem_fuse(gem_handle* h, int n, const int* index, const int* R, const int* G,
         int rc;
         if ((rc = ensure(h, h->stage, S * 7))) return rc;
         unsigned char* d = static_cast<unsigned char*>(h->stage.p);
+        HostPins pins(h);
+        for (const void* a : {(const void*)index, (const void*)height, (const void*)var}) pins.pin(a, S);
+        if (attr) for (const void* a : {(const void*)R, (const void*)G, (const void*)B, (const void*)intensity}) pins.pin(a, S);
         GEM_HIP(h, hipMemcpyAsync(d, index, S, hipMemcpyHostToDevice, h->stream));
         GEM_HIP(h, hipMemcpyAsync(d + S, height, S, hipMemcpyHostToDevice, h->stream));
         GEM_HIP(h, hipMemcpyAsync(d + 2 * S, var, S, hipMemcpyHostToDevice, h->stream));
@@ -1368,6 +1397,8 @@ int gem_add(gem_handle* h, const gem_frame_params* p, int n, const float* xyzi, 
         int rc;
         if ((rc = ensure(h, h->stage, S * 6))) return rc;
         unsigned char* d = static_cast<unsigned char*>(h->stage.p);
+        HostPins pins(h);
+        pins.pin(xyzi, S * 4); pins.pin(rgb, S); pins.pin(orig_index, S);
         GEM_HIP(h, hipMemcpyAsync(d, xyzi, S * 4, hipMemcpyHostToDevice, h->stream));
         in.xyzi = reinterpret_cast<const float4*>(d);
         if (rgb) { GEM_HIP(h, hipMemcpyAsync(d + 4 * S, rgb, S, hipMemcpyHostToDevice, h->stream)); in.rgb = reinterpret_cast<const uint32_t*>(d + 4 * S); }
@@ -1541,8 +1572,8 @@ int gem_reserve(gem_handle* h, long long max_points, int max_sweeps, int with_co
     // the tile pipeline takes what stays below the thresholds (and everything when the sorted forms are off)
     if ((rc = reserve_tiles(sorted_single ? std::min(max_points, h->sort_min_points - 1) : max_points, 1))) return rc;
     if (max_sweeps > 1 && (rc = reserve_tiles(sorted_batch ? std::min(max_points, h->sort_min_points_batch - 1) : max_points, max_sweeps))) return rc;
-    if (h->track_lowest && !h->ray.p) {                                  // gem_raytracing's list of walking cells
-        if ((rc = ensure(h, h->ray, ((size_t)h->cells + 4) * sizeof(uint32_t)))) return rc;
+    if (h->track_lowest && !h->ray.p) {                                  // gem_raytracing's list of walking cells, counters and snapshot
+        if ((rc = ensure(h, h->ray, ((size_t)h->cells * 2 + 4) * sizeof(uint32_t)))) return rc;
         GEM_HIP(h, hipMemsetAsync(static_cast<uint32_t*>(h->ray.p) + h->cells, 0, 4 * sizeof(uint32_t), h->stream));
     }
     GEM_HIP(h, hipStreamSynchronize(h->stream));
@@ -1590,6 +1621,8 @@ int gem_get_layer(gem_handle* h, int layer, int layout, void* dst_host)
     int rc = flush_pending(h, false);
     if (rc) return rc;
     const size_t bytes = (size_t)h->cells * 4;
+    HostPins pins(h);
+    pins.pin(dst_host, bytes);
     if (layout == GEM_LAYOUT_STORAGE_ROWMAJOR) {
         GEM_HIP(h, hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, h->stream));
     } else if (layout == GEM_LAYOUT_GRIDMAP_COLMAJOR_NAN) {
@@ -1689,6 +1722,8 @@ int gem_map_feature(gem_handle* h, float* elevation, float* variance, int* color
         {colorB, h->layers.colorB}, {rough, h->layers.rough}, {slope, h->layers.slope}, {traver, h->layers.traver},
         {intensity, h->layers.intensity}};
     bool any = false;
+    HostPins pins(h);
+    for (auto& o : out) pins.pin(o.dst, bytes);
     for (auto& o : out) if (o.dst) { GEM_HIP(h, hipMemcpyAsync(o.dst, o.src, bytes, hipMemcpyDeviceToHost, h->stream)); any = true; }
     if (any) GEM_HIP(h, hipStreamSynchronize(h->stream));
     return GEM_OK;
@@ -1843,13 +1878,13 @@ int gem_raytracing(gem_handle* h)
     if (h->row0 != 0 || h->row1 != h->L) return fail(h, GEM_ERR_INVALID, "gem_raytracing: not available on a row-strip handle");
     int rc = flush_pending(h, false);               // the queued variance increments are part of what the kernel reads
     if (rc) return rc;
-    if (!h->ray.p) {                                    // the list of walking cells and its counter (zeroed once; every call leaves it zero)
-        if ((rc = ensure(h, h->ray, ((size_t)h->cells + 4) * sizeof(uint32_t)))) return rc;
+    if (!h->ray.p) {                                    // the list of walking cells, its two counters (zeroed once; every call zeroes the next one's), the snapshot
+        if ((rc = ensure(h, h->ray, ((size_t)h->cells * 2 + 4) * sizeof(uint32_t)))) return rc;
         GEM_HIP(h, hipMemsetAsync(static_cast<uint32_t*>(h->ray.p) + h->cells, 0, 4 * sizeof(uint32_t), h->stream));
     }
     uint32_t* list = static_cast<uint32_t*>(h->ray.p);
     GEM_HIP(h, launch_raytracing(h->stream, h->layers, h->L, h->start[0], h->start[1], h->sensor_z, h->cfg.obstacle_threshold,
-                                 h->row0, h->row1, list, list + h->cells, h->ray_depth, h->ray_lanes));
+                                 h->row0, h->row1, list, list + h->cells, (int)(h->ray_calls++ & 1u), reinterpret_cast<float*>(list + h->cells + 4), h->ray_depth, h->ray_lanes));
     return GEM_OK;
 }
 
@@ -1932,6 +1967,8 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "lane_sort")          h->lane_sort = value != 0;
     else if (k == "plain_loop")         h->plain_loop = value != 0;
     else if (k == "cache_tables")       h->cache_tables = value != 0;
+    else if (k == "pin_host")           h->pin_host = value != 0;
+    else if (k == "pin_host_min_bytes") { if (value < 0) return fail(h, GEM_ERR_INVALID, "pin_host_min_bytes: >= 0"); h->pin_host_min_bytes = (size_t)value; }
     else if (k == "event_fence") {                                     // 1: the per-buffer-set events with the default system-scope fence (A/B)
         for (hipStream_t st : {h->own_stream, h->bin_stream, h->bin_stream2, h->tab_stream}) if (st) hipStreamSynchronize(st);
         for (auto& b : h->pb) {

@@ -1523,12 +1523,19 @@ __device__ __forceinline__ float div_by(float a, float b, float r)     // a / b,
 // (one ballot and one atomic per wave; the order is irrelevant, every cell only touches itself) and k_raytracing runs on full waves.
 __device__ __forceinline__ int ray_robot_index(int L) { return (L % 2 == 0) ? (int)(float)(L / 2 - 0.5) : (int)(float)(L / 2); }   // GPU:733, 739: float -> int
 
+// The same pass over the cells takes G_Clear_maplowest (GPU:232-239) with it: the walks read a SNAPSHOT of the lowest scan points,
+// written here next to the reset of the layer itself -- one launch and one pass over the layer less than clearing behind the walks
+// (k_clear_lowest was 3.8-5.6 us of the node's 45 us frame).  It also zeroes the OTHER call parity's counter of walkers.
 __global__ __launch_bounds__(256) void k_ray_list(LayerPtrs m, int L, int start0, int start1, float obstacle_threshold, int row0, int row1,
-                                                 uint32_t* __restrict__ list, uint32_t* __restrict__ count)
+                                                 uint32_t* __restrict__ list, uint32_t* __restrict__ count, uint32_t* __restrict__ count_next,
+                                                 float* __restrict__ lowest_snapshot)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool walks = false;
+    if (i == 0) *count_next = 0u;
     if (i < L * L) {
+        lowest_snapshot[i] = m.lowest[i];
+        m.lowest[i] = 10.0f;
         const int cell_x = i / L, cell_y = i - cell_x * L;
         if (cell_x >= row0 && cell_x < row1 && m.traver[i] < obstacle_threshold && m.elevation[i] != kEmptyElevation) {    // GPU:712
             int ob0 = cell_x + L - start0; ob0 -= ob0 >= L ? L : 0;                              // GPU:672-675 (% L)
@@ -1556,7 +1563,8 @@ __global__ __launch_bounds__(256) void k_ray_list(LayerPtrs m, int L, int start0
 // major index reaches (g + 1) S or the walk leaves the map; the lanes' bounds are folded by a minimum (the order is irrelevant).
 template <int RD, int G>
 __global__ __launch_bounds__(256) void k_raytracing(LayerPtrs m, int L, int start0, int start1, float sensor_z,
-                                                   const uint32_t* __restrict__ list, const uint32_t* __restrict__ count)
+                                                   const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
+                                                   const float* __restrict__ lowest_snapshot)
 {
     static_assert(G >= 1 && G <= 64 && (G & (G - 1)) == 0, "lanes per ray: a power of two inside a wave");
     const uint32_t n_rays = *count;
@@ -1628,7 +1636,7 @@ __global__ __launch_bounds__(256) void k_raytracing(LayerPtrs m, int L, int star
                 const float step = step_y ? dir_num_y : dir_num_x;
                 hit[u] = inside && step - later > threshold && c0 != ob0 && c1 != ob1;       // GPU:823-830 and twins
                 hc0[u] = c0;
-                low[u] = m.lowest[hit[u] ? (uint32_t)(c0 * L + c1) : 0u];
+                low[u] = lowest_snapshot[hit[u] ? (uint32_t)(c0 * L + c1) : 0u];
                 later = inside ? step : later;
                 const float nbx = bound_x + (float)inc_x, nby = bound_y + (float)inc_y;
                 const float ndx = div_by(nbx, dir0, rcp0), ndy = div_by(nby, dir1, rcp1);
@@ -1679,20 +1687,14 @@ hipError_t launch_unpack_aos(hipStream_t st, const void* src, int n, int step, i
     return hipGetLastError();
 }
 
-// G_Clear_maplowest (GPU:232-239) behind the walks; the same launch zeroes the list's counter for the next call
-__global__ __launch_bounds__(256) void k_clear_lowest(float* p, int n, uint32_t* count)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *count = 0u;
-    if (i < n) p[i] = 10.0f;
-}
-
-// list: L * L words (the walking cells); count: their number, zero on entry (zeroed at allocation and by every call on its way out)
+// list: L * L words (the walking cells); counts: two words, the walkers of even / odd calls (this call's is zero on entry: zeroed at
+// allocation and by the call before); snapshot: L * L floats
 hipError_t launch_raytracing(hipStream_t st, const LayerPtrs& m, int L, int start0, int start1, float sensor_z, float obstacle_threshold,
-                             int row0, int row1, uint32_t* list, uint32_t* count, int depth, int lanes)
+                             int row0, int row1, uint32_t* list, uint32_t* counts, int parity, float* lowest_snapshot, int depth, int lanes)
 {
     const dim3 grid((L * L + 255) / 256), block(256);
-    hipLaunchKernelGGL(k_ray_list, grid, block, 0, st, m, L, start0, start1, obstacle_threshold, row0, row1, list, count);
+    uint32_t* count = counts + (parity & 1), *count_next = counts + ((parity + 1) & 1);
+    hipLaunchKernelGGL(k_ray_list, grid, block, 0, st, m, L, start0, start1, obstacle_threshold, row0, row1, list, count, count_next, lowest_snapshot);
     auto k = lanes >= 16 ? (depth >= 8 ? k_raytracing<8, 16> : k_raytracing<4, 16>)
            : lanes >= 8  ? (depth >= 8 ? k_raytracing<8, 8>  : k_raytracing<4, 8>)
            : lanes >= 4  ? (depth >= 8 ? k_raytracing<8, 4>  : k_raytracing<4, 4>)
@@ -1700,8 +1702,7 @@ hipError_t launch_raytracing(hipStream_t st, const LayerPtrs& m, int L, int star
     const int g_lanes = lanes >= 16 ? 16 : lanes >= 8 ? 8 : lanes >= 4 ? 4 : 1;
     const long long want = ((long long)L * L * g_lanes + 255) / 256;
     const dim3 ray_grid((unsigned)(want < 4096 ? want : 4096));           // the walkers are a fraction of the cells: grid-stride
-    hipLaunchKernelGGL(k, ray_grid, block, 0, st, m, L, start0, start1, sensor_z, (const uint32_t*)list, (const uint32_t*)count);
-    hipLaunchKernelGGL(k_clear_lowest, grid, block, 0, st, m.lowest, L * L, count);
+    hipLaunchKernelGGL(k, ray_grid, block, 0, st, m, L, start0, start1, sensor_z, (const uint32_t*)list, (const uint32_t*)count, (const float*)lowest_snapshot);
     return hipGetLastError();
 }
 

@@ -218,7 +218,9 @@ size_t     fuse_lds_bytes(int ts, int variant, int attr);
 hipError_t launch_init(hipStream_t st, const LayerPtrs& m, int cells, int clear_lowest);
 hipError_t launch_unpack_aos(hipStream_t st, const void* src, int n, int step, int ox, int oy, int oz, int oi, int orgb, float4* xyzi, uint32_t* rgb);
 hipError_t launch_raytracing(hipStream_t st, const LayerPtrs& m, int L, int start0, int start1, float sensor_z, float obstacle_threshold,
-                             int row0, int row1, uint32_t* list, uint32_t* count, int depth = 4, int lanes = 16);   // depth: loads in flight per lane (4, 8); lanes per ray (1, 4, 8, 16); list: L * L words; count: one word, zero on entry, left zero
+                             int row0, int row1, uint32_t* list, uint32_t* counts, int parity, float* lowest_snapshot, int depth = 4, int lanes = 16);
+                             // depth: loads in flight per lane (4, 8); lanes per ray (1, 4, 8, 16); list: L * L words; counts: two words (even / odd calls),
+                             // this call's zero on entry; lowest_snapshot: L * L floats (the walks read it, the layer itself is reset to 10)
 hipError_t launch_clear_strip(hipStream_t st, const LayerPtrs& m, int L, int start, int count, int is_row);
 hipError_t launch_dense_variance(hipStream_t st, float* variance, int cells, int n_pending, const float* pending,
                                  int apply_floor, float var_floor);

@@ -118,3 +118,136 @@ def test_cpp_host_side_known_answers_on_gpu(lib, tmp_path):
     exe = build_facade_check(tmp_path)
     res = subprocess.run([str(exe), "1"], capture_output=True, text=True)
     assert res.returncode == 0, res.stdout + res.stderr
+
+
+# ---- the boundary from the CALLERS' side -------------------------------------------------------------------------
+REF_SRC = Path("/root/reference/elevation_mapping/elevation_mapping/src")
+CALLER_DECLS = {          # where the reference's callers forward-declare the nine libgpu.so functions (no shared header exists)
+    "ElevationMapping.cpp": ["Move", "Init_GPU_elevationmap", "Map_closeloop", "Raytracing", "Fuse", "Map_feature", "Map_optmove"],
+    "sensor_processors/SensorProcessorBase.cpp": ["Process_points"],
+    "RobotMotionMapUpdater.cpp": ["Mapvar_update"],
+}
+
+
+def callers_declarations():
+    """The forward declarations, read from the reference WHERE IT LIES at test time (nothing of it is committed)."""
+    out = []
+    for rel, names in CALLER_DECLS.items():
+        text = (REF_SRC / rel).read_text(errors="ignore")
+        for n in names:
+            m = re.search(r"^(?:void|int)\s+" + n + r"\s*\([^;{]*\)\s*;", text, flags=re.M)
+            assert m, f"{n} is not forward-declared in {rel} any more"
+            out.append(m.group(0))
+    return out
+
+
+def build_adapter_object(tmp_path) -> Path:
+    src = tmp_path / "adapter.cpp"
+    src.write_text('#include "gem/gem_compat_eigen.hpp"\n')
+    obj = tmp_path / "adapter.o"
+    res = subprocess.run(["g++", "-std=c++17", "-O1", "-fPIC", "-c", "-I", str(ROOT / "include"), "-I", str(ROOT / "tests" / "cpp" / "fake_eigen"),
+                          str(src), "-o", str(obj)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    return obj
+
+
+def test_the_callers_own_declarations_link_against_the_adapter(lib, tmp_path):
+    """A translation unit holding the reference callers' OWN forward declarations (ElevationMapping.cpp:44-50,
+    SensorProcessorBase.cpp:34, RobotMotionMapUpdater.cpp:18) calls all nine functions and is linked against the adapter object
+    (include/gem/gem_compat_eigen.hpp), with one Eigen stand-in on both sides: C++ mangling carries every parameter type, so a link
+    without unresolved symbols means the nine signatures are the callers' -- including Mapvar_update, declared `int` by its caller
+    and defined `void` by the library (the mangled name has no return type)."""
+    if not REF_SRC.exists():
+        pytest.skip("no /root/reference on this box")
+    decls = callers_declarations()
+    assert len(decls) == 9
+    calls = """
+int call_all(int n)
+{
+    float f3[3] = {0, 0, 0}, f2[2] = {0, 0}; int i2[2] = {0, 0};
+    std::vector<int> iv(n > 0 ? n : 1); std::vector<float> fv(n > 0 ? n : 1);
+    Init_GPU_elevationmap(64, 0.1f, 5.0f, 0.7f);
+    Move(f3, 0.1f, 64, f2, i2, f2);
+    Process_points(iv.data(), fv.data(), fv.data(), fv.data(), fv.data(), fv.data(), fv.data(), fv.data(), Eigen::Matrix4f(), n, -1.0, 1.0, 0.018f, 0.0006f, 0.0015f,
+                   Eigen::RowVector3f(), Eigen::Matrix3f(), Eigen::Matrix3f(), Eigen::RowVector3f(), Eigen::Matrix3f());
+    Fuse(64, n, iv.data(), iv.data(), iv.data(), iv.data(), fv.data(), fv.data(), fv.data());
+    const int r = Mapvar_update(64, 1e-6f);
+    Map_feature(64, fv.data(), fv.data(), iv.data(), iv.data(), iv.data(), fv.data(), fv.data(), fv.data(), fv.data());
+    Raytracing(64);
+    Map_optmove(f2, 0.0f, 0.1f, 64, f2);
+    Map_closeloop(f2, 0.0f, 64, 0.1f);
+    return r;
+}
+int main(int argc, char**) { return argc > 100 ? call_all(argc) : 0; }       // (linked, not run: this is a link test)
+"""
+    src = tmp_path / "callers.cpp"
+    src.write_text("#include <Eigen/Core>\n#include <vector>\n" + "\n".join(decls) + "\n" + calls)
+    obj = tmp_path / "callers.o"
+    res = subprocess.run(["g++", "-std=c++17", "-O0", "-c", "-I", str(ROOT / "tests" / "cpp" / "fake_eigen"), str(src), "-o", str(obj)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    adapter = build_adapter_object(tmp_path)
+    libdir = ROOT / "gem_amd" / "lib"
+    exe = tmp_path / "callers"
+    res = subprocess.run(["g++", str(obj), str(adapter), "-o", str(exe), f"-L{libdir}", "-lgem_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, "the callers' declarations do not resolve against the adapter:\n" + res.stderr
+    undefined = subprocess.run(["nm", "-C", "-u", str(obj)], capture_output=True, text=True).stdout
+    for n in sum(CALLER_DECLS.values(), []):
+        assert n + "(" in undefined, f"{n} is not referenced by the callers' translation unit"
+    assert subprocess.run([str(exe)], capture_output=True).returncode == 0
+
+
+@pytest.mark.gpu
+def test_reference_motion_updater_drives_the_adapters_mapvar_update(lib, tmp_path, oracle_mod):
+    """The reference's own RobotMotionMapUpdater::update (compiled from where it lies, oracle/_ref/libgem_ref_motion.so) computes the
+    increments; each is handed to the ADAPTER's Mapvar_update (the symbol RMU.cpp:81 calls) on a populated GPU map; the variance layer
+    read back through the adapter's Map_feature must equal the oracle's after the same calls."""
+    import numpy as np
+    import ref
+    from gem_amd import synth
+    if ref.motion_lib() is None:
+        pytest.skip("no /root/reference to build from and no prebuilt oracle/_ref/libgem_ref_motion.so")
+    adapter = build_adapter_object(tmp_path)
+    libdir = ROOT / "gem_amd" / "lib"
+    so = tmp_path / "libadapter.so"
+    res = subprocess.run(["g++", "-shared", str(adapter), "-o", str(so), f"-L{libdir}", "-lgem_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    names = {}
+    for line in subprocess.run(["nm", "-D", "--defined-only", str(so)], capture_output=True, text=True).stdout.splitlines():
+        sym = line.split()[-1]
+        for n in ("Init_GPU_elevationmap", "Fuse", "Mapvar_update", "Map_feature"):
+            if re.fullmatch(r"_Z\d+" + n + r"[a-zA-Z_0-9]*", sym):
+                names[n] = sym
+    assert len(names) == 4, names
+    ad = C.CDLL(str(so))
+    L, res_m = 96, 0.1
+    F, I = C.POINTER(C.c_float), C.POINTER(C.c_int)
+    getattr(ad, names["Init_GPU_elevationmap"]).argtypes = [C.c_int, C.c_float, C.c_float, C.c_float]
+    getattr(ad, names["Fuse"]).argtypes = [C.c_int, C.c_int, I, I, I, I, F, F, F]
+    getattr(ad, names["Mapvar_update"]).argtypes = [C.c_int, C.c_float]
+    getattr(ad, names["Map_feature"]).argtypes = [C.c_int, F, F, I, I, I, F, F, F, F]
+    getattr(ad, names["Init_GPU_elevationmap"])(L, res_m, 5.0, 0.7)
+    rng = np.random.default_rng(11)
+    n = 5000
+    idx = rng.integers(0, L * L, n).astype(np.int32); hgt = rng.normal(0, 0.2, n).astype(np.float32); var = rng.uniform(3e-4, 2e-3, n).astype(np.float32)
+    zi = np.zeros(n, np.int32); zf = np.zeros(n, np.float32)
+    p = lambda a, t: a.ctypes.data_as(t)
+    getattr(ad, names["Fuse"])(L, n, p(idx, I), p(zi, I), p(zi, I), p(zi, I), p(zf, F), p(hgt, F), p(var, F))
+    om = oracle_mod.OracleMap(L, res_m)
+    om.fuse(idx, hgt, var)
+    rm = ref.RefMotion(1.3, L)
+    pos = np.zeros(3)
+    for k in range(12):
+        pos = pos + rng.normal(0, 0.2, 3)
+        R = synth.rot_zyx(0.1 * k, rng.normal(0, 0.05), rng.normal(0, 0.05))
+        a = rng.normal(size=(6, 6)) * 1e-2
+        u = rm.compute(pos, R, a @ a.T * (1 + 0.1 * k))
+        if u is None:
+            continue
+        getattr(ad, names["Mapvar_update"])(L, float(u))
+        om.mapvar_update(float(u))
+    out = [np.zeros(L * L, np.float32) for _ in range(6)]; outi = [np.zeros(L * L, np.int32) for _ in range(3)]
+    getattr(ad, names["Map_feature"])(L, p(out[0], F), p(out[1], F), p(outi[0], I), p(outi[1], I), p(outi[2], I), p(out[2], F), p(out[3], F), p(out[4], F), p(out[5], F))
+    assert np.array_equal(out[0].reshape(L, L), om.layer("elevation")) and np.array_equal(out[1].reshape(L, L), om.layer("variance"))
+    assert (om.layer("variance") > 1e-4).sum() > 1000

@@ -119,6 +119,30 @@ def test_other_noise_models(oracle_mod, model):
     assert rel_err(g["var"][o["index"] >= 0], o["var"][o["index"] >= 0]) <= 1e-5     # double pow()/sqrt() may differ in the last ulp
 
 
+@pytest.mark.parametrize("model", ["structured_light", "stereo"])
+def test_full_c3_fused_with_the_camera_noise_models(oracle_mod, model):
+    """The whole depth image (307 200 points, hundreds per cell under the camera) FUSED with the structured-light and the stereo
+    variance models -- not only projected (test_other_noise_models) -- through whatever pipeline the run selects, from a host array
+    and from a device tensor, twice into the map.  The variances go through double pow / sqrt on both sides and may differ in the
+    last ulp, so the bar is north_star's 1e-5 on every cell (and the same set of non-empty cells), not bit equality."""
+    import torch
+    gpu, ref = make_pair(oracle_mod, 400, 0.025)
+    gpu_d = ElevationMap(400, 0.025)
+    wl = synth.config_c3(structured_light=(model == "structured_light"))
+    f = wl.frames[0]
+    if model == "stereo":
+        f.model = SensorModel(2, (0.1, 0.001, 380.0, 1.0, 0.002, 0.001, 30.0), original_width=640)
+    c, oi = wl.clouds[0], wl.orig_index
+    dc, doi = torch.from_numpy(c).cuda(), torch.from_numpy(oi).cuda()
+    for m in (gpu, gpu_d, ref):
+        m.move(wl.map_position)
+    for rep in range(2):
+        gpu.add(f, c, orig_index=oi); gpu_d.add(f, dc, orig_index=doi); ref.add(f, c, orig_index=oi)
+        assert_maps_match(gpu, ref, exact=False)
+        assert_maps_match(gpu_d, ref, exact=False)
+    assert (ref.layer("elevation") != -10).sum() > 20000
+
+
 # ---- the fused add path -----------------------------------------------------------------------------
 @pytest.mark.parametrize("cfg", ["c1", "c2", "c2_filter", "c3"])
 def test_add_parity(oracle_mod, cfg):
