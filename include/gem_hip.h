@@ -247,7 +247,11 @@ int  gem_get_stats(gem_handle* h, gem_stats* out, int reset);
 /* Pre-size the handle's device arenas for the largest pass that is going to come: max_points points in at most max_sweeps sweeps
  * per call (1 for gem_add / gem_add_device / gem_fuse), with or without colours.  The arenas only ever grow, but growing in the
  * middle of a stream -- the first bigger cloud after smaller ones -- waits for everything in flight and re-allocates; after
- * gem_reserve no pass within these bounds allocates.  Synchronous; call it once after gem_create.                            */
+ * gem_reserve no pass within these bounds allocates, whichever pipeline it takes (the sorted forms from their thresholds on, the
+ * tile pipeline below them; the sweeps of a batch below the sorted threshold are taken to be at most twice their mean length).
+ * On a handle that joined a communicator with gem_comm_init_tiles the bounds are those of a gem_add_sharded_device STEP -- the
+ * GLOBAL points and sweeps: the shard's sort (its W-th of the points), both sets of receive buffers (no strip gets more records
+ * than the step has points) and the staging tables are sized.  Synchronous; call it once after gem_create / gem_comm_init*.    */
 int  gem_reserve(gem_handle* h, long long max_points, int max_sweeps, int with_colours);
 
 /* ---- multi-GPU: RCCL all-gather of the fused strips over xGMI ------------------------
@@ -274,11 +278,17 @@ int  gem_allgather_layers(gem_handle* h, int with_attributes);   /* elevation+va
  *      range), the sorted records of every strip travel to the strip's owner together with their block ranges (ncclSend /
  *      ncclRecv, one group, on the handle's communication stream; a rank's own records stay where they are), and the owner takes
  *      every block's records source by source in rank order -- ascending index ranges, so rank order is input order and every
- *      cell sees its points exactly as on one device.  With one rank nothing is exchanged and nothing returns to the host; with
- *      more, one host round trip per call tells the ranks what they receive.  Follow with gem_allgather_layers (asynchronous:
- *      it overlaps the next call's sort).  var_updates_global (n_global_sweeps values, identical on all ranks) may be NULL.  No
- *      colours, no lowest tracking on this path.  An error returned after the first collective of a call means the communicator
- *      has to be aborted (the other ranks wait in theirs); arguments, geometry and allocations are checked before it.
+ *      cell sees its points exactly as on one device.  With one rank nothing is exchanged and nothing returns to the host.  With
+ *      more, the call enqueues the step's sort and the all-gather of its strip boundaries (16 words per rank, copied to the host)
+ *      and returns; the step's SECOND HALF -- the exchange on the communication stream, the fusion on the handle's stream, and the
+ *      all-gather of the layers on a stream and communicator of their own if gem_allgather_layers followed the step -- is enqueued by
+ *      the NEXT call, or by whatever observes or modifies the map (gem_synchronize, gem_get_layer, gem_move, gem_mapvar_update,
+ *      ...): nothing ever waits for work the same call enqueued, and consecutive steps overlap stage by stage.  All of these are
+ *      collectives: every rank makes the same sequence of calls.  var_updates_global (n_global_sweeps <= 512 values, identical on
+ *      all ranks) may be NULL.  No colours, no lowest tracking on this path.  Arguments, geometry and every allocation -- the receive
+ *      buffers included, sized from gem_reserve's bound or from W shares like this rank's -- are checked before the step's first
+ *      collective; a rank that still cannot go on in the middle of a step (a step that brings more records than foreseen, and no
+ *      memory to grow) aborts both communicators, so that its peers fail instead of waiting.
  *      The two halves are exported for hosts that carry the exchange themselves (gem_amd/tiling.py with torch.distributed):
  *      gem_shard_sort_device returns the device arrays of the sorted records {h, var} (8 bytes) / keys (4 bytes),
  *      out_bounds[nstrips + 1] = the first record of every strip, and (optional) the device array of the block ranges
