@@ -117,6 +117,7 @@ struct gem_handle {
     int  walk_prio = 4096;              // k_fuse_block: blocks of at least this many records run at raised issue priority (debug knob, 0 = off)
     bool pin_host = true;               // caller-owned host arrays of at least pin_host_min_bytes are pinned for the call (HostPins; debug knob)
     size_t pin_host_min_bytes = 256 * 1024;
+    bool light_fast = true;             // k_fuse_block's light rounds by arrival slots + sorting network (debug knob)
     bool cache_tables = true;           // batched calls: skip building / uploading tables equal to the ones the buffer set already holds (debug knob)
     std::vector<unsigned char> key_scratch;
     bool plain_loop = true;             // the walks' plain chain loop for blocks whose values are in range (debug knob: 0 = the guarded loop everywhere)
@@ -754,7 +755,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     wa.n_pending = h->n_pending;
     for (int i = 0; i < kMaxPending; ++i) wa.pending[i] = h->pending[i];
     wa.plain_env = h->plain_loop ? walk_plain_env(wa.var_floor, wa.mahal, h->pending, h->n_pending, batched ? in.var_updates : nullptr, in.n_sweeps) : 0;
-    wa.prio_records = h->walk_prio; wa.lds_pad = h->walk_lds_pad;
+    wa.prio_records = h->walk_prio; wa.lds_pad = h->walk_lds_pad; wa.light_fast = h->light_fast ? 1 : 0;
     wa.elevation = h->layers.elevation; wa.variance = h->layers.variance; wa.lowest = h->layers.lowest;
     wa.start0 = h->start[0]; wa.start1 = h->start[1];
     wa.intensity = h->layers.intensity; wa.colorR = h->layers.colorR; wa.colorG = h->layers.colorG; wa.colorB = h->layers.colorB;
@@ -1967,6 +1968,7 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "lane_sort")          h->lane_sort = value != 0;
     else if (k == "plain_loop")         h->plain_loop = value != 0;
     else if (k == "cache_tables")       h->cache_tables = value != 0;
+    else if (k == "light_fast")         h->light_fast = value != 0;
     else if (k == "pin_host")           h->pin_host = value != 0;
     else if (k == "pin_host_min_bytes") { if (value < 0) return fail(h, GEM_ERR_INVALID, "pin_host_min_bytes: >= 0"); h->pin_host_min_bytes = (size_t)value; }
     else if (k == "event_fence") {                                     // 1: the per-buffer-set events with the default system-scope fence (A/B)
@@ -2329,7 +2331,7 @@ int shard_fuse_locked(gem_handle* h, int n_src, const void* const* d_hv, const v
     wa.n_pending = h->n_pending;
     for (int i = 0; i < kMaxPending; ++i) wa.pending[i] = h->pending[i];
     wa.plain_env = h->plain_loop ? walk_plain_env(wa.var_floor, wa.mahal, h->pending, h->n_pending, var_updates_global, n_global_sweeps) : 0;
-    wa.prio_records = h->walk_prio; wa.lds_pad = h->walk_lds_pad;
+    wa.prio_records = h->walk_prio; wa.lds_pad = h->walk_lds_pad; wa.light_fast = h->light_fast ? 1 : 0;
     wa.elevation = h->layers.elevation; wa.variance = h->layers.variance; wa.lowest = h->layers.lowest;
     wa.start0 = h->start[0]; wa.start1 = h->start[1];
     wa.counters = h->counting ? h->d_counters : nullptr;

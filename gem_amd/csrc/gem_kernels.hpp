@@ -174,6 +174,7 @@ struct WalkArgs {
     int light_blocks;                  // k_fuse_block: rounds of 512 records instead of 2048 (blocks of a few hundred records)
     int   exact_bins;                  // 1: the last pass's bins ARE the blocks (one-pass sort): bin_base gives a block's records without a search
     const uint32_t* odd_flag; uint32_t epoch;   // k_fuse_walk: *odd_flag == epoch: some record of the pass is outside the plain range (k_sort_project)
+    int   light_fast;                  // k_fuse_block, rounds of 512: arrival slots + a sorting network per cell instead of rank / scan / placement (0 = off, debug knob)
     int   lds_pad;                     // k_fuse_block: unused dynamic LDS on top of what the kernel needs (debug knob)
     int   prio_records;                // k_fuse_block: blocks of at least this many records raise their waves' issue priority (0 = off)
     int   plain_env;                   // 1: floor, threshold and every variance increment of the pass lie in the range the walks' plain chain loop assumes (walk_plain_env)

@@ -993,6 +993,11 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
     __shared__ uint32_t seg_first[kMaxRanks], seg_off[kMaxRanks + 1];                  // per source: first record of the block; prefix of the counts
     __shared__ unsigned long long seg_key[kMaxRanks], seg_hv[kMaxRanks];
     __shared__ uint32_t blk_odd;                                                       // some record or cell state of this block is outside the plain range (below)
+    // LIGHT rounds the fast way (below): arrival slots per cell + a flag "some cell got more than kLightSlots records this round"
+    constexpr bool FAST_LIGHT = B <= 512 && FLAGS == 0 && !COUNT_SWEEPS;
+    constexpr int kLightSlots = 6;
+    __shared__ uint16_t cslot[FAST_LIGHT ? NT * kLightSlots : 1];
+    __shared__ uint32_t blk_over;
     const int tid = (int)threadIdx.x, lane = lane_id(), w = __builtin_amdgcn_readfirstlane(tid >> 6);
     // The PLAIN chain loop (the blocks of every LiDAR pass): one step of the recurrence is a single wave issuing ~90 instructions in
     // order, a third of them guards -- the exponent ranges that let both Kalman quotients share one reciprocal (fuse_step<true>), the
@@ -1004,7 +1009,8 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
     // |N1| >= 2^-60 (a cancellation) and at the threshold band.  Anything else takes the loop as it was.
     constexpr bool PLAIN_OK = FLAGS == 0 && !COUNT_SWEEPS;
     constexpr float kPlainHi = 268435456.0f, kPlainLo = 3.7252902984619140625e-9f;      // 2^28, 2^-28
-    if (tid == 0) blk_odd = 0u;
+    if (tid == 0) { blk_odd = 0u; blk_over = 0u; }
+    ccnt[tid] = 0u;
 
     // workgroup -> block of 256 cells: tile rows centre-first when all workgroups are resident at once (see k_fuse_walk), else memory
     // order.  (Tried: the blocks sorted by record count on the device and dealt out heavy / middle / light to consecutive
@@ -1211,9 +1217,79 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         if (dbg && tid == 0) { const unsigned long long t = __builtin_readcyclecounter(); acc += t - t_prev; t_prev = t; }
     };
 
+    // ---- one step of the PLAIN chain loop (see the head of the kernel for what makes a block plain)
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const float fl_ = a.var_floor, thr_ = a.mahal, band_ = 1e-5f * fabsf(a.mahal);
+    float un1 = 0.0f, un2 = 0.0f, un3 = 0.0f;                          // increments of sweeps cur + 1 .. cur + 3, fetched a step ahead
+    auto plain_begin = [&]() { if constexpr (HAS_VU) { un1 = vu[rp.cur + 1u]; un2 = vu[rp.cur + 2u]; un3 = vu[rp.cur + 3u]; } };
+    auto plain_step = [&](const uint2 r, const uint32_t swr, const bool live) {
+        const float h = __uint_as_float(r.x), v = __uint_as_float(r.y);
+        bool rare = false;
+        uint32_t sw = 0;
+        if constexpr (HAS_VU) {
+            // Between two records of sweeps s < t the cell lives through (t - s) x {floor (GPU:533-534); next sweep's increment
+            // (GPU:540-547)}.  The floor is positive, so a floored variance is never the -10 of an empty cell and the increment
+            // always applies; the increments are not negative (plain_env), so after the first floor the later ones change
+            // nothing: a gap of g sweeps is one floor and g rounded additions.  Gaps of up to three sweeps -- 99.98 % of them
+            // on a LiDAR batch, and with 64 lanes per step the rest still matters -- are predicated straight-line code on
+            // increments fetched a step ahead; wider ones take the rare branch.  (The guarded loop's way -- a ballot and a
+            // branch per sweep of the widest gap in the wave -- was a third of its step.)
+            sw = live ? swr : rp.cur;
+            const uint32_t gap = sw - rp.cur;
+            const float c1 = (cs < fl_ ? fl_ : cs) + un1;
+            cs = gap >= 1u ? c1 : cs;
+            const float c2 = cs + un2;
+            cs = gap >= 2u ? c2 : cs;
+            const float c3 = cs + un3;
+            cs = gap >= 3u ? c3 : cs;
+            rp.cur += min(gap, 3u);
+            rare = gap > 3u;
+            un1 = vu[rp.cur + 1u]; un2 = vu[rp.cur + 2u]; un3 = vu[rp.cur + 3u];
+        }
+        const float sf = cs < fl_ ? fl_ : cs;                              // GPU:500-501
+        const float m = fabsf(h - ce) * __builtin_amdgcn_rsqf(sf);         // GPU:502, see fuse_step
+        const float D = sf + v;                                            // GPU:518, 519
+        v2f N; N.x = sf * h + v * ce; N.y = v * sf;
+        rare = (rare | (fabsf(m - thr_) <= band_) | !(fabsf(N.x) >= 8.673617379884035e-19f)) & live;   // 2^-60
+        // both quotients from one refined reciprocal (fuse_step<true>), as a pair
+        const float r0 = __builtin_amdgcn_rcpf(D);
+        const float rr = __builtin_fmaf(__builtin_fmaf(-D, r0, 1.0f), r0, r0);
+        const v2f rr2 = {rr, rr}, nD2 = {-D, -D};
+        v2f q = N * rr2;
+        v2f t = __builtin_elementwise_fma(nD2, q, N);
+        q = __builtin_elementwise_fma(t, rr2, q);
+        t = __builtin_elementwise_fma(nD2, q, N);
+        q = __builtin_elementwise_fma(t, rr2, q);
+        const bool outlier = m > thr_;
+        const bool replace = (ce == kEmptyElevation) | (outlier & (ce < h));   // GPU:484-486, 505-507
+        float e2 = replace ? h : (outlier ? ce : q.x);
+        float s2 = replace ? v : (outlier ? sf : q.y);
+        if (__builtin_expect(__ballot(rare) != 0, 0)) {                    // wave-uniform: the step as the guarded loop takes it
+            if (dbg && tid == 0) ++acc_rare;
+            if constexpr (HAS_VU) {
+                while (__ballot(rp.cur < sw) != 0) { if (rp.cur < sw) rp.one(cs, vu[rp.cur + 1u], fl_); }
+                un1 = vu[rp.cur + 1u]; un2 = vu[rp.cur + 2u]; un3 = vu[rp.cur + 3u];
+            }
+            e2 = ce; s2 = cs;
+            fuse_step<true>(e2, s2, h, v, thr_, fl_);
+        }
+        ce = live ? e2 : ce; cs = live ? s2 : cs;
+    };
+    // ... and of the guarded one (no colours, no lowest scan points: the light rounds below)
+    auto guarded_step = [&](const uint2 r, const uint32_t sw, const bool live) {
+        const float h = __uint_as_float(r.x), v = __uint_as_float(r.y);
+        if constexpr (HAS_VU) rp.advance(cs, live ? sw : rp.cur, vu, a.var_floor);
+        float e2 = ce, s2 = cs;
+        fuse_step<true>(e2, s2, h, v, a.mahal, a.var_floor);
+        ce = live ? e2 : ce; cs = live ? s2 : cs;
+    };
+
     uint32_t parity = 0;
     if (R) load_batch(0u, min(R, (uint32_t)B));
-    if constexpr (!MULTI) zero_tables();
+    // (light kernels clear the general way's tables only when a round needs them: `tables_clear`)
+    bool tables_clear = false;
+    if constexpr (!MULTI) { if (!(FAST_LIGHT && a.light_fast)) { zero_tables(); tables_clear = true; } else __syncthreads(); }
+    else tables_clear = true;
     sh_e[tid] = e_in; sh_s[tid] = s_in;                                // (the first wait for memory: the map values, with the first batch in flight behind them)
     if constexpr (LOWEST) sh_l[tid] = l_in;
     if constexpr (PLAIN_OK) odd = !(fabsf(e_in) <= kPlainHi) || !(s_in <= kPlainHi);
@@ -1230,6 +1306,73 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
             if (ATTR) asm volatile("" : "+v"(nsrc[k]));
 #endif
             key[k] = nkey[k]; hv[k] = nhv[k]; if (ATTR) src[k] = nsrc[k];
+        }
+        // ---- LIGHT rounds the fast way.  A big map's blocks hold a few hundred records each -- one or two per cell and round -- and
+        //      the general way below (a stable rank per (wave, cell), a block scan, the placement: five barriers) is most of such a
+        //      block's time.  Here every record takes an ARRIVAL slot of its cell (one LDS atomic) and leaves its position in the
+        //      round there; the cell's thread sorts its at most six positions (a 12-comparator network: ascending position = input
+        //      order) and runs the records straight from the stage: two barriers.  A round in which some cell gets more than six
+        //      records takes the general way (the counts are cleared first).
+        if constexpr (FAST_LIGHT) {
+            if (a.light_fast) {                                        // (debug knob; block-uniform)
+                bool over = false;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    if (in_batch(k, steps, nb)) {
+                        const uint32_t j = ((uint32_t)w * steps + (uint32_t)k) * 64u + (uint32_t)lane, cell = key[k] & 255u;
+                        st_hv[j] = hv[k];
+                        if constexpr (KEYED) st_sw[j] = (uint16_t)(key[k] >> a.id_bits);
+                        const uint32_t slot = atomicAdd(&ccnt[cell], 1u);
+                        if (slot < (uint32_t)kLightSlots) cslot[cell * kLightSlots + slot] = (uint16_t)j; else over = true;
+                        if constexpr (PLAIN_OK) {
+                            const float hh = __uint_as_float(hv[k].x), vv = __uint_as_float(hv[k].y);
+                            odd = odd || !(fabsf(hh) <= kPlainHi) || !(vv >= kPlainLo) || !(vv <= kPlainHi);
+                        }
+                    }
+                }
+                if constexpr (PLAIN_OK) { if (odd) blk_odd = 1u; }
+                if (over) blk_over = 1u;
+                __syncthreads();
+                lap(acc_rank);
+                if (blk_over == 0u) {                                  // block-uniform
+                    if (P + (uint32_t)B < R) load_batch(P + (uint32_t)B, min(R - P - (uint32_t)B, (uint32_t)B));
+                    if (P == 0u) take_cell();                          // (light passes hand the cells out in place: c == tid)
+                    const uint32_t cn = ccnt[tid];
+                    ccnt[tid] = 0u;
+                    uint32_t sp[kLightSlots];
+#pragma unroll
+                    for (int i = 0; i < kLightSlots; ++i) sp[i] = (uint32_t)i < cn ? (uint32_t)cslot[tid * kLightSlots + i] : 0xffffu;
+                    auto cx = [&](int i, int j) { const uint32_t lo = min(sp[i], sp[j]), hi = max(sp[i], sp[j]); sp[i] = lo; sp[j] = hi; };
+                    n_total += cn;
+                    const uint32_t nmax = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_max(cn), 63);
+                    // (unused slots hold 0xffff and sort to the end; the network is as wide as the wave's busiest cell needs)
+                    if (nmax > 4u) { cx(0, 1); cx(2, 3); cx(4, 5); cx(0, 2); cx(3, 5); cx(1, 4); cx(0, 1); cx(2, 3); cx(4, 5); cx(1, 2); cx(3, 4); cx(2, 3); }
+                    else if (nmax > 2u) { cx(0, 1); cx(2, 3); cx(0, 2); cx(1, 3); cx(1, 2); }
+                    else if (nmax > 1u) cx(0, 1);
+                    lap(acc_pre);
+                    bool plain = false;
+                    if constexpr (PLAIN_OK) plain = a.plain_env != 0 && blk_odd == 0u;
+                    if (plain) { if constexpr (PLAIN_OK) plain_begin(); } else { if constexpr (HAS_VU) rp.refill(vu); }
+#pragma unroll
+                    for (int i = 0; i < kLightSlots; ++i) {
+                        if ((uint32_t)i < nmax) {                      // wave-uniform
+                            const uint32_t at = min(sp[i], (uint32_t)B - 1u);
+                            const uint2 r = st_hv[at];
+                            uint32_t sw = 0;
+                            if constexpr (KEYED) sw = st_sw[at];
+                            if (plain) { if constexpr (PLAIN_OK) plain_step(r, sw, (uint32_t)i < cn); }
+                            else guarded_step(r, sw, (uint32_t)i < cn);
+                        }
+                    }
+                    lap(acc_walk);
+                    acc_nmax += nmax; ++n_batches;
+                    __syncthreads();                                   // the stage, the slots and the counts are free for the next round
+                    continue;
+                }
+                ccnt[tid] = 0u;                                        // the general way for this round
+                if (!tables_clear) { zero_tables(); tables_clear = true; } else __syncthreads();
+                if (tid == 0) blk_over = 0u;
+            }
         }
         // ---- 1. stable rank of every record among the records of its cell in the wave's share.  Phase by phase: a wave's LDS
         //         operations execute in order, so the K steps' round trips overlap.
@@ -1322,10 +1465,7 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         if (plain) {
             // ---- the PLAIN loop: straight-line, one rarely-taken branch per step
             if constexpr (PLAIN_OK) {
-                typedef float v2f __attribute__((ext_vector_type(2)));
-                const float fl_ = a.var_floor, thr = a.mahal, band = 1e-5f * fabsf(a.mahal);
-                float un1 = 0.0f, un2 = 0.0f, un3 = 0.0f;              // increments of sweeps cur + 1 .. cur + 3, fetched a step ahead
-                if constexpr (HAS_VU) { un1 = vu[rp.cur + 1u]; un2 = vu[rp.cur + 2u]; un3 = vu[rp.cur + 3u]; }
+                plain_begin();
                 // (the reads run past a lane's last record -- into the next cell's, or the tables behind the stage: LDS reads do not
                 //  fault and a lane that is not `live` discards what it computes -- so the addresses are plain increments)
                 const uint2* ph = st_hv + cf + 1u;
@@ -1334,58 +1474,7 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
                     const uint2 r = nx; const uint32_t swr = nx_sw;
                     nx = *ph++;
                     if constexpr (KEYED) nx_sw = *ps++;
-                    const bool live = i < cn;
-                    const float h = __uint_as_float(r.x), v = __uint_as_float(r.y);
-                    bool rare = false;
-                    uint32_t sw = 0;
-                    if constexpr (HAS_VU) {
-                        // Between two records of sweeps s < t the cell lives through (t - s) x {floor (GPU:533-534); next sweep's increment
-                        // (GPU:540-547)}.  The floor is positive, so a floored variance is never the -10 of an empty cell and the increment
-                        // always applies; the increments are not negative (plain_env), so after the first floor the later ones change
-                        // nothing: a gap of g sweeps is one floor and g rounded additions.  Gaps of up to three sweeps -- 99.98 % of them
-                        // on a LiDAR batch, and with 64 lanes per step the rest still matters -- are predicated straight-line code on
-                        // increments fetched a step ahead; wider ones take the rare branch.  (The guarded loop's way -- a ballot and a
-                        // branch per sweep of the widest gap in the wave -- was a third of its step.)
-                        sw = live ? swr : rp.cur;
-                        const uint32_t gap = sw - rp.cur;
-                        const float c1 = (cs < fl_ ? fl_ : cs) + un1;
-                        cs = gap >= 1u ? c1 : cs;
-                        const float c2 = cs + un2;
-                        cs = gap >= 2u ? c2 : cs;
-                        const float c3 = cs + un3;
-                        cs = gap >= 3u ? c3 : cs;
-                        rp.cur += min(gap, 3u);
-                        rare = gap > 3u;
-                        un1 = vu[rp.cur + 1u]; un2 = vu[rp.cur + 2u]; un3 = vu[rp.cur + 3u];
-                    }
-                    const float sf = cs < fl_ ? fl_ : cs;                              // GPU:500-501
-                    const float m = fabsf(h - ce) * __builtin_amdgcn_rsqf(sf);         // GPU:502, see fuse_step
-                    const float D = sf + v;                                            // GPU:518, 519
-                    v2f N; N.x = sf * h + v * ce; N.y = v * sf;
-                    rare = (rare | (fabsf(m - thr) <= band) | !(fabsf(N.x) >= 8.673617379884035e-19f)) & live;   // 2^-60
-                    // both quotients from one refined reciprocal (fuse_step<true>), as a pair
-                    const float r0 = __builtin_amdgcn_rcpf(D);
-                    const float rr = __builtin_fmaf(__builtin_fmaf(-D, r0, 1.0f), r0, r0);
-                    const v2f rr2 = {rr, rr}, nD2 = {-D, -D};
-                    v2f q = N * rr2;
-                    v2f t = __builtin_elementwise_fma(nD2, q, N);
-                    q = __builtin_elementwise_fma(t, rr2, q);
-                    t = __builtin_elementwise_fma(nD2, q, N);
-                    q = __builtin_elementwise_fma(t, rr2, q);
-                    const bool outlier = m > thr;
-                    const bool replace = (ce == kEmptyElevation) | (outlier & (ce < h));   // GPU:484-486, 505-507
-                    float e2 = replace ? h : (outlier ? ce : q.x);
-                    float s2 = replace ? v : (outlier ? sf : q.y);
-                    if (__builtin_expect(__ballot(rare) != 0, 0)) {                    // wave-uniform: the step as the guarded loop takes it
-                        if (dbg && tid == 0) ++acc_rare;
-                        if constexpr (HAS_VU) {
-                            while (__ballot(rp.cur < sw) != 0) { if (rp.cur < sw) rp.one(cs, vu[rp.cur + 1u], fl_); }
-                            un1 = vu[rp.cur + 1u]; un2 = vu[rp.cur + 2u]; un3 = vu[rp.cur + 3u];
-                        }
-                        e2 = ce; s2 = cs;
-                        fuse_step<true>(e2, s2, h, v, thr, fl_);
-                    }
-                    ce = live ? e2 : ce; cs = live ? s2 : cs;
+                    plain_step(r, swr, i < cn);
                 }
             }
         } else {
@@ -1410,7 +1499,9 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         }
         lap(acc_walk);
         acc_nmax += nmax; ++n_batches;
-        // (the next round's ranking touches the cursors and masks only; its stores into the stage come after two barriers)
+        // (the next round's ranking touches the cursors and masks only; its stores into the stage come after two barriers -- unless
+        //  it is a light round, which writes the stage and the counts at once)
+        if constexpr (FAST_LIGHT) { if (a.light_fast) { ccnt[tid] = 0u; __syncthreads(); } }
     }
     if (dbg && tid == 0) {
         dbg[2] = acc_rank; dbg[3] = acc_base; dbg[4] = acc_place; dbg[5] = acc_walk; dbg[6] = __builtin_readcyclecounter();
