@@ -441,8 +441,7 @@ def node_host_arrays(emap_cls, dev, reps: int = 40):
     """The path the UNMODIFIED node drives, with its caller-owned host arrays (never `value`): per frame Mapvar_update, Process_points
     (3 arrays up, 5 down: gpu_process.cu:1096-1141), Fuse (7 arrays up: :1165-1192), Map_feature (nine L x L layers down: :1283-1291)
     and Raytracing, through the C ABI entry points the nine-symbol adapter calls (include/gem/gem_compat_eigen.hpp), arrays
-    allocated once like the node's.  PCIe and the runtime's handling of pageable memory set this rate; the arrays are pinned for
-    the duration of each call (gem_capi.cpp, HostPins)."""
+    allocated once like the node's.  PCIe and the runtime's staging of pageable memory set this rate."""
     import ctypes as C
     from gem_amd import synth, _lib
     wl = synth.config_c2(reference_filter=True)

@@ -115,8 +115,6 @@ struct gem_handle {
     bool lane_sort = true;              // k_fuse_block: cells to threads by record count (debug knob)
     int  walk_lds_pad = 0;              // k_fuse_block: extra dynamic LDS per workgroup (debug knob: fewer workgroups per CU)
     int  walk_prio = 4096;              // k_fuse_block: blocks of at least this many records run at raised issue priority (debug knob, 0 = off)
-    bool pin_host = true;               // caller-owned host arrays of at least pin_host_min_bytes are pinned for the call (HostPins; debug knob)
-    size_t pin_host_min_bytes = 256 * 1024;
     bool light_fast = true;             // k_fuse_block's light rounds by arrival slots + sorting network (debug knob)
     bool cache_tables = true;           // batched calls: skip building / uploading tables equal to the ones the buffer set already holds (debug knob)
     std::vector<unsigned char> key_scratch;
@@ -321,26 +319,10 @@ struct Timed {
     ~Timed() { if (on) h->events.push_back(ep); }
 };
 
-// Caller-owned PAGEABLE host arrays (the reference's interface hands over stack arrays, valid for the call only): a copy from or
-// to pageable memory is staged by the runtime through its own pinned buffers with CPU copies in between -- 0.5 MB arrays move at a
-// few GB/s, and the nine 1.44 MB layers of Map_feature take over a millisecond.  Pinned for the duration of the call instead
-// (hipHostRegister ... hipHostUnregister, never cached: the caller's memory may be a thread's stack that is gone after the call),
-// the same copies are plain DMA.  Small arrays are not worth the two system calls.
-struct HostPins {
-    gem_handle* h;
-    std::vector<void*> pinned;
-    explicit HostPins(gem_handle* hh) : h(hh) {}
-    void pin(const void* p, size_t bytes)
-    {
-        if (!p || !h->pin_host || bytes < h->pin_host_min_bytes) return;
-        // whole pages: two arrays of one call may share a page, which can be registered only once
-        const uintptr_t page = 4096, a = reinterpret_cast<uintptr_t>(p) & ~(page - 1), b = (reinterpret_cast<uintptr_t>(p) + bytes + page - 1) & ~(page - 1);
-        if (hipHostRegister(reinterpret_cast<void*>(a), b - a, hipHostRegisterDefault) == hipSuccess) pinned.push_back(reinterpret_cast<void*>(a));
-        else (void)hipGetLastError();                                   // (already registered by the caller, overlapping an earlier array, ...: the copy is staged as before)
-    }
-    ~HostPins() { for (void* p : pinned) if (hipHostUnregister(p) != hipSuccess) (void)hipGetLastError(); }
-};
-
+// (Pinning caller-owned pageable arrays for the duration of a call -- hipHostRegister ... hipHostUnregister around the copies --
+//  was built and measured in round 4: Process_points 345 -> 235 us.  It is NOT in the product: the randomised soak died with GPU
+//  memory faults on host heap addresses a few hundred scenarios in, every time, and ran clean for 4600 scenarios without it.
+//  Registrations of heap memory that is freed and reused between calls are not something this runtime tolerates.)
 void fold_events(gem_handle* h)
 {
     for (auto& ep : h->events) {
@@ -426,7 +408,9 @@ struct PassInput {
     const int* f_R = nullptr; const int* f_G = nullptr; const int* f_B = nullptr; const float* f_I = nullptr;
 };
 
-constexpr unsigned  kDeviceEventFlags = hipEventDisableTiming | hipEventDisableSystemFence;
+// (hipEventDisableSystemFence on these events was measured -- no gain on C4 / C5 -- and is NOT used: the multi-XCD part needs the
+//  release / acquire a recorded event stands for, for one stream's kernels to see another stream's writes)
+constexpr unsigned  kDeviceEventFlags = hipEventDisableTiming;
 constexpr int       kUnit = 64;                      // points per unit (one wave of k_bin_wave)
 constexpr long long kSweepPoints = 2048ll * kUnit;   // a single cloud longer than this is processed as a batch of sweeps of this size
 
@@ -1128,8 +1112,6 @@ int gem_create(const gem_map_config* cfg, gem_handle** out)
     if ((e = hipEventCreateWithFlags(&h->switch_done, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     // (the handle's four streams come from the process-wide pool as a set, see acquire_streams: ROCm maps streams onto a few
     //  hardware queues, and streams that share one serialise)
-    // (the events between the handle's own streams order device work on device memory only: no system-scope fence -- the cache
-    //  write-back and invalidation it stands for sat between consecutive walks, debug knob "event_fence")
     for (auto& b : h->pb) {
         if ((e = hipEventCreateWithFlags(&b.bin_done, kDeviceEventFlags)) != hipSuccess) return bail("hipEventCreate", e);
         if ((e = hipEventCreateWithFlags(&b.fuse_done, kDeviceEventFlags)) != hipSuccess) return bail("hipEventCreate", e);
@@ -1315,9 +1297,6 @@ int gem_process_points(gem_handle* h, const gem_frame_params* p, int n, float* x
     int* didx = reinterpret_cast<int*>(d + 4 * S);     float* dvar = reinterpret_cast<float*>(d + 5 * S);
     float* dxt = reinterpret_cast<float*>(d + 6 * S);  float* dyt = reinterpret_cast<float*>(d + 7 * S);
     float* dzt = reinterpret_cast<float*>(d + 8 * S);
-    HostPins pins(h);
-    for (const void* a : {(const void*)x, (const void*)y, (const void*)z, (const void*)orig_index, (const void*)map_index, (const void*)var,
-                          (const void*)x_ts, (const void*)y_ts, (const void*)z_ts}) pins.pin(a, S);
     GEM_HIP(h, hipMemcpyAsync(dx, x, S, hipMemcpyHostToDevice, h->stream));
     GEM_HIP(h, hipMemcpyAsync(dy, y, S, hipMemcpyHostToDevice, h->stream));
     GEM_HIP(h, hipMemcpyAsync(dz, z, S, hipMemcpyHostToDevice, h->stream));
@@ -1352,9 +1331,6 @@ int gem_fuse(gem_handle* h, int n, const int* index, const int* R, const int* G,
         int rc;
         if ((rc = ensure(h, h->stage, S * 7))) return rc;
         unsigned char* d = static_cast<unsigned char*>(h->stage.p);
-        HostPins pins(h);
-        for (const void* a : {(const void*)index, (const void*)height, (const void*)var}) pins.pin(a, S);
-        if (attr) for (const void* a : {(const void*)R, (const void*)G, (const void*)B, (const void*)intensity}) pins.pin(a, S);
         GEM_HIP(h, hipMemcpyAsync(d, index, S, hipMemcpyHostToDevice, h->stream));
         GEM_HIP(h, hipMemcpyAsync(d + S, height, S, hipMemcpyHostToDevice, h->stream));
         GEM_HIP(h, hipMemcpyAsync(d + 2 * S, var, S, hipMemcpyHostToDevice, h->stream));
@@ -1398,8 +1374,6 @@ int gem_add(gem_handle* h, const gem_frame_params* p, int n, const float* xyzi, 
         int rc;
         if ((rc = ensure(h, h->stage, S * 6))) return rc;
         unsigned char* d = static_cast<unsigned char*>(h->stage.p);
-        HostPins pins(h);
-        pins.pin(xyzi, S * 4); pins.pin(rgb, S); pins.pin(orig_index, S);
         GEM_HIP(h, hipMemcpyAsync(d, xyzi, S * 4, hipMemcpyHostToDevice, h->stream));
         in.xyzi = reinterpret_cast<const float4*>(d);
         if (rgb) { GEM_HIP(h, hipMemcpyAsync(d + 4 * S, rgb, S, hipMemcpyHostToDevice, h->stream)); in.rgb = reinterpret_cast<const uint32_t*>(d + 4 * S); }
@@ -1622,8 +1596,6 @@ int gem_get_layer(gem_handle* h, int layer, int layout, void* dst_host)
     int rc = flush_pending(h, false);
     if (rc) return rc;
     const size_t bytes = (size_t)h->cells * 4;
-    HostPins pins(h);
-    pins.pin(dst_host, bytes);
     if (layout == GEM_LAYOUT_STORAGE_ROWMAJOR) {
         GEM_HIP(h, hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, h->stream));
     } else if (layout == GEM_LAYOUT_GRIDMAP_COLMAJOR_NAN) {
@@ -1723,8 +1695,6 @@ int gem_map_feature(gem_handle* h, float* elevation, float* variance, int* color
         {colorB, h->layers.colorB}, {rough, h->layers.rough}, {slope, h->layers.slope}, {traver, h->layers.traver},
         {intensity, h->layers.intensity}};
     bool any = false;
-    HostPins pins(h);
-    for (auto& o : out) pins.pin(o.dst, bytes);
     for (auto& o : out) if (o.dst) { GEM_HIP(h, hipMemcpyAsync(o.dst, o.src, bytes, hipMemcpyDeviceToHost, h->stream)); any = true; }
     if (any) GEM_HIP(h, hipStreamSynchronize(h->stream));
     return GEM_OK;
@@ -1969,18 +1939,6 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "plain_loop")         h->plain_loop = value != 0;
     else if (k == "cache_tables")       h->cache_tables = value != 0;
     else if (k == "light_fast")         h->light_fast = value != 0;
-    else if (k == "pin_host")           h->pin_host = value != 0;
-    else if (k == "pin_host_min_bytes") { if (value < 0) return fail(h, GEM_ERR_INVALID, "pin_host_min_bytes: >= 0"); h->pin_host_min_bytes = (size_t)value; }
-    else if (k == "event_fence") {                                     // 1: the per-buffer-set events with the default system-scope fence (A/B)
-        for (hipStream_t st : {h->own_stream, h->bin_stream, h->bin_stream2, h->tab_stream}) if (st) hipStreamSynchronize(st);
-        for (auto& b : h->pb) {
-            for (hipEvent_t* ev : {&b.bin_done, &b.fuse_done}) {
-                if (*ev) hipEventDestroy(*ev);
-                GEM_HIP(h, hipEventCreateWithFlags(ev, value ? (unsigned)hipEventDisableTiming : kDeviceEventFlags));
-            }
-            b.fuse_recorded = false;
-        }
-    }
     else if (k == "walk_lds_pad")       { if (value < 0 || value > 100 * 1024) return fail(h, GEM_ERR_INVALID, "walk_lds_pad: 0 .. 102400 bytes"); h->walk_lds_pad = (int)value; }
     else if (k == "walk_prio")          { if (value < 0 || value > (1 << 30)) return fail(h, GEM_ERR_INVALID, "walk_prio: 0 (off) or a record count"); h->walk_prio = (int)value; }
     else if (k == "blk_batch")          { if (value != 0 && value != 512 && value != 2048) return fail(h, GEM_ERR_INVALID, "blk_batch: 0 (by pass), 512 or 2048"); h->blk_batch = (int)value; }
