@@ -233,6 +233,55 @@ def test_fuse_arrays_parity(oracle_mod):
     assert_maps_match(gpu, ref)
 
 
+@pytest.mark.parametrize("what", ["variances", "heights", "state", "increments", "cancellation"])
+def test_values_outside_the_plain_range_take_the_guarded_chain_loops(oracle_mod, what):
+    """The walks' plain chain loops (gem_sort.hip) drop the per-step guards when every record has |h| <= 2^28, 2^-28 <= v <= 2^28,
+    every cell starts in range and the increments are in [0, 2^18]; anything else -- tiny, huge, zero, negative, infinite or NaN
+    variances, huge or non-finite heights, a map that already holds such values, odd increments -- must be routed to the guarded
+    loops, per block (k_fuse_block) or per pass (k_fuse_walk), and still equal the oracle bit for bit.  `cancellation`: in-range
+    records whose Kalman numerator sf h + v e cancels to (almost) zero -- the one thing the plain step itself looks at."""
+    import torch
+    L = 96
+    rng = np.random.default_rng({"variances": 1, "heights": 2, "state": 3, "increments": 4, "cancellation": 5}[what])
+    n = 60000
+    idx = rng.integers(0, L * L, n).astype(np.int32)
+    idx[: n // 2] = rng.integers(0, 400, n // 2)                           # long chains in a few blocks, short ones elsewhere
+    h = rng.normal(0, 0.2, n).astype(F32)
+    v = rng.uniform(3e-4, 2e-3, n).astype(F32)
+    incs = [1e-5, 2e-5]
+    weird = rng.integers(0, n, 300)
+    if what == "variances":
+        v[weird] = rng.choice(np.array([0.0, -1e-3, 1e-40, 1e-38, 1e-30, 1e-12, 3e8, 1e30, np.inf, np.nan, 3.7e-9, 2.7e8], F32), weird.size)
+    elif what == "heights":
+        h[weird] = rng.choice(np.array([3e8, -3e8, 1e30, -1e30, np.inf, -np.inf, np.nan, 2.6e8, 1e-40, -0.0], F32), weird.size)
+    elif what == "increments":
+        incs = [-1e-5, 3e5]
+    elif what == "cancellation":
+        h[:] = 0.0; h[rng.integers(0, n, n // 3)] = -0.0                  # e and h both zero: N1 = +-0
+    maps = {"hip": ElevationMap(L, 0.1), "oracle": oracle_mod.OracleMap(L, 0.1)}
+    if what == "state":
+        e0 = np.full((L, L), -10.0, F32); s0 = np.full((L, L), -10.0, F32)
+        cells = rng.integers(0, L * L, 500)
+        e0.ravel()[cells] = rng.choice(np.array([5e8, -1e20, np.inf, np.nan, 1.0, -0.0], F32), cells.size)
+        s0.ravel()[cells] = rng.choice(np.array([5e8, 1e25, np.inf, np.nan, 1e-42, 0.0, -3.0], F32), cells.size)
+        for m in maps.values():
+            m.set_layer("elevation", e0); m.set_layer("variance", s0)
+    for rep in range(2):
+        for k, inc in enumerate(incs):
+            part = slice(k * n // 2, (k + 1) * n // 2)
+            for m in maps.values():
+                m.mapvar_update(inc)
+                m.fuse(idx[part], h[part], v[part])
+        g_e, o_e = maps["hip"].layer("elevation"), maps["oracle"].layer("elevation")
+        g_s, o_s = maps["hip"].layer("variance"), maps["oracle"].layer("variance")
+        for name, g, o in (("elevation", g_e, o_e), ("variance", g_s, o_s)):   # NaNs must match as NaNs, -0.0 as -0.0, everything else bit for bit
+            assert np.array_equal(np.isnan(g), np.isnan(o)), (what, rep, name, "NaN pattern")
+            ok = ~np.isnan(o)
+            bad = np.flatnonzero(g[ok].view(np.uint32) != o[ok].view(np.uint32))
+            assert bad.size == 0, (what, rep, name, bad.size, g[ok][bad[:5]], o[ok][bad[:5]])
+    maps["hip"].close()
+
+
 @pytest.mark.parametrize("thr", [5.0, 2.5, 0.75])
 def test_mahalanobis_decision_at_the_threshold(oracle_mod, thr):
     """GPU:502-504: m = |h - e| / sqrt(s) > threshold.  The device takes the decision from a fast estimate and
