@@ -556,7 +556,7 @@ def run_c5_distributed(args, torch, dist, world, rank, local_rank, dev):
     if world > 1:
         for key in ("exchange", "exchange_to_walk", "walk", "publish", "gather"):
             ns = emap.debug_get(f"step_{key}_ns")
-            phases[key] = None if ns < 0 else ns / 1e3
+            phases[key] = None if ns <= -(1 << 60) else ns / 1e3
     emap.set_timing(False)
     us_step = 1e6 * elapsed / args.steps
     us_step_nogather = 1e6 * elapsed_nogather / args.steps

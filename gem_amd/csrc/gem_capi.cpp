@@ -1971,7 +1971,9 @@ int gem_debug_get(gem_handle* h, const char* key, long long* out)
         else return fail(h, GEM_ERR_INVALID, "gem_debug_get: unknown key");
         hipSetDevice(h->device);
         float ms = 0.f;
-        if (!h->ev_t[a] || hipEventElapsedTime(&ms, h->ev_t[a], h->ev_t[b]) != hipSuccess) { (void)hipGetLastError(); *out = -1; return GEM_OK; }
+        // (not recorded: a value no pair of time stamps gives; two stamps taken on different hardware queues may come out a few
+        //  microseconds apart the wrong way round)
+        if (!h->ev_t[a] || hipEventElapsedTime(&ms, h->ev_t[a], h->ev_t[b]) != hipSuccess) { (void)hipGetLastError(); *out = -(1ll << 62); return GEM_OK; }
         *out = (long long)((double)ms * 1e6);
     }
     else return fail(h, GEM_ERR_INVALID, "gem_debug_get: unknown key");

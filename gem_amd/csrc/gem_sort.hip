@@ -980,7 +980,10 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
     // equal cells by BALLOT, one per bit of the cell number -- 24 scalar / vector instructions per step instead of three LDS round
     // trips -- and keep no mask table: 18 KB of LDS per workgroup instead of 28, eight workgroups per CU instead of five (C5's walk alone
     // 114 -> 111 us, 153 -> 133 beside the sort chains; the call's period did not move: it is the sum of the kernels' work).
-    constexpr bool BALLOT = B <= 512;
+#ifndef GEM_BALLOT_MAX
+#define GEM_BALLOT_MAX 512
+#endif
+    constexpr bool BALLOT = B <= GEM_BALLOT_MAX;
     unsigned long long* wpm = reinterpret_cast<unsigned long long*>(st_hv + B);         // [NW][320] who shares my cell in this wave instruction (!BALLOT)
     uint32_t* wcur = reinterpret_cast<uint32_t*>(wpm + (BALLOT ? 0 : NW * 320));        // [NW][320] records of (wave, cell) so far
     uint32_t* cbase = wcur + NW * 320;                                                  // [NW][256] where the run of (wave, cell) starts in the batch

@@ -33,7 +33,7 @@ int gem_debug_set(gem_handle* h, const char* key, long long value);
  *            "sort_fallbacks" (passes whose forced sorted form / pass count did not fit the map and took the other form),
  *            "step_pending" (1: the second half of a gem_add_sharded_device step is still to come),
  *            "step_exchange_ns", "step_walk_ns", "step_publish_ns", "step_gather_ns", "step_exchange_to_walk_ns": device time stamps of
- *            the last finished multi-rank step (recorded while gem_set_timing is on; read after gem_synchronize; -1 = not recorded) */
+ *            the last finished multi-rank step (recorded while gem_set_timing is on; read after gem_synchronize; -2^62 = not recorded) */
 int gem_debug_get(gem_handle* h, const char* key, long long* out);
 
 /* LOOPBACK communicator: nranks handles of THIS process, on ONE device, join the world `world_id` (any number the caller picks,

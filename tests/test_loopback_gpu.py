@@ -182,6 +182,38 @@ def test_steps_interleaved_with_whole_map_operations(oracle_mod):
         tm.map.close()
 
 
+def test_step_phase_time_stamps(oracle_mod):
+    """bench.py --gpus N reads the device time of every phase of a multi-rank step from events on the streams the phases run on
+    (gem_debug_get "step_*_ns", recorded while gem_set_timing is on): all five must be there after a synchronisation."""
+    import torch
+    world, L, res = 2, 160, 0.1
+    _, _, frames, clouds, off, upd = small_batch(L=L, res=res, per=8000)
+    cat = torch.from_numpy(np.concatenate(clouds)).cuda()
+    maps = make_world(world, L, res, debug={"overlap_min_points": 1})
+    got = [None] * world
+
+    def rank(r):
+        tm = maps[r]
+        tm.map.set_timing(True)
+        for _ in range(3):
+            tm.add_sharded(frames, cat, off, upd)
+            tm.allgather()
+        tm.map.synchronize()
+        st = tm.map.stats()
+        got[r] = {k: tm.map.debug_get(f"step_{k}_ns") for k in ("exchange", "exchange_to_walk", "walk", "publish", "gather")}
+        got[r]["launches_walk"] = st["launches_walk"]
+        tm.map.set_timing(False)
+    run_ranks(world, rank)
+    for r in range(world):
+        assert got[r]["launches_walk"] == 3, got[r]
+        for k in ("exchange", "walk", "gather"):
+            assert got[r][k] > 0, (r, k, got[r])
+        for k in ("exchange_to_walk", "publish"):                          # (hand-overs between two hardware queues: recorded; a few us of skew either way)
+            assert got[r][k] > -1_000_000, (r, k, got[r])
+    for tm in maps:
+        tm.map.close()
+
+
 @pytest.mark.parametrize("world,L,res", [(3, 75, 0.2), (2, 96, 0.1)])
 def test_stage_a_row_strips_through_the_loopback(oracle_mod, world, L, res):
     """Stage A (every rank bins the whole cloud and fuses its row strip; uneven strips for L = 75) + the all-gather with attributes."""
