@@ -26,7 +26,12 @@
 //     bigger ones (k_sort_project then also counts every block's records, k_block_prefix turns the counts into the blocks' ranges);
 //     k_fuse_block  one workgroup per block: the block's records, in input order, a round of 2048 (512 for light blocks) at a time:
 //                   ordered by cell in LDS (stable), then every thread runs its cell's records of the round from LDS; the cell
-//                   state stays in registers.
+//                   state stays in registers.  Light rounds: arrival slots per cell + a sorting network instead of rank / scan /
+//                   placement.
+//
+// Both walks run the per-cell recurrence in a PLAIN chain loop whenever the values allow it (every record and cell state within
+// 2^-28 .. 2^28, checked outside the chain: per block where the records are placed, per pass by k_sort_project): one rarely taken
+// branch per step instead of the guards of fuse_step<true> and of the increments' replay; anything else takes the guarded loops.
 //
 // Stability of every pass keeps ascending input order inside every cell; no float atomics.  A wave takes the time of its LONGEST
 // cell chain.  Algorithmic bytes: 16 B per point (read) + 16 B per distinct touched cell (+ 8 L^2 per dense variance pass).  What

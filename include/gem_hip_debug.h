@@ -25,6 +25,11 @@ extern "C" {
  *       LDS way; < 0: one ballot per digit bit), "ray_lanes" (1, 4, 8, 16: lanes of a wave that share one walk of gem_raytracing) and
  *       "ray_depth" (4, 8: steps a lane walks ahead of the loads it waits for), "walk_permute" (0/1),
  *       "sort_streams" (1, 2: binning streams consecutive overlapped passes of the sorted pipeline alternate between), "sort_ring" (2..4: the buffer sets they rotate through),
+ *       "plain_loop" (0/1: the walks' plain chain loop for blocks / passes whose values are in range; 0 = the guarded loop everywhere),
+ *       "light_fast" (0/1: k_fuse_block's rounds of 512 by arrival slots + a per-cell sorting network; 0 = the general rounds),
+ *       "cache_tables" (0/1: a batched call whose frames / offsets / increments / map pose equal what a buffer set's device tables were
+ *       built from skips building and uploading them), "walk_prio" (0 = off; blocks of at least that many records raise their waves'
+ *       issue priority), "walk_lds_pad" (bytes of unused LDS per k_fuse_block workgroup: fewer workgroups per CU; an experiment's knob),
  *       "trace" (0/1: one line on stderr per pass of the sorted pipeline), "stream_roles" (a permutation of 0123 as a decimal
  *       number: which of the handle's current own / bin / bin2 / upload streams takes each role; tools/dbg/roles.py).  Returns GEM_ERR_INVALID for an unknown key or a value out of range. */
 int gem_debug_set(gem_handle* h, const char* key, long long value);
