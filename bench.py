@@ -437,7 +437,7 @@ def c2_variants(emap_cls, dev, torch, reps: int = 400):
     return out
 
 
-def node_host_arrays(emap_cls, dev, reps: int = 40):
+def node_host_arrays(emap_cls, dev, reps: int = 40, copy_threads=None):
     """The path the UNMODIFIED node drives, with its caller-owned host arrays (never `value`): per frame Mapvar_update, Process_points
     (3 arrays up, 5 down: gpu_process.cu:1096-1141), Fuse (7 arrays up: :1165-1192), Map_feature (nine L x L layers down: :1283-1291)
     and Raytracing, through the C ABI entry points the nine-symbol adapter calls (include/gem/gem_compat_eigen.hpp), arrays
@@ -452,6 +452,9 @@ def node_host_arrays(emap_cls, dev, reps: int = 40):
     layers_f = [np.empty(L * L, np.float32) for _ in range(6)]; layers_i = [np.empty(L * L, np.int32) for _ in range(3)]
     m = emap_cls(L, wl.resolution, device=dev.index)
     m.set_lowest_tracking(True)
+    if copy_threads is not None:
+        m.debug_set("copy_threads", int(copy_threads))
+    m.reserve(n, 1, True)                               # (the node's maximum cloud: every arena and the pinned staging sized up front)
     lib, h, P = m._lib, m._h, f.to_struct()
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
     t = {"mapvar_update": [], "process_points": [], "fuse": [], "map_feature": [], "raytracing": []}
@@ -467,12 +470,14 @@ def node_host_arrays(emap_cls, dev, reps: int = 40):
         if r >= 4:
             for k, v in zip(t, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
                 t[k].append(v * 1e6)
+    m_threads = m.debug_get("copy_threads")
+    xfer = {k: m.debug_get(f"xfer_{k}_ns") / (reps + 4) / 1e3 for k in ("upload_memcpy", "upload_enqueue", "download_enqueue", "download_wait", "download_memcpy")}
     m.synchronize(); m.close()
     us = {k: float(np.median(v)) for k, v in t.items()}
     total = sum(us.values())
     return {"workload": "the node's frame with caller-owned HOST arrays: Mapvar_update + Process_points + Fuse (colours) + Map_feature (nine layers to the host) + "
                         "Raytracing, C2 sweep with the reference's reject filter, 600 x 600 map",
-            "us_per_frame": total, "us_per_call": us, "bytes_over_pcie_per_frame": 12.0 * n + 20.0 * n + 28.0 * n + 36.0 * L * L,
+            "copy_threads": m_threads, "us_per_frame": total, "us_per_call": us, "host_us_per_frame_in_transfers": xfer, "bytes_over_pcie_per_frame": 12.0 * n + 20.0 * n + 28.0 * n + 36.0 * L * L,
             "value": n / (total * 1e-6), "unit": "points/s"}
 
 

@@ -17,7 +17,7 @@ LIBDIR = ROOT / "lib"
 LIB = LIBDIR / "libgem_hip.so"
 
 SOURCES = [CSRC / "gem_kernels.hip", CSRC / "gem_sort.hip", CSRC / "gem_capi.cpp"]
-HEADERS = [CSRC / "gem_device.hpp", CSRC / "gem_kernels.hpp", CSRC / "gem_wave.hpp", CSRC / "gem_transport.hpp", ROOT.parent / "include" / "gem_hip_debug.h", ROOT.parent / "include" / "gem_hip.h"]
+HEADERS = [CSRC / "gem_device.hpp", CSRC / "gem_kernels.hpp", CSRC / "gem_wave.hpp", CSRC / "gem_transport.hpp", CSRC / "gem_hostcopy.hpp", ROOT.parent / "include" / "gem_hip_debug.h", ROOT.parent / "include" / "gem_hip.h"]
 
 # -ffp-contract=off: cell indices must be bit-exact with the reference arithmetic, so no product+sum
 # may be contracted into an FMA (see csrc/gem_device.hpp).  hipcc's default IEEE divide/sqrt stay on.
@@ -80,7 +80,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         raise RuntimeError("\n".join(errors))
     tag.write_text(flag_line)
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", *[str(objdir / (s.stem + ".o")) for s in SOURCES], "-o", str(LIB),
-           f"-L{rocm}/lib", "-lrccl", f"-Wl,-rpath,{rocm}/lib"]
+           f"-L{rocm}/lib", "-lrccl", "-pthread", f"-Wl,-rpath,{rocm}/lib"]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)

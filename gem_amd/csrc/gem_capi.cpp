@@ -8,11 +8,13 @@
 #include "../../include/gem_hip.h"
 #include "../../include/gem_hip_debug.h"
 #include "gem_kernels.hpp"
+#include "gem_hostcopy.hpp"
 #include "gem_transport.hpp"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -136,6 +138,20 @@ struct gem_handle {
     gem_stats stats{};
     hipEvent_t copy_done = nullptr;
 
+    // ---- caller-owned pageable arrays (gem_hostcopy.hpp): the handle's pinned staging buffer, the DMA between it and the device,
+    //      a few threads between it and the caller's arrays.  copy_threads 0 = the runtime's own pageable path.
+    static constexpr int kStageEvents = 24;
+    void*  hstage = nullptr;            // hipHostMalloc'ed
+    size_t hstage_cap = 0;
+    bool   hstage_failed = false;       // an allocation failed: not tried again
+    size_t hstage_max = 256u << 20;     // larger transfers go through the runtime
+    int    copy_threads = 4;            // the calling thread + 3 workers (gem_debug_set "copy_threads")
+    hipEvent_t ev_stage[kStageEvents] = {};      // host-visible: a segment's DMA into the staging buffer is done
+    hipEvent_t stage_read = nullptr;    // the last DMA OUT of the staging buffer is done (it may be written again)
+    bool   stage_read_pending = false;
+    long long hstage_allocations = 0;
+    long long xfer_ns[5] = {0, 0, 0, 0, 0};    // host time so far: upload memcpy, upload enqueue, download enqueue, download wait, download memcpy
+
     // ---- multi-GPU.  Two communicators, each with a stream of its own: `tp_x` carries a step's boundary
     //      all-gather and record exchange on `comm_stream`, `tp_g` the all-gather of the fused layers on `gather_stream` -- step
     //      p + 1's exchange does not queue behind step p's 46 MB of layers.  (RCCL over xGMI; W handles of one process on one
@@ -243,6 +259,143 @@ int ensure_zeroed(gem_handle* h, Arena& a, size_t bytes)
     if (rc) return rc;
     GEM_HIP(h, hipMemsetAsync(a.p, 0, a.cap, h->stream));
     GEM_HIP(h, hipStreamSynchronize(h->stream));
+    return GEM_OK;
+}
+
+// ---- caller-owned host arrays <-> device arenas ---------------------------------------------------------------------------------
+struct HostXfer { void* host; void* dev; size_t bytes; };
+
+static inline long long host_ns()
+{
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// the pinned staging buffer, at least `bytes` large -- or nullptr: switched off, too large, or the allocation failed (the callers
+// then hand the arrays to the runtime, which stages pageable memory itself: slower, never wrong)
+unsigned char* host_stage(gem_handle* h, size_t bytes)
+{
+    if (h->copy_threads <= 0 || h->hstage_failed || bytes > h->hstage_max) return nullptr;
+    if (bytes > h->hstage_cap) {
+        if (h->hstage) {
+            if (hipStreamSynchronize(h->stream) != hipSuccess) return nullptr;       // a DMA may still read it
+            h->stage_read_pending = false;
+            hipHostFree(h->hstage); h->hstage = nullptr; h->hstage_cap = 0;
+        }
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (hipHostMalloc(&h->hstage, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h->hstage = nullptr; h->hstage_failed = true; return nullptr; }
+        h->hstage_cap = want;
+        ++h->hstage_allocations;
+    }
+    for (auto& ev : h->ev_stage) if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ev = nullptr; return nullptr; }
+    if (!h->stage_read && hipEventCreateWithFlags(&h->stage_read, hipEventDisableTiming) != hipSuccess) { h->stage_read = nullptr; return nullptr; }
+    return static_cast<unsigned char*>(h->hstage);
+}
+
+// Host arrays -> device, on h->stream.  On return the caller's arrays have been READ (they may be stack arrays that die with the
+// call, EMg.cpp:260-267); the device copies are enqueued.  `stage_off`: where in the staging buffer this call's uploads begin.
+int upload_arrays(gem_handle* h, const HostXfer* x, int n)
+{
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += (x[i].bytes + 255) & ~(size_t)255;
+    unsigned char* stg = total >= (128u << 10) ? host_stage(h, total) : nullptr;
+    if (!stg) {
+        for (int i = 0; i < n; ++i) if (x[i].bytes) GEM_HIP(h, hipMemcpyAsync(x[i].dev, x[i].host, x[i].bytes, hipMemcpyHostToDevice, h->stream));
+        GEM_HIP(h, hipEventRecord(h->copy_done, h->stream));
+        GEM_HIP(h, hipEventSynchronize(h->copy_done));
+        return GEM_OK;
+    }
+    if (h->stage_read_pending) { GEM_HIP(h, hipEventSynchronize(h->stage_read)); h->stage_read_pending = false; }
+    // Arrays that follow each other on the device at the staging buffer's own 256-byte stride form one region, copied by DMA
+    // commands that ignore the array boundaries (a command costs ~9 us before its first byte: seven 0.5 MB arrays one by one run at
+    // 29 GB/s, as two commands at 43); the DMA of one group runs under the memcpy of the next.
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t off = 0;
+    for (int i = 0; i < n;) {
+        int e = i + 1;
+        size_t len = pad(x[i].bytes);
+        while (e < n && static_cast<unsigned char*>(x[e].dev) == static_cast<unsigned char*>(x[i].dev) + len) len += pad(x[e++].bytes);
+        const size_t group = pad(len <= (8u << 20) ? std::max<size_t>(len / 2, 512u << 10) : (4u << 20));
+        for (size_t a = 0; a < len; a += group) {
+            const size_t b = std::min(len, a + group);
+            gem::CopySeg segs[16]; int ns = 0;
+            size_t m_off = 0;
+            for (int m = i; m < e; ++m) {                                           // the members' parts inside [a, b)
+                const size_t lo = std::max(a, m_off), hi = std::min(b, m_off + x[m].bytes);
+                if (lo < hi && ns < 16) segs[ns++] = {stg + off + lo, static_cast<const unsigned char*>(x[m].host) + (lo - m_off), hi - lo};
+                m_off += pad(x[m].bytes);
+            }
+            const long long t0 = host_ns();
+            gem::CopyPool::get().run(segs, ns, h->copy_threads);
+            const long long t1 = host_ns();
+            GEM_HIP(h, hipMemcpyAsync(static_cast<unsigned char*>(x[i].dev) + a, stg + off + a, b - a, hipMemcpyHostToDevice, h->stream));
+            h->xfer_ns[0] += t1 - t0; h->xfer_ns[1] += host_ns() - t1;
+        }
+        off += len;
+        i = e;
+    }
+    // The pipeline reads the arena on its binning streams too, which are not ordered behind h->stream by anything but the host:
+    // the copies are waited for, as they were when the runtime staged the arrays.
+    GEM_HIP(h, hipEventRecord(h->stage_read, h->stream));
+    GEM_HIP(h, hipEventSynchronize(h->stage_read));
+    h->stage_read_pending = false;
+    return GEM_OK;
+}
+
+// Device -> host arrays, after everything enqueued on h->stream so far.  Returns when the caller's arrays hold the data (and
+// h->stream is idle).  `stage_off`: the staging bytes before it may still be read by this call's own uploads.
+int download_arrays(gem_handle* h, const HostXfer* x, int n, size_t stage_off)
+{
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += (x[i].bytes + 255) & ~(size_t)255;
+    stage_off = (stage_off + 255) & ~(size_t)255;
+    unsigned char* stg = total >= (128u << 10) ? host_stage(h, stage_off + total) : nullptr;
+    if (!stg) {
+        for (int i = 0; i < n; ++i) if (x[i].bytes) GEM_HIP(h, hipMemcpyAsync(x[i].host, x[i].dev, x[i].bytes, hipMemcpyDeviceToHost, h->stream));
+        GEM_HIP(h, hipStreamSynchronize(h->stream));
+        h->stage_read_pending = false;
+        return GEM_OK;
+    }
+    stg += stage_off;
+    const long long t_begin = host_ns();
+    // groups of pieces, a launch of k_copy_list + an event each: while the device writes group g + 1 into the staging buffer the
+    // copy threads move group g on to the caller's arrays.  At most kStageEvents groups of at most kCopyListMax pieces.
+    size_t group = std::max<size_t>(768u << 10, (total + 7) / 8);
+    group = (group + 255) & ~(size_t)255;
+    gem::CopySeg segs[gem_handle::kStageEvents][kCopyListMax];
+    int nseg[gem_handle::kStageEvents] = {};
+    int ng = 0;
+    {
+        CopyList cl; cl.n = 0;
+        size_t in_group = 0, off = 0;
+        auto flush = [&]() -> int {
+            if (!cl.n) return GEM_OK;
+            GEM_HIP(h, launch_copy_list(h->stream, cl));
+            GEM_HIP(h, hipEventRecord(h->ev_stage[ng], h->stream));
+            nseg[ng++] = cl.n; cl.n = 0; in_group = 0;
+            return GEM_OK;
+        };
+        for (int i = 0; i < n; ++i) {
+            for (size_t o = 0; o < x[i].bytes;) {
+                const size_t b = std::min(x[i].bytes - o, group - in_group);
+                cl.piece[cl.n] = {stg + off + o, static_cast<const unsigned char*>(x[i].dev) + o, b};
+                segs[ng][cl.n] = {static_cast<unsigned char*>(x[i].host) + o, stg + off + o, b};
+                ++cl.n; in_group += b; o += b;
+                if (in_group >= group || cl.n == kCopyListMax) { const int rcf = flush(); if (rcf) return rcf; }
+            }
+            off += (x[i].bytes + 255) & ~(size_t)255;
+        }
+        { const int rcf = flush(); if (rcf) return rcf; }
+    }
+    long long t0 = host_ns();
+    h->xfer_ns[2] += t0 - t_begin;
+    for (int g = 0; g < ng; ++g) {
+        GEM_HIP(h, hipEventSynchronize(h->ev_stage[g]));
+        const long long t1 = host_ns();
+        gem::CopyPool::get().run(segs[g], nseg[g], h->copy_threads);
+        const long long t2 = host_ns();
+        h->xfer_ns[3] += t1 - t0; h->xfer_ns[4] += t2 - t1; t0 = t2;
+    }
+    h->stage_read_pending = false;                      // the last group's event followed everything on the stream
     return GEM_OK;
 }
 
@@ -1178,6 +1331,9 @@ void gem_destroy(gem_handle* h)
         if (b.fuse_done) hipEventDestroy(b.fuse_done);
     }
     if (h->copy_done) hipEventDestroy(h->copy_done);
+    if (h->hstage) hipHostFree(h->hstage);
+    for (auto& ev : h->ev_stage) if (ev) hipEventDestroy(ev);
+    if (h->stage_read) hipEventDestroy(h->stage_read);
     if (h->switch_done) hipEventDestroy(h->switch_done);
     release_streams(h->device, h->streams);            // back to the pool, as a set
     delete h;
@@ -1290,6 +1446,59 @@ int gem_process_points(gem_handle* h, const gem_frame_params* p, int n, float* x
     if (n == 0) return GEM_OK;
     const size_t N = (size_t)n, S = N * 4;
     int rc;
+    FrameConst fc; fill_frame(h, p, fc);
+    // Nothing of this call stays on the device: with the pinned staging buffer the kernel reads the cloud from it and writes its
+    // five arrays into it, over the link, both directions at once (no device copy of either), in ranges of kRange points -- the
+    // copy threads fill range c + 1 and empty range c - 1 while the device works on range c.
+    constexpr int kRange = 65536;
+    const size_t SP = (S + 255) & ~(size_t)255;
+    unsigned char* stg = S >= (64u << 10) ? host_stage(h, SP * 9) : nullptr;
+    if (stg && (n + kRange - 1) / kRange <= gem_handle::kStageEvents) {
+        if (h->stage_read_pending) { GEM_HIP(h, hipEventSynchronize(h->stage_read)); h->stage_read_pending = false; }
+        float* sx = reinterpret_cast<float*>(stg);            float* sy = reinterpret_cast<float*>(stg + SP);
+        float* sz = reinterpret_cast<float*>(stg + 2 * SP);   int* sorig = reinterpret_cast<int*>(stg + 3 * SP);
+        int* sidx = reinterpret_cast<int*>(stg + 4 * SP);     float* svar = reinterpret_cast<float*>(stg + 5 * SP);
+        float* sxt = reinterpret_cast<float*>(stg + 6 * SP);  float* syt = reinterpret_cast<float*>(stg + 7 * SP);
+        float* szt = reinterpret_cast<float*>(stg + 8 * SP);
+        const int ranges = (n + kRange - 1) / kRange;
+        auto out_of = [&](int c) {
+            const int first = c * kRange, cnt = std::min(kRange, n - first);
+            const size_t b = (size_t)cnt * 4;
+            gem::CopySeg segs[8]; int ns = 0;
+            if (map_index) segs[ns++] = {map_index + first, sidx + first, b};
+            if (var)  segs[ns++] = {var + first, svar + first, b};
+            if (x_ts) segs[ns++] = {x_ts + first, sxt + first, b};
+            if (y_ts) segs[ns++] = {y_ts + first, syt + first, b};
+            if (z_ts) segs[ns++] = {z_ts + first, szt + first, b};
+            if (write_back_xyz) { segs[ns++] = {x + first, sx + first, b}; segs[ns++] = {y + first, sy + first, b}; segs[ns++] = {z + first, sz + first, b}; }
+            gem::CopyPool::get().run(segs, ns, h->copy_threads);
+        };
+        for (int c = 0; c < ranges; ++c) {
+            const int first = c * kRange, cnt = std::min(kRange, n - first);
+            const size_t b = (size_t)cnt * 4;
+            gem::CopySeg in[4] = {{sx + first, x + first, b}, {sy + first, y + first, b}, {sz + first, z + first, b}, {sorig + first, orig_index ? orig_index + first : nullptr, orig_index ? b : 0}};
+            long long t0 = host_ns();
+            gem::CopyPool::get().run(in, orig_index ? 4 : 3, h->copy_threads);
+            long long t1 = host_ns();
+            GEM_HIP(h, launch_project(h->stream, fc, first, cnt, sx + first, sy + first, sz + first, orig_index ? sorig + first : nullptr, write_back_xyz,
+                                      sidx + first, svar + first, sxt + first, syt + first, szt + first));
+            GEM_HIP(h, hipEventRecord(h->ev_stage[c], h->stream));
+            long long t2 = host_ns();
+            h->xfer_ns[0] += t1 - t0; h->xfer_ns[1] += t2 - t1;
+            if (c > 0) {
+                GEM_HIP(h, hipEventSynchronize(h->ev_stage[c - 1]));
+                t0 = host_ns();
+                out_of(c - 1);
+                h->xfer_ns[3] += t0 - t2; h->xfer_ns[4] += host_ns() - t0;
+            }
+        }
+        long long t0 = host_ns();
+        GEM_HIP(h, hipEventSynchronize(h->ev_stage[ranges - 1]));
+        long long t1 = host_ns();
+        out_of(ranges - 1);
+        h->xfer_ns[3] += t1 - t0; h->xfer_ns[4] += host_ns() - t1;
+        return GEM_OK;
+    }
     if ((rc = ensure(h, h->stage, S * 9))) return rc;
     unsigned char* d = static_cast<unsigned char*>(h->stage.p);
     float* dx = reinterpret_cast<float*>(d);           float* dy = reinterpret_cast<float*>(d + S);
@@ -1297,22 +1506,17 @@ int gem_process_points(gem_handle* h, const gem_frame_params* p, int n, float* x
     int* didx = reinterpret_cast<int*>(d + 4 * S);     float* dvar = reinterpret_cast<float*>(d + 5 * S);
     float* dxt = reinterpret_cast<float*>(d + 6 * S);  float* dyt = reinterpret_cast<float*>(d + 7 * S);
     float* dzt = reinterpret_cast<float*>(d + 8 * S);
-    GEM_HIP(h, hipMemcpyAsync(dx, x, S, hipMemcpyHostToDevice, h->stream));
-    GEM_HIP(h, hipMemcpyAsync(dy, y, S, hipMemcpyHostToDevice, h->stream));
-    GEM_HIP(h, hipMemcpyAsync(dz, z, S, hipMemcpyHostToDevice, h->stream));
-    if (orig_index) GEM_HIP(h, hipMemcpyAsync(dorig, orig_index, S, hipMemcpyHostToDevice, h->stream));
-    FrameConst fc; fill_frame(h, p, fc);
-    GEM_HIP(h, launch_project(h->stream, fc, n, dx, dy, dz, orig_index ? dorig : nullptr, write_back_xyz, didx, dvar, dxt, dyt, dzt));
-    if (map_index) GEM_HIP(h, hipMemcpyAsync(map_index, didx, S, hipMemcpyDeviceToHost, h->stream));
-    if (var)  GEM_HIP(h, hipMemcpyAsync(var, dvar, S, hipMemcpyDeviceToHost, h->stream));
-    if (x_ts) GEM_HIP(h, hipMemcpyAsync(x_ts, dxt, S, hipMemcpyDeviceToHost, h->stream));
-    if (y_ts) GEM_HIP(h, hipMemcpyAsync(y_ts, dyt, S, hipMemcpyDeviceToHost, h->stream));
-    if (z_ts) GEM_HIP(h, hipMemcpyAsync(z_ts, dzt, S, hipMemcpyDeviceToHost, h->stream));
-    if (write_back_xyz) {
-        GEM_HIP(h, hipMemcpyAsync(x, dx, S, hipMemcpyDeviceToHost, h->stream));
-        GEM_HIP(h, hipMemcpyAsync(y, dy, S, hipMemcpyDeviceToHost, h->stream));
-        GEM_HIP(h, hipMemcpyAsync(z, dz, S, hipMemcpyDeviceToHost, h->stream));
-    }
+    HostXfer up[4] = {{x, dx, S}, {y, dy, S}, {z, dz, S}, {const_cast<int*>(orig_index), dorig, S}};
+    HostXfer down[8]; int nd = 0;
+    if (map_index) down[nd++] = {map_index, didx, S};
+    if (var)  down[nd++] = {var, dvar, S};
+    if (x_ts) down[nd++] = {x_ts, dxt, S};
+    if (y_ts) down[nd++] = {y_ts, dyt, S};
+    if (z_ts) down[nd++] = {z_ts, dzt, S};
+    if (write_back_xyz) { down[nd++] = {x, dx, S}; down[nd++] = {y, dy, S}; down[nd++] = {z, dz, S}; }
+    if ((rc = upload_arrays(h, up, orig_index ? 4 : 3))) return rc;
+    GEM_HIP(h, launch_project(h->stream, fc, 0, n, dx, dy, dz, orig_index ? dorig : nullptr, write_back_xyz, didx, dvar, dxt, dyt, dzt));
+    if (nd) return download_arrays(h, down, nd, SP * 4);
     GEM_HIP(h, hipStreamSynchronize(h->stream));
     return GEM_OK;
 }
@@ -1329,24 +1533,20 @@ int gem_fuse(gem_handle* h, int n, const int* index, const int* R, const int* G,
     PassInput in; in.src = 1; in.n = n;
     if (n > 0) {
         int rc;
-        if ((rc = ensure(h, h->stage, S * 7))) return rc;
+        const size_t P = (S + 255) & ~(size_t)255;                  // the arrays' stride on the device = in the staging buffer (upload_arrays)
+        if ((rc = ensure(h, h->stage, P * 7))) return rc;
         unsigned char* d = static_cast<unsigned char*>(h->stage.p);
-        GEM_HIP(h, hipMemcpyAsync(d, index, S, hipMemcpyHostToDevice, h->stream));
-        GEM_HIP(h, hipMemcpyAsync(d + S, height, S, hipMemcpyHostToDevice, h->stream));
-        GEM_HIP(h, hipMemcpyAsync(d + 2 * S, var, S, hipMemcpyHostToDevice, h->stream));
-        in.f_index = reinterpret_cast<const int*>(d); in.f_height = reinterpret_cast<const float*>(d + S);
-        in.f_var = reinterpret_cast<const float*>(d + 2 * S);
+        HostXfer up[7] = {{const_cast<int*>(index), d, S}, {const_cast<float*>(height), d + P, S}, {const_cast<float*>(var), d + 2 * P, S},
+                          {const_cast<int*>(R), d + 3 * P, S}, {const_cast<int*>(G), d + 4 * P, S}, {const_cast<int*>(B), d + 5 * P, S},
+                          {const_cast<float*>(intensity), d + 6 * P, S}};
+        // the caller's arrays are only valid for the call (they are stack VLAs in the reference, EMg.cpp:260-267): read before it returns
+        if ((rc = upload_arrays(h, up, attr ? 7 : 3))) return rc;
+        in.f_index = reinterpret_cast<const int*>(d); in.f_height = reinterpret_cast<const float*>(d + P);
+        in.f_var = reinterpret_cast<const float*>(d + 2 * P);
         if (attr) {
-            GEM_HIP(h, hipMemcpyAsync(d + 3 * S, R, S, hipMemcpyHostToDevice, h->stream));
-            GEM_HIP(h, hipMemcpyAsync(d + 4 * S, G, S, hipMemcpyHostToDevice, h->stream));
-            GEM_HIP(h, hipMemcpyAsync(d + 5 * S, B, S, hipMemcpyHostToDevice, h->stream));
-            GEM_HIP(h, hipMemcpyAsync(d + 6 * S, intensity, S, hipMemcpyHostToDevice, h->stream));
-            in.f_R = reinterpret_cast<const int*>(d + 3 * S); in.f_G = reinterpret_cast<const int*>(d + 4 * S);
-            in.f_B = reinterpret_cast<const int*>(d + 5 * S); in.f_I = reinterpret_cast<const float*>(d + 6 * S);
+            in.f_R = reinterpret_cast<const int*>(d + 3 * P); in.f_G = reinterpret_cast<const int*>(d + 4 * P);
+            in.f_B = reinterpret_cast<const int*>(d + 5 * P); in.f_I = reinterpret_cast<const float*>(d + 6 * P);
         }
-        // the caller's arrays are only valid for the call (they are stack VLAs in the reference, EMg.cpp:260-267)
-        GEM_HIP(h, hipEventRecord(h->copy_done, h->stream));
-        GEM_HIP(h, hipEventSynchronize(h->copy_done));
     }
     return run_pipeline(h, in);
 }
@@ -1372,14 +1572,16 @@ int gem_add(gem_handle* h, const gem_frame_params* p, int n, const float* xyzi, 
     if (n > 0) {
         const size_t S = (size_t)n * 4;
         int rc;
-        if ((rc = ensure(h, h->stage, S * 6))) return rc;
+        const size_t P4 = (S * 4 + 255) & ~(size_t)255, P = (S + 255) & ~(size_t)255;      // strides as in the staging buffer (upload_arrays)
+        if ((rc = ensure(h, h->stage, P4 + 2 * P))) return rc;
         unsigned char* d = static_cast<unsigned char*>(h->stage.p);
-        GEM_HIP(h, hipMemcpyAsync(d, xyzi, S * 4, hipMemcpyHostToDevice, h->stream));
+        HostXfer up[3] = {{const_cast<float*>(xyzi), d, S * 4}, {nullptr, nullptr, 0}, {nullptr, nullptr, 0}};
+        int nu = 1;
         in.xyzi = reinterpret_cast<const float4*>(d);
-        if (rgb) { GEM_HIP(h, hipMemcpyAsync(d + 4 * S, rgb, S, hipMemcpyHostToDevice, h->stream)); in.rgb = reinterpret_cast<const uint32_t*>(d + 4 * S); }
-        if (orig_index) { GEM_HIP(h, hipMemcpyAsync(d + 5 * S, orig_index, S, hipMemcpyHostToDevice, h->stream)); in.orig = reinterpret_cast<const int*>(d + 5 * S); }
-        GEM_HIP(h, hipEventRecord(h->copy_done, h->stream));
-        GEM_HIP(h, hipEventSynchronize(h->copy_done));
+        unsigned char* next = d + P4;
+        if (rgb) { up[nu++] = {const_cast<uint32_t*>(rgb), next, S}; in.rgb = reinterpret_cast<const uint32_t*>(next); next += P; }
+        if (orig_index) { up[nu++] = {const_cast<int*>(orig_index), next, S}; in.orig = reinterpret_cast<const int*>(next); }
+        if ((rc = upload_arrays(h, up, nu))) return rc;
     }
     return run_pipeline(h, in);
 }
@@ -1401,13 +1603,12 @@ int gem_add_aos(gem_handle* h, const gem_frame_params* p, int n, const void* poi
         int rc;
         if ((rc = ensure(h, h->stage, raw + S * 5))) return rc;
         unsigned char* d = static_cast<unsigned char*>(h->stage.p);
-        GEM_HIP(h, hipMemcpyAsync(d, points, (size_t)n * point_step, hipMemcpyHostToDevice, h->stream));
+        HostXfer up{const_cast<void*>(points), d, (size_t)n * point_step};
+        if ((rc = upload_arrays(h, &up, 1))) return rc;              // (returns once the caller's buffer has been read)
         float4* xyzi = reinterpret_cast<float4*>(d + raw);
         uint32_t* rgb = off_rgb >= 0 ? reinterpret_cast<uint32_t*>(d + raw + S * 4) : nullptr;
         GEM_HIP(h, launch_unpack_aos(h->stream, d, n, point_step, off_x, off_y, off_z, off_intensity, off_rgb, xyzi, rgb));
         in.xyzi = xyzi; in.rgb = rgb;
-        GEM_HIP(h, hipEventRecord(h->copy_done, h->stream));
-        GEM_HIP(h, hipEventSynchronize(h->copy_done));              // the caller's buffer has been read
     }
     return run_pipeline(h, in);
 }
@@ -1454,7 +1655,14 @@ int gem_reserve(gem_handle* h, long long max_points, int max_sweeps, int with_co
     int rc;
     const long long blocks = 4ll * ((h->L + 31) / 32) * ((h->L + 31) / 32);
     // staging of host-pointer inputs (gem_add: XYZI + rgb + orig; gem_fuse: seven arrays; gem_process_points: nine)
-    if ((rc = ensure(h, h->stage, (size_t)max_points * 4 * 9))) return rc;
+    if ((rc = ensure(h, h->stage, ((size_t)max_points * 4 + 256) * 9))) return rc;
+    {   // ... and its pinned counterpart for callers with host arrays (gem_process_points: nine arrays; gem_map_feature: nine layers),
+        // where that is a modest amount: larger ones grow on first use
+        constexpr size_t kReserveMax = 64u << 20;
+        const size_t a = ((size_t)max_points * 4 + 256) * 9, b = ((size_t)h->cells * 4 + 256) * 9;
+        const size_t want = std::max(a <= kReserveMax ? a : 0, b <= kReserveMax ? b : 0);
+        if (want) (void)host_stage(h, want);
+    }
     auto reserve_tables = [&](int sweeps) -> int {                       // the batched calls' tables and their pinned staging copies
         const size_t tables = sizeof(FrameConst) * sweeps + (sizeof(int) + sizeof(long long)) * (sweeps + 1) + (sizeof(float) + sizeof(int)) * sweeps + 64;
         for (auto& pb : h->pb) {
@@ -1597,18 +1805,17 @@ int gem_get_layer(gem_handle* h, int layer, int layout, void* dst_host)
     if (rc) return rc;
     const size_t bytes = (size_t)h->cells * 4;
     if (layout == GEM_LAYOUT_STORAGE_ROWMAJOR) {
-        GEM_HIP(h, hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, h->stream));
+        HostXfer down{dst_host, src, bytes};
+        return download_arrays(h, &down, 1, 0);
     } else if (layout == GEM_LAYOUT_GRIDMAP_COLMAJOR_NAN) {
         if (layer == GEM_LAYER_LOWEST) return fail(h, GEM_ERR_INVALID, "gem_get_layer: the LOWEST layer is indexed by geographic cell, it has no grid_map layout");
         if ((rc = ensure(h, h->scratch, bytes))) return rc;
         const int is_int = layer >= GEM_LAYER_COLOR_R && layer <= GEM_LAYER_COLOR_B;
         GEM_HIP(h, launch_export_gridmap(h->stream, src, h->layers.elevation, static_cast<float*>(h->scratch.p), h->L, is_int));
-        GEM_HIP(h, hipMemcpyAsync(dst_host, h->scratch.p, bytes, hipMemcpyDeviceToHost, h->stream));
-    } else {
-        return fail(h, GEM_ERR_INVALID, "gem_get_layer: bad layout");
+        HostXfer down{dst_host, h->scratch.p, bytes};
+        return download_arrays(h, &down, 1, 0);
     }
-    GEM_HIP(h, hipStreamSynchronize(h->stream));
-    return GEM_OK;
+    return fail(h, GEM_ERR_INVALID, "gem_get_layer: bad layout");
 }
 
 int gem_set_layer(gem_handle* h, int layer, const void* src_host)
@@ -1694,10 +1901,9 @@ int gem_map_feature(gem_handle* h, float* elevation, float* variance, int* color
         {elevation, h->layers.elevation}, {variance, h->layers.variance}, {colorR, h->layers.colorR}, {colorG, h->layers.colorG},
         {colorB, h->layers.colorB}, {rough, h->layers.rough}, {slope, h->layers.slope}, {traver, h->layers.traver},
         {intensity, h->layers.intensity}};
-    bool any = false;
-    for (auto& o : out) if (o.dst) { GEM_HIP(h, hipMemcpyAsync(o.dst, o.src, bytes, hipMemcpyDeviceToHost, h->stream)); any = true; }
-    if (any) GEM_HIP(h, hipStreamSynchronize(h->stream));
-    return GEM_OK;
+    HostXfer down[9]; int nd = 0;
+    for (auto& o : out) if (o.dst) down[nd++] = {o.dst, const_cast<void*>(o.src), bytes};
+    return nd ? download_arrays(h, down, nd, 0) : GEM_OK;
 }
 
 // ElevationMap::show's cell loop (ElevationMap.cpp:85-149) on the resident layers: visualMap_'s nine layers in grid_map's own
@@ -1940,6 +2146,7 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "cache_tables")       h->cache_tables = value != 0;
     else if (k == "light_fast")         h->light_fast = value != 0;
     else if (k == "walk_lds_pad")       { if (value < 0 || value > 100 * 1024) return fail(h, GEM_ERR_INVALID, "walk_lds_pad: 0 .. 102400 bytes"); h->walk_lds_pad = (int)value; }
+    else if (k == "copy_threads")       { if (value < 0 || value > gem::CopyPool::kMaxThreads) return fail(h, GEM_ERR_INVALID, "copy_threads: 0 (the runtime's pageable path) .. 16"); h->copy_threads = (int)value; }
     else if (k == "walk_prio")          { if (value < 0 || value > (1 << 30)) return fail(h, GEM_ERR_INVALID, "walk_prio: 0 (off) or a record count"); h->walk_prio = (int)value; }
     else if (k == "blk_batch")          { if (value != 0 && value != 512 && value != 2048) return fail(h, GEM_ERR_INVALID, "blk_batch: 0 (by pass), 512 or 2048"); h->blk_batch = (int)value; }
     else if (k == "few_bins")           { if (value < -1 || value > 64) return fail(h, GEM_ERR_INVALID, "few_bins: -1 (one ballot per digit bit), 0 (by pass), 1..64"); h->few_bins = (int)value; }
@@ -1957,6 +2164,13 @@ int gem_debug_get(gem_handle* h, const char* key, long long* out)
     std::lock_guard<std::mutex> lk(h->mu);
     const std::string k(key);
     if (k == "arena_allocations") *out = h->arena_allocations;
+    else if (k == "hstage_allocations") *out = h->hstage_allocations;
+    else if (k == "copy_threads") *out = h->copy_threads;
+    else if (k == "xfer_upload_memcpy_ns") *out = h->xfer_ns[0];
+    else if (k == "xfer_upload_enqueue_ns") *out = h->xfer_ns[1];
+    else if (k == "xfer_download_enqueue_ns") *out = h->xfer_ns[2];
+    else if (k == "xfer_download_wait_ns") *out = h->xfer_ns[3];
+    else if (k == "xfer_download_memcpy_ns") *out = h->xfer_ns[4];
     else if (k == "sort_fallbacks") *out = h->sort_fallbacks;
     else if (k == "step_pending") *out = h->step.valid ? 1 : 0;
     else if (k.rfind("step_", 0) == 0) {

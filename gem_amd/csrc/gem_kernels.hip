@@ -32,13 +32,14 @@ namespace gem {
 // ------------------------------------------------------------------------------------------
 // k_project : Process_points' kernel (GPU:384-455) for the GEM-compatible host-array entry.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_project(FrameConst fc, int n, float* __restrict__ x, float* __restrict__ y,
+// (`first`: the index of point 0 of these arrays in the caller's cloud -- gem_process_points hands a large cloud over in ranges)
+__global__ __launch_bounds__(256) void k_project(FrameConst fc, int first, int n, float* __restrict__ x, float* __restrict__ y,
                                                  float* __restrict__ z, const int* __restrict__ orig, int write_back,
                                                  int* __restrict__ map_idx, float* __restrict__ var,
                                                  float* __restrict__ xt, float* __restrict__ yt, float* __restrict__ zt)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const Projected r = project_point(fc, x[i], y[i], z[i], orig ? orig[i] : i);
+        const Projected r = project_point(fc, x[i], y[i], z[i], orig ? orig[i] : first + i);
         map_idx[i] = r.cell; var[i] = r.var; xt[i] = r.xt; yt[i] = r.yt; zt[i] = r.h;
         if (write_back && !r.accepted) { x[i] = -1.0f; y[i] = -1.0f; z[i] = -1.0f; }   // GPU:443-446
     }
@@ -1106,6 +1107,22 @@ __global__ __launch_bounds__(256) void k_update_height(float* __restrict__ eleva
     }
 }
 
+// Device arrays -> the handle's pinned staging buffer (gem_capi.cpp: download_arrays): up to kCopyListMax pieces per launch, piece =
+// blockIdx.y.  Stores to host memory over PCIe, a wave writing 1 KiB contiguous; one launch instead of one DMA command per array
+// (whose fixed cost, not its rate, is what a frame's five 0.5 MB outputs pay).  Pieces are 16-byte aligned except for a tail.
+__global__ __launch_bounds__(256) void k_copy_list(CopyList l)
+{
+    const CopyPiece pc = l.piece[blockIdx.y];
+    const size_t n16 = pc.bytes / 16;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* __restrict__ s = static_cast<const u32x4*>(pc.src);
+    u32x4* __restrict__ d = static_cast<u32x4*>(pc.dst);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+        __builtin_nontemporal_store(s[i], d + i);
+    if (blockIdx.x == 0 && threadIdx.x < (pc.bytes & 15))
+        static_cast<unsigned char*>(pc.dst)[n16 * 16 + threadIdx.x] = static_cast<const unsigned char*>(pc.src)[n16 * 16 + threadIdx.x];
+}
+
 // grid_map export (EM.cpp:98-111 reads the flat arrays with the GridMap *buffer* index; a
 // grid_map::Matrix is an Eigen column-major float matrix; empty cells become NaN)
 __global__ __launch_bounds__(256) void k_export_gridmap(const void* __restrict__ src, const float* __restrict__ elevation,
@@ -1363,11 +1380,11 @@ static inline int grid_for(long long work, int block, int cap = 2048)
     return (int)g;
 }
 
-hipError_t launch_project(hipStream_t st, const FrameConst& fc, int n, float* x, float* y, float* z, const int* orig,
+hipError_t launch_project(hipStream_t st, const FrameConst& fc, int first, int n, float* x, float* y, float* z, const int* orig,
                           int write_back, int* map_idx, float* var, float* xt, float* yt, float* zt)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_project, dim3(grid_for(n, 256)), dim3(256), 0, st, fc, n, x, y, z, orig, write_back, map_idx, var, xt, yt, zt);
+    hipLaunchKernelGGL(k_project, dim3(grid_for(n, 256)), dim3(256), 0, st, fc, first, n, x, y, z, orig, write_back, map_idx, var, xt, yt, zt);
     return hipGetLastError();
 }
 
@@ -1740,6 +1757,16 @@ hipError_t launch_map_feature(hipStream_t st, const float* elevation, float* tra
 {
     const int tiles = (L + 15) / 16;
     hipLaunchKernelGGL(k_map_feature, dim3(tiles * tiles), dim3(256), 0, st, elevation, traver, rough, slope, L, res, sx, sy, row0, row1);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy_list(hipStream_t st, const CopyList& l)
+{
+    if (l.n <= 0) return hipSuccess;
+    size_t longest = 0;
+    for (int i = 0; i < l.n; ++i) longest = l.piece[i].bytes > longest ? l.piece[i].bytes : longest;
+    const size_t blocks = (longest / 16 + 255) / 256;                   // one 16-byte store per lane: the link wants many stores in flight
+    hipLaunchKernelGGL(k_copy_list, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks)), (unsigned)l.n), dim3(256), 0, st, l);
     return hipGetLastError();
 }
 

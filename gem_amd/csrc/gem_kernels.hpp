@@ -209,7 +209,7 @@ hipError_t launch_strip_bounds(hipStream_t st, const uint32_t* keys, const uint3
 constexpr int kSortChunkRecords = 4096, kSortSegsPerChunk = 4;   // records per counting-sort chunk; 1024-point wave segments per pass-1 chunk (seg_cnt words)
 constexpr int kSortMaxBins = 8000;     // bins per pass the sorted pipeline handles (LDS of k_sort_scatter)
 
-hipError_t launch_project(hipStream_t st, const FrameConst& fc, int n, float* x, float* y, float* z, const int* orig,
+hipError_t launch_project(hipStream_t st, const FrameConst& fc, int first, int n, float* x, float* y, float* z, const int* orig,
                           int write_back, int* map_idx, float* var, float* xt, float* yt, float* zt);
 
 hipError_t launch_bin(hipStream_t st, const BinArgs& a, int src, int ts, LaunchEvents ev);
@@ -242,6 +242,11 @@ struct ColorArgs {
     float4* xyzi; uint32_t* rgb;       // intensity zeroed / 0x00RRGGBB written
 };
 hipError_t launch_colorize(hipStream_t st, const ColorArgs& a);
+// device -> pinned host staging, several pieces per launch (k_copy_list)
+constexpr int kCopyListMax = 12;
+struct CopyPiece { void* dst; const void* src; size_t bytes; };
+struct CopyList { CopyPiece piece[kCopyListMax]; int n; };
+hipError_t launch_copy_list(hipStream_t st, const CopyList& l);
 hipError_t launch_export_gridmap(hipStream_t st, const void* src, const float* elevation, float* dst, int L, int is_int);
 
 } // namespace gem

@@ -58,6 +58,17 @@ def test_the_product_reads_no_environment_variables():
         assert "getenv" not in text and "os.environ" not in text, p
 
 
+def test_the_copy_thread_pool_moves_every_byte(tmp_path):
+    """gem_amd/csrc/gem_hostcopy.hpp on its own (tests/cpp/hostcopy_pool.cpp): thread counts 1..8, sizes around the piece size, workers
+    polling and asleep, concurrent callers."""
+    exe = tmp_path / "hostcopy_pool"
+    res = subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-pthread", str(ROOT / "tests" / "cpp" / "hostcopy_pool.cpp"), "-o", str(exe)],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and run.stdout.strip() == "ok", run.stdout + run.stderr
+
+
 def test_struct_layouts_match_the_header(tmp_path):
     from gem_amd import _lib
     src = tmp_path / "layout.c"

@@ -233,6 +233,72 @@ def test_fuse_arrays_parity(oracle_mod):
     assert_maps_match(gpu, ref)
 
 
+@pytest.mark.parametrize("threads", [0, 1, 4, 8])
+def test_host_arrays_through_the_pinned_staging_and_through_the_runtime(oracle_mod, threads):
+    """Caller-owned pageable arrays (the node's: gpu_process.cu:1096-1141, :1165-1192, :1283-1291) travel through the handle's pinned
+    staging buffer with `copy_threads` threads between it and the arrays (gem_hostcopy.hpp; 0 = handed to the runtime as they are).
+    A frame's calls with sizes that grow and shrink (the buffer is reallocated while an upload may still be read), odd sizes,
+    sizes under the staging threshold, write-back, every array of Process_points / Fuse / Map_feature / get_layer: equal to the
+    oracle whatever the route."""
+    import ctypes as C
+    L, res = 300, 0.1
+    gpu, ref = make_pair(oracle_mod, L, res)
+    gpu.debug_set("copy_threads", threads)
+    assert gpu.debug_get("copy_threads") == threads
+    f = synth.config_c2(reference_filter=True).frames[0]             # (the reject filter looks at a point's index in the cloud)
+    for it, n in enumerate([70001, 300, 262144 + 3, 131072, 9, 524288 + 1]):
+        c = synth.random_cloud(40 + it, n, 14.0)
+        idx = np.arange(n, dtype=np.int32)[::-1].copy() if it % 3 == 0 else None
+        g = gpu.process_points(f, c[:, 0], c[:, 1], c[:, 2], orig_index=idx, write_back_xyz=True)
+        o = ref.process_points(f, c[:, 0], c[:, 1], c[:, 2], orig_index=idx, write_back_xyz=True)
+        for k in ("index", "var", "x_ts", "y_ts", "height", "x", "y", "z"):
+            assert np.array_equal(g[k], o[k]), (k, n)
+        rng = np.random.default_rng(it)
+        R, G, B = (rng.integers(0, 256, n).astype(np.int32) for _ in range(3))
+        I = rng.integers(0, 2, n).astype(F32)
+        gpu.mapvar_update(1e-6); ref.mapvar_update(1e-6)
+        if it % 2:
+            gpu.fuse(g["index"], g["height"], g["var"]); ref.fuse(o["index"], o["height"], o["var"])
+        else:
+            gpu.fuse(g["index"], g["height"], g["var"], R, G, B, I); ref.fuse(o["index"], o["height"], o["var"], R, G, B, I)
+        gpu.add(f, c); ref.add(f, c)                                     # (XYZI host array: the fused entry point's upload)
+        outs = {k: np.full(L * L, -77, np.int32 if k.startswith("color") else F32) for k in
+                ("elevation", "variance", "color_r", "color_g", "color_b", "rough", "slope", "traver", "intensity")}
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        assert gpu._lib.gem_map_feature(gpu._h, *[vp(outs[k]) for k in ("elevation", "variance", "color_r", "color_g", "color_b", "rough", "slope", "traver", "intensity")]) == 0
+        feat = ref.map_feature()
+        for k, a in outs.items():
+            assert np.array_equal(a.reshape(L, L), feat[k] if k in feat else ref.layer(k)), (k, n)
+        assert_maps_match(gpu, ref, layers=("elevation", "variance", "intensity", "color_r", "color_g", "color_b"))      # gem_get_layer
+    assert (gpu.debug_get("hstage_allocations") > 0) == (threads > 0)
+
+
+def test_host_array_calls_from_several_threads_on_their_own_handles(oracle_mod):
+    """One pool of copy threads serves the process: calls on different handles at the same time (one gets the pool, the others
+    copy on their own thread) and all give the oracle's map."""
+    import threading
+    wl = synth.config_c2()
+    ref = oracle_mod.OracleMap(wl.length, wl.resolution)
+    c, f = wl.clouds[0], wl.frames[0]
+    o = ref.process_points(f, c[:, 0], c[:, 1], c[:, 2]); ref.fuse(o["index"], o["height"], o["var"])
+    want = {k: ref.layer(k) for k in ("elevation", "variance")}
+    bad = []
+
+    def frame(k):
+        for _ in range(3):
+            m = ElevationMap(wl.length, wl.resolution)
+            g = m.process_points(f, c[:, 0], c[:, 1], c[:, 2]); m.fuse(g["index"], g["height"], g["var"])
+            for name, w in want.items():
+                if not np.array_equal(m.layer(name), w):
+                    bad.append((k, name))
+            m.close()
+
+    ts = [threading.Thread(target=frame, args=(k,)) for k in range(4)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("what", ["variances", "heights", "state", "increments", "cancellation"])
 def test_values_outside_the_plain_range_take_the_guarded_chain_loops(oracle_mod, what):
     """The walks' plain chain loops (gem_sort.hip) drop the per-step guards when every record has |h| <= 2^28, 2^-28 <= v <= 2^28,

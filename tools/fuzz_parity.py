@@ -58,6 +58,7 @@ def scenario(seed):
     gpu = ElevationMap(L, res, debug=knobs); ora = oracle.OracleMap(L, res)
     if lowest:
         gpu.set_lowest_tracking(True)
+    gpu.debug_set("copy_threads", int(rng.choice([0, 1, 4, 4, 8])))      # host arrays: the runtime's path, or the pinned staging + copy threads
     extent = 0.5 * L * res
     pts_total = 0
     steps = int(rng.integers(2, 6))
@@ -85,8 +86,17 @@ def scenario(seed):
         if n_sweeps == 1 and rng.random() < 0.5:
             if incs:
                 gpu.mapvar_update(incs[0]); ora.mapvar_update(incs[0])
-            dev = torch.from_numpy(clouds[0]).cuda() if rng.random() < 0.7 else clouds[0]
-            gpu.add(frames[0], dev); ora.add(frames[0], clouds[0])
+            how = rng.random()
+            if how < 0.2:                                      # the node's two calls with host arrays (Process_points, then Fuse)
+                c0 = clouds[0]
+                g = gpu.process_points(frames[0], c0[:, 0], c0[:, 1], c0[:, 2]); o = ora.process_points(frames[0], c0[:, 0], c0[:, 1], c0[:, 2])
+                for k in ("index", "var", "x_ts", "y_ts", "height"):
+                    if not np.array_equal(g[k], o[k]):
+                        raise AssertionError(f"seed {seed} step {step}: process_points {k}")
+                gpu.fuse(g["index"], g["height"], g["var"]); ora.fuse(o["index"], o["height"], o["var"])
+            else:
+                dev = torch.from_numpy(clouds[0]).cuda() if how < 0.75 else clouds[0]
+                gpu.add(frames[0], dev); ora.add(frames[0], clouds[0])
         else:
             off = np.concatenate([[0], np.cumsum([c.shape[0] for c in clouds])])
             gpu.add_batch(frames, torch.from_numpy(np.concatenate(clouds, 0)).cuda(), off, incs)
