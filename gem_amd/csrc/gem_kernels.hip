@@ -1543,10 +1543,16 @@ __device__ __forceinline__ int ray_robot_index(int L) { return (L % 2 == 0) ? (i
 // The same pass over the cells takes G_Clear_maplowest (GPU:232-239) with it: the walks read a SNAPSHOT of the lowest scan points,
 // written here next to the reset of the layer itself -- one launch and one pass over the layer less than clearing behind the walks
 // (k_clear_lowest was 3.8-5.6 us of the node's 45 us frame).  It also zeroes the OTHER call parity's counter of walkers.
-__global__ __launch_bounds__(256) void k_ray_list(LayerPtrs m, int L, int start0, int start1, float obstacle_threshold, int row0, int row1,
-                                                 uint32_t* __restrict__ list, uint32_t* __restrict__ count, uint32_t* __restrict__ count_next,
-                                                 float* __restrict__ lowest_snapshot)
+// One atomic per WORKGROUP of 1024 cells claims the list slots of its sixteen waves: with one per wave, a map where most waves hold
+// a walker (C2 with the reference's reject filter: walkers all over the map) sent 5 600 atomics to one address and the kernel took
+// 31 us for 7 MB of traffic.  (The order of the list is irrelevant: the walks only lower running minima.)
+constexpr int kRayListThreads = 1024;
+__global__ __launch_bounds__(kRayListThreads) void k_ray_list(LayerPtrs m, int L, int start0, int start1, float obstacle_threshold, int row0, int row1,
+                                                              uint32_t* __restrict__ list, uint32_t* __restrict__ count, uint32_t* __restrict__ count_next,
+                                                              float* __restrict__ lowest_snapshot)
 {
+    __shared__ uint32_t wave_cnt[kRayListThreads / 64];
+    __shared__ uint32_t block_base;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool walks = false;
     if (i == 0) *count_next = 0u;
@@ -1562,11 +1568,19 @@ __global__ __launch_bounds__(256) void k_ray_list(LayerPtrs m, int L, int start0
         }
     }
     const uint64_t mk = __ballot(walks);
-    if (mk == 0) return;
-    uint32_t base = 0;
-    if (lane_id() == 0) base = atomicAdd(count, (uint32_t)__popcll(mk));
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    if (walks) list[base + (uint32_t)__popcll(mk & lanemask_lt())] = (uint32_t)i;
+    const int w = (int)(threadIdx.x >> 6);
+    if (lane_id() == 0) wave_cnt[w] = (uint32_t)__popcll(mk);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int k = 0; k < kRayListThreads / 64; ++k) total += wave_cnt[k];
+        block_base = total ? atomicAdd(count, total) : 0u;
+    }
+    __syncthreads();
+    if (!walks) return;
+    uint32_t base = block_base;
+    for (int k = 0; k < w; ++k) base += wave_cnt[k];
+    list[base + (uint32_t)__popcll(mk & lanemask_lt())] = (uint32_t)i;
 }
 
 // One ray is walked by G adjacent lanes, each a run of S crossings of the ray's MAJOR axis (the one with the larger |increment|):
@@ -1709,9 +1723,9 @@ hipError_t launch_unpack_aos(hipStream_t st, const void* src, int n, int step, i
 hipError_t launch_raytracing(hipStream_t st, const LayerPtrs& m, int L, int start0, int start1, float sensor_z, float obstacle_threshold,
                              int row0, int row1, uint32_t* list, uint32_t* counts, int parity, float* lowest_snapshot, int depth, int lanes)
 {
-    const dim3 grid((L * L + 255) / 256), block(256);
+    const dim3 grid((L * L + kRayListThreads - 1) / kRayListThreads), block(256);
     uint32_t* count = counts + (parity & 1), *count_next = counts + ((parity + 1) & 1);
-    hipLaunchKernelGGL(k_ray_list, grid, block, 0, st, m, L, start0, start1, obstacle_threshold, row0, row1, list, count, count_next, lowest_snapshot);
+    hipLaunchKernelGGL(k_ray_list, grid, dim3(kRayListThreads), 0, st, m, L, start0, start1, obstacle_threshold, row0, row1, list, count, count_next, lowest_snapshot);
     auto k = lanes >= 16 ? (depth >= 8 ? k_raytracing<8, 16> : k_raytracing<4, 16>)
            : lanes >= 8  ? (depth >= 8 ? k_raytracing<8, 8>  : k_raytracing<4, 8>)
            : lanes >= 4  ? (depth >= 8 ? k_raytracing<8, 4>  : k_raytracing<4, 4>)
