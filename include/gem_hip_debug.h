@@ -30,11 +30,17 @@ extern "C" {
  *       "cache_tables" (0/1: a batched call whose frames / offsets / increments / map pose equal what a buffer set's device tables were
  *       built from skips building and uploading them), "walk_prio" (0 = off; blocks of at least that many records raise their waves'
  *       issue priority), "walk_lds_pad" (bytes of unused LDS per k_fuse_block workgroup: fewer workgroups per CU; an experiment's knob),
+ *       "copy_threads" (0 .. 16, default 4: caller-owned HOST arrays travel through the handle's pinned staging buffer, this many threads
+ *       -- the caller's and process-wide workers on its CCD -- copying between it and the arrays (csrc/gem_hostcopy.hpp); 0 = the arrays are
+ *       handed to the runtime as they are),
  *       "trace" (0/1: one line on stderr per pass of the sorted pipeline), "stream_roles" (a permutation of 0123 as a decimal
  *       number: which of the handle's current own / bin / bin2 / upload streams takes each role; tools/dbg/roles.py).  Returns GEM_ERR_INVALID for an unknown key or a value out of range. */
 int gem_debug_set(gem_handle* h, const char* key, long long value);
 
 /* read-outs: "arena_allocations" (device allocations the handle's arenas have made so far: none may follow gem_reserve),
+ *            "hstage_allocations" (allocations of the pinned staging buffer: none may follow gem_reserve for clouds / maps within 64 MB),
+ *            "xfer_upload_memcpy_ns", "xfer_upload_enqueue_ns", "xfer_download_enqueue_ns", "xfer_download_wait_ns", "xfer_download_memcpy_ns"
+ *            (host time spent so far moving caller-owned host arrays: bench.py's node_host_arrays),
  *            "sort_fallbacks" (passes whose forced sorted form / pass count did not fit the map and took the other form),
  *            "step_pending" (1: the second half of a gem_add_sharded_device step is still to come),
  *            "step_exchange_ns", "step_walk_ns", "step_publish_ns", "step_gather_ns", "step_exchange_to_walk_ns": device time stamps of
