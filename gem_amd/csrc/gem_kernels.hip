@@ -1243,6 +1243,55 @@ __device__ __forceinline__ float f_cos(float x)            { return (float)cos((
 __device__ __forceinline__ float f_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
 __device__ __forceinline__ float f_acos(float x)           { return (float)acos((double)x); }
 
+// The Jacobi loop runs for the cells whose covariance has an off-diagonal entry of at least 0.01 -- slopes, steps, windows cut by
+// the map's edge or by holes: a minority, scattered over every wave, each wave as slow as its slowest lane (up to 30 rotations of five
+// double-precision libm calls).  The workgroup therefore COMPACTS them: the cells that rotate put their six matrix entries into LDS,
+// the first `count` threads run the loop on dense waves and hand back what the cell needs (the diagonal and the eigenvectors' z
+// components); the same operations on the same values per cell, in whatever lane.
+struct JacobiOut { float d0, d1, d2, z0, z1, z2; };
+__device__ __forceinline__ JacobiOut jacobi_3x3(float a00, float a11, float a22, float a01, float a02, float a12)
+{
+    // ---- computerEigenvalue (GPU:66-187), dbEps = 0.01, nJt = 30 ----
+    float v00 = 1.f, v01 = 0.f, v02 = 0.f, v10 = 0.f, v11 = 1.f, v12 = 0.f, v20 = 0.f, v21 = 0.f, v22 = 1.f;
+    int count = 0;
+    while (true) {
+        float mxv = a01; int pair = 0;                          // GPU:85-100 (signed start value, strict >)
+        { const float d = fabsf(a01); if (d > mxv) { mxv = d; pair = 0; } }
+        { const float d = fabsf(a02); if (d > mxv) { mxv = d; pair = 1; } }
+        { const float d = fabsf(a12); if (d > mxv) { mxv = d; pair = 2; } }
+        if (mxv < 0.01f) break;
+        if (count > 30) break;
+        ++count;
+        // (p, q, r): pair 0 -> (0,1,2), 1 -> (0,2,1), 2 -> (1,2,0)
+        float app, aqq, apq, arp, arq;
+        if (pair == 0)      { app = a00; aqq = a11; apq = a01; arp = a02; arq = a12; }
+        else if (pair == 1) { app = a00; aqq = a22; apq = a02; arp = a01; arq = a12; }
+        else                { app = a11; aqq = a22; apq = a12; arp = a01; arq = a02; }
+        const float ang = (float)(0.5 * (double)f_atan2(-2 * apq, aqq - app));             // GPU:116
+        const float sn = f_sin(ang), cs = f_cos(ang), sn2 = f_sin(2 * ang), cs2 = f_cos(2 * ang);
+        const float npp = app * cs * cs + aqq * sn * sn + 2 * apq * cs * sn;                // GPU:122-123
+        const float nqq = app * sn * sn + aqq * cs * cs - 2 * apq * cs * sn;                // GPU:124-125
+        const float npq = (float)(0.5 * (double)(aqq - app) * (double)sn2 + (double)(apq * cs2));   // GPU:126
+        const float nrp = arq * sn + arp * cs;                                               // GPU:129-151
+        const float nrq = arq * cs - arp * sn;
+        if (pair == 0)      { a00 = npp; a11 = nqq; a01 = npq; a02 = nrp; a12 = nrq; }
+        else if (pair == 1) { a00 = npp; a22 = nqq; a02 = npq; a01 = nrp; a12 = nrq; }
+        else                { a11 = npp; a22 = nqq; a12 = npq; a01 = nrp; a02 = nrq; }
+        // eigenvector columns p, q (GPU:154-161)
+        float u0, u1, u2, w0, w1, w2;
+        if (pair == 0)      { u0 = v00; u1 = v10; u2 = v20; w0 = v01; w1 = v11; w2 = v21; }
+        else if (pair == 1) { u0 = v00; u1 = v10; u2 = v20; w0 = v02; w1 = v12; w2 = v22; }
+        else                { u0 = v01; u1 = v11; u2 = v21; w0 = v02; w1 = v12; w2 = v22; }
+        const float nu0 = w0 * sn + u0 * cs, nw0 = w0 * cs - u0 * sn;
+        const float nu1 = w1 * sn + u1 * cs, nw1 = w1 * cs - u1 * sn;
+        const float nu2 = w2 * sn + u2 * cs, nw2 = w2 * cs - u2 * sn;
+        if (pair == 0)      { v00 = nu0; v10 = nu1; v20 = nu2; v01 = nw0; v11 = nw1; v21 = nw2; }
+        else if (pair == 1) { v00 = nu0; v10 = nu1; v20 = nu2; v02 = nw0; v12 = nw1; v22 = nw2; }
+        else                { v01 = nu0; v11 = nu1; v21 = nu2; v02 = nw0; v12 = nw1; v22 = nw2; }
+    }
+    return JacobiOut{a00, a11, a22, v20, v21, v22};
+}
+
 __global__ __launch_bounds__(256) void k_map_feature(const float* __restrict__ elevation, float* __restrict__ traver,
                                                      float* __restrict__ rough, float* __restrict__ slope,
                                                      int L, float res, int sx, int sy, int row0, int row1)
@@ -1250,6 +1299,8 @@ __global__ __launch_bounds__(256) void k_map_feature(const float* __restrict__ e
     // one workgroup per 16x16 block of storage cells; the block and its 2-cell halo (storage wrap-around) are staged
     // in LDS once: 400 loads per 256 cells instead of 50 per cell
     __shared__ float zt[20 * 20];
+    __shared__ float jq[6][256];                                       // the rotating cells' matrices, then their results
+    __shared__ uint32_t jn;
     const int tiles = (L + 15) >> 4;
     const int tr_ = (int)blockIdx.x / tiles, tc_ = (int)blockIdx.x - tr_ * tiles;
     const int R0 = tr_ << 4, C0 = tc_ << 4;
@@ -1259,14 +1310,16 @@ __global__ __launch_bounds__(256) void k_map_feature(const float* __restrict__ e
         int py = C0 - 2 + j; py = py < 0 ? py + L : (py >= L ? py - L : py); py = py >= L ? py - L : py;
         zt[t] = elevation[px * L + py];
     }
+    if (threadIdx.x == 0) jn = 0u;
     __syncthreads();
     const int ly = (int)threadIdx.x >> 4, lx = (int)threadIdx.x & 15;
     const int cell_x = R0 + ly, cell_y = C0 + lx;
-    if (cell_x >= L || cell_y >= L) return;
-    if (cell_x < row0 || cell_x >= row1) return;                       // multi-GPU: only the owned strip
+    const bool mine = cell_x < L && cell_y < L && cell_x >= row0 && cell_x < row1;      // (multi-GPU: only the owned strip)
     const int idx = cell_x * L + cell_y;
-    const float height = zt[(ly + 2) * 20 + lx + 2];
-    float r_out = 0.0f, s_out = 0.0f;
+    const float height = mine ? zt[(ly + 2) * 20 + lx + 2] : kEmptyElevation;
+    float mz = 0.0f;
+    float a00 = 0.f, a11 = 0.f, a22 = 0.f, a01 = 0.f, a02 = 0.f, a12 = 0.f;
+    bool fitted = false;                                                // n > 7: the plane fit exists
     if (height != kEmptyElevation) {                                    // GPU:581
         int gx = cell_x + L - sx; if (gx >= L) gx -= L;                 // unrolled index of the cell, GPU:587-588
         int gy = cell_y + L - sy; if (gy >= L) gy -= L;
@@ -1281,7 +1334,7 @@ __global__ __launch_bounds__(256) void k_map_feature(const float* __restrict__ e
             int py = cell_y + k - 2; py = py < 0 ? py + L : (py >= L ? py - L : py);
             xs[k] = (float)px * res; ys[k] = (float)py * res;
         }
-        float mx = 0.0f, my = 0.0f, mz = 0.0f;
+        float mx = 0.0f, my = 0.0f;
         int n = 0;
 #pragma unroll
         for (int i = 0; i < 5; ++i)
@@ -1290,10 +1343,9 @@ __global__ __launch_bounds__(256) void k_map_feature(const float* __restrict__ e
                 const float z = zt[(ly + i) * 20 + lx + j];
                 if (rv[i] && cv[j] && z != kEmptyElevation) { mx = mx + xs[i]; my = my + ys[j]; mz = mz + z; ++n; }
             }
-        float tr = -10.0f;                                              // GPU:660-666
         if (n > 7) {
+            fitted = true;
             mx = mx / (float)n; my = my / (float)n; mz = mz / (float)n;
-            float a00 = 0.f, a11 = 0.f, a22 = 0.f, a01 = 0.f, a02 = 0.f, a12 = 0.f;
 #pragma unroll
             for (int i = 0; i < 5; ++i)
 #pragma unroll
@@ -1305,48 +1357,41 @@ __global__ __launch_bounds__(256) void k_map_feature(const float* __restrict__ e
                         a01 = a01 + dx * dy; a02 = a02 + dx * dz; a12 = a12 + dy * dz;
                     }
                 }
-            // ---- computerEigenvalue (GPU:66-187), dbEps = 0.01, nJt = 30 ----
-            float v00 = 1.f, v01 = 0.f, v02 = 0.f, v10 = 0.f, v11 = 1.f, v12 = 0.f, v20 = 0.f, v21 = 0.f, v22 = 1.f;
-            int count = 0;
-            while (true) {
-                float mxv = a01; int pair = 0;                          // GPU:85-100 (signed start value, strict >)
-                { const float d = fabsf(a01); if (d > mxv) { mxv = d; pair = 0; } }
-                { const float d = fabsf(a02); if (d > mxv) { mxv = d; pair = 1; } }
-                { const float d = fabsf(a12); if (d > mxv) { mxv = d; pair = 2; } }
-                if (mxv < 0.01f) break;
-                if (count > 30) break;
-                ++count;
-                // (p, q, r): pair 0 -> (0,1,2), 1 -> (0,2,1), 2 -> (1,2,0)
-                float app, aqq, apq, arp, arq;
-                if (pair == 0)      { app = a00; aqq = a11; apq = a01; arp = a02; arq = a12; }
-                else if (pair == 1) { app = a00; aqq = a22; apq = a02; arp = a01; arq = a12; }
-                else                { app = a11; aqq = a22; apq = a12; arp = a01; arq = a02; }
-                const float ang = (float)(0.5 * (double)f_atan2(-2 * apq, aqq - app));             // GPU:116
-                const float sn = f_sin(ang), cs = f_cos(ang), sn2 = f_sin(2 * ang), cs2 = f_cos(2 * ang);
-                const float npp = app * cs * cs + aqq * sn * sn + 2 * apq * cs * sn;                // GPU:122-123
-                const float nqq = app * sn * sn + aqq * cs * cs - 2 * apq * cs * sn;                // GPU:124-125
-                const float npq = (float)(0.5 * (double)(aqq - app) * (double)sn2 + (double)(apq * cs2));   // GPU:126
-                const float nrp = arq * sn + arp * cs;                                               // GPU:129-151
-                const float nrq = arq * cs - arp * sn;
-                if (pair == 0)      { a00 = npp; a11 = nqq; a01 = npq; a02 = nrp; a12 = nrq; }
-                else if (pair == 1) { a00 = npp; a22 = nqq; a02 = npq; a01 = nrp; a12 = nrq; }
-                else                { a11 = npp; a22 = nqq; a12 = npq; a01 = nrp; a02 = nrq; }
-                // eigenvector columns p, q (GPU:154-161)
-                float u0, u1, u2, w0, w1, w2;
-                if (pair == 0)      { u0 = v00; u1 = v10; u2 = v20; w0 = v01; w1 = v11; w2 = v21; }
-                else if (pair == 1) { u0 = v00; u1 = v10; u2 = v20; w0 = v02; w1 = v12; w2 = v22; }
-                else                { u0 = v01; u1 = v11; u2 = v21; w0 = v02; w1 = v12; w2 = v22; }
-                const float nu0 = w0 * sn + u0 * cs, nw0 = w0 * cs - u0 * sn;
-                const float nu1 = w1 * sn + u1 * cs, nw1 = w1 * cs - u1 * sn;
-                const float nu2 = w2 * sn + u2 * cs, nw2 = w2 * cs - u2 * sn;
-                if (pair == 0)      { v00 = nu0; v10 = nu1; v20 = nu2; v01 = nw0; v11 = nw1; v21 = nw2; }
-                else if (pair == 1) { v00 = nu0; v10 = nu1; v20 = nu2; v02 = nw0; v12 = nw1; v22 = nw2; }
-                else                { v01 = nu0; v11 = nu1; v21 = nu2; v02 = nw0; v12 = nw1; v22 = nw2; }
-            }
+        }
+    }
+    // does the loop rotate at all?  (its own first test: the signed a01 or the largest magnitude reaches 0.01)
+    float mxv = a01;
+    { const float d = fabsf(a01); if (d > mxv) mxv = d; }
+    { const float d = fabsf(a02); if (d > mxv) mxv = d; }
+    { const float d = fabsf(a12); if (d > mxv) mxv = d; }
+    const bool rotates = fitted && !(mxv < 0.01f);
+    uint32_t slot = 0;
+    {
+        const uint64_t mk = __ballot(rotates);
+        uint32_t base = 0;
+        if (lane_id() == 0 && mk) base = atomicAdd(&jn, (uint32_t)__popcll(mk));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        slot = base + (uint32_t)__popcll(mk & lanemask_lt());
+        if (rotates) { jq[0][slot] = a00; jq[1][slot] = a11; jq[2][slot] = a22; jq[3][slot] = a01; jq[4][slot] = a02; jq[5][slot] = a12; }
+    }
+    __syncthreads();
+    if (threadIdx.x < jn) {
+        const int t = (int)threadIdx.x;
+        const JacobiOut o = jacobi_3x3(jq[0][t], jq[1][t], jq[2][t], jq[3][t], jq[4][t], jq[5][t]);
+        jq[0][t] = o.d0; jq[1][t] = o.d1; jq[2][t] = o.d2; jq[3][t] = o.z0; jq[4][t] = o.z1; jq[5][t] = o.z2;
+    }
+    __syncthreads();
+    if (!mine) return;
+    float r_out = 0.0f, s_out = 0.0f;
+    if (height != kEmptyElevation) {
+        float tr = -10.0f;                                              // GPU:660-666
+        if (fitted) {
+            float d0 = a00, d1 = a11, d2 = a22, z0 = 0.f, z1 = 0.f, z2 = 1.f;          // no rotation: the eigenvectors are the axes
+            if (rotates) { d0 = jq[0][slot]; d1 = jq[1][slot]; d2 = jq[2][slot]; z0 = jq[3][slot]; z1 = jq[4][slot]; z2 = jq[5][slot]; }
             // z component of the eigenvector of the smallest eigenvalue (first minimum wins, GPU:168-186)
-            float mn = a00, nz = v20;
-            if (mn > a11) { mn = a11; nz = v21; }
-            if (mn > a22) { mn = a22; nz = v22; }
+            float mn = d0, nz = z0;
+            if (mn > d1) { mn = d1; nz = z1; }
+            if (mn > d2) { mn = d2; nz = z2; }
             const float anz = nz > 0 ? nz : -nz;                        // GPU:647-650; acos(1) is exactly 0: spare flat cells the double acos
             const float Slope = anz == 1.0f ? 0.0f : f_acos(anz);
             const float Rough = fabsf(height - mz);
