@@ -1010,13 +1010,16 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     std::vector<gem_frame_params> cut_params;
     std::vector<long long> cut_offsets;
     std::vector<int> orig0;
-    if (in.n_sweeps == 1 && in.src == 0 && in.n > kSweepPoints) {
+    // (Fuse's arrays too, src == 1: a descriptor row holds the units of ONE sweep, k_fuse_list reads one chunk of kChunkUnits of it --
+    //  until round 4 the cut was only made for clouds, and a Fuse of more than 131 072 points that stayed below the sorted pipeline's
+    //  threshold lost every point behind the first 131 072.)
+    if (in.n_sweeps == 1 && in.n > kSweepPoints) {
         const int ns = (int)((in.n + kSweepPoints - 1) / kSweepPoints);
-        cut_params.assign(ns, *in.params);
+        if (in.src == 0) cut_params.assign(ns, *in.params);
         cut_offsets.resize(ns + 1); orig0.resize(ns);
         for (int s = 0; s <= ns; ++s) cut_offsets[s] = std::min<long long>(in.n, (long long)s * kSweepPoints);
         for (int s = 0; s < ns; ++s) orig0[s] = (int)cut_offsets[s];
-        in.n_sweeps = ns; in.params = cut_params.data(); in.offsets = cut_offsets.data(); in.var_updates = nullptr;
+        in.n_sweeps = ns; in.params = in.src == 0 ? cut_params.data() : nullptr; in.offsets = cut_offsets.data(); in.var_updates = nullptr;
     }
     const bool batched = in.n_sweeps > 1;
     const int U = kUnit;
@@ -1145,7 +1148,7 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
         if (pb.tables_recorded) GEM_HIP(h, hipEventSynchronize(pb.tables_done));     // the previous upload from this buffer has been read
         unsigned char* host = static_cast<unsigned char*>(pb.host_tables);
         memset(host, 0, total);
-        for (int s = 0; s < in.n_sweeps; ++s) fill_frame(h, &in.params[s], reinterpret_cast<FrameConst*>(host + o_frames)[s]);
+        for (int s = 0; s < in.n_sweeps; ++s) fill_frame(h, in.src == 0 ? &in.params[s] : nullptr, reinterpret_cast<FrameConst*>(host + o_frames)[s]);
         memcpy(host + o_unit0, unit0.data(), sizeof(int) * (in.n_sweeps + 1));
         memcpy(host + o_first, in.offsets, sizeof(long long) * (in.n_sweeps + 1));
         if (!orig0.empty()) memcpy(host + o_orig, orig0.data(), sizeof(int) * in.n_sweeps);

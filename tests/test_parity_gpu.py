@@ -233,6 +233,30 @@ def test_fuse_arrays_parity(oracle_mod):
     assert_maps_match(gpu, ref)
 
 
+@pytest.mark.parametrize("n", [131072 + 1, 180000, 199656, 200000, 420000])
+@pytest.mark.parametrize("colours", [False, True])
+def test_fuse_arrays_longer_than_one_descriptor_row(oracle_mod, n, colours):
+    """Fuse (gpu_process.cu:1154-1193) with more than 131 072 points whose LATER points reach tiles the earlier ones never touch --
+    a depth image handed over row by row.  The tile pipeline's descriptor rows hold 2048 units of 64 points: longer inputs are cut
+    into sweeps (run_pipeline); until round 4 only clouds were, and a Fuse between 131 073 and the sorted pipeline's threshold
+    (200 000) lost every point behind the first 131 072 (found by the soak once it drove gem_fuse)."""
+    L = 400
+    gpu, ref = make_pair(oracle_mod, L, 0.05)
+    rng = np.random.default_rng(n)
+    idx = np.sort(rng.integers(0, L * L, n)).astype(np.int32)              # cells in increasing order: the map fills row by row
+    idx[rng.integers(0, n, 200)] = -1
+    h = rng.normal(0, 0.2, n).astype(F32); v = rng.uniform(1e-6, 2e-3, n).astype(F32)
+    h[rng.integers(0, n, 100)] = -1.0                                       # the "rejected" sentinel (GPU:482)
+    if colours:
+        R, G, B = (rng.integers(0, 3, n).astype(np.int32) * 90 for _ in range(3)); I = rng.integers(0, 2, n).astype(F32)
+        gpu.fuse(idx, h, v, R, G, B, I); ref.fuse(idx, h, v, R, G, B, I)
+        assert_maps_match(gpu, ref, layers=("elevation", "variance", "intensity", "color_r", "color_g", "color_b"))
+    else:
+        gpu.fuse(idx, h, v); ref.fuse(idx, h, v)
+        assert_maps_match(gpu, ref)
+    assert (ref.layer("elevation")[L - 3:] != -10).sum() > 100               # the last rows of the map did get their points
+
+
 @pytest.mark.parametrize("threads", [0, 1, 4, 8])
 def test_host_arrays_through_the_pinned_staging_and_through_the_runtime(oracle_mod, threads):
     """Caller-owned pageable arrays (the node's: gpu_process.cu:1096-1141, :1165-1192, :1283-1291) travel through the handle's pinned

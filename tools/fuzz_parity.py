@@ -7,6 +7,7 @@ every step compared bit for bit with the CPU oracle (test infrastructure: this t
 Prints one line per scenario and a final summary; exit code 1 on the first mismatch (the scenario's seed is printed).
 """
 import argparse
+import os
 import sys
 import time
 from pathlib import Path
@@ -58,7 +59,13 @@ def scenario(seed):
     gpu = ElevationMap(L, res, debug=knobs); ora = oracle.OracleMap(L, res)
     if lowest:
         gpu.set_lowest_tracking(True)
-    gpu.debug_set("copy_threads", int(rng.choice([0, 1, 4, 4, 8])))      # host arrays: the runtime's path, or the pinned staging + copy threads
+    ct = int(rng.choice([0, 1, 4, 4, 8]))                      # host arrays: the runtime's path, or the pinned staging + copy threads
+    try:
+        gpu.debug_set("copy_threads", ct)
+    except Exception:                                          # (a library from before the knob, when bisecting)
+        ct = -1
+    if os.environ.get("FUZZ_COPY_THREADS") and ct >= 0:                    # (reproducing a scenario with another route for its host arrays)
+        gpu.debug_set("copy_threads", int(os.environ["FUZZ_COPY_THREADS"]))
     extent = 0.5 * L * res
     pts_total = 0
     steps = int(rng.integers(2, 6))
@@ -83,10 +90,12 @@ def scenario(seed):
             frames.append(f); clouds.append(c)
         pts_total += sum(c.shape[0] for c in clouds)
         incs = [float(rng.uniform(0, 1e-4)) for _ in range(n_sweeps)] if rng.random() < 0.6 else None
+        entry = "add_batch"
         if n_sweeps == 1 and rng.random() < 0.5:
             if incs:
                 gpu.mapvar_update(incs[0]); ora.mapvar_update(incs[0])
             how = rng.random()
+            entry = "process_points + fuse (host arrays)" if how < 0.2 else ("add (device cloud)" if how < 0.75 else "add (host cloud)")
             if how < 0.2:                                      # the node's two calls with host arrays (Process_points, then Fuse)
                 c0 = clouds[0]
                 g = gpu.process_points(frames[0], c0[:, 0], c0[:, 1], c0[:, 2]); o = ora.process_points(frames[0], c0[:, 0], c0[:, 1], c0[:, 2])
@@ -104,7 +113,7 @@ def scenario(seed):
                 if incs:
                     ora.mapvar_update(incs[k])
                 ora.add(frames[k], clouds[k])
-        compare(gpu, ora, f"seed {seed} step {step} after the fusion ({knobs}, L {L}, sweeps {n_sweeps})", ("elevation", "variance") + (("lowest",) if lowest else ()))
+        compare(gpu, ora, f"seed {seed} step {step} after the fusion by {entry}, copy_threads {ct}, {[c.shape[0] for c in clouds]} points ({knobs}, L {L}, sweeps {n_sweeps})", ("elevation", "variance") + (("lowest",) if lowest else ()))
         if lowest and rng.random() < 0.7:
             gpu.map_feature(fetch=False); ora.map_feature()
             gpu.debug_set("ray_lanes", int(rng.choice([1, 4, 8, 16]))); gpu.debug_set("ray_depth", int(rng.choice([4, 8])))
