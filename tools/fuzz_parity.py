@@ -82,7 +82,7 @@ def scenario(seed):
             f = synth._frame_for(T, SensorModel.velodyne(), RejectFilter.reference() if rng.random() < 0.2 else None)
             if rng.random() < 0.3:
                 f.lower, f.upper = -3.0, 3.0
-            n = int(rng.choice([1, 63, 64, 1000, 4097, 30000, 131072, 200000, 300000]))
+            n = int(rng.choice([1, 63, 64, 1000, 4097, 30000, 131072, 131073, 150000, 199999, 200000, 300000]))
             n = min(n, 2_000_000 // n_sweeps)
             c = make_cloud(rng, int(rng.integers(3)), n, extent, T)
             if c.shape[0] == 0:
@@ -90,22 +90,39 @@ def scenario(seed):
             frames.append(f); clouds.append(c)
         pts_total += sum(c.shape[0] for c in clouds)
         incs = [float(rng.uniform(0, 1e-4)) for _ in range(n_sweeps)] if rng.random() < 0.6 else None
-        entry = "add_batch"
+        entry = "add_batch"; attr_layers = ()
         if n_sweeps == 1 and rng.random() < 0.5:
             if incs:
                 gpu.mapvar_update(incs[0]); ora.mapvar_update(incs[0])
             how = rng.random()
-            entry = "process_points + fuse (host arrays)" if how < 0.2 else ("add (device cloud)" if how < 0.75 else "add (host cloud)")
-            if how < 0.2:                                      # the node's two calls with host arrays (Process_points, then Fuse)
-                c0 = clouds[0]
-                g = gpu.process_points(frames[0], c0[:, 0], c0[:, 1], c0[:, 2]); o = ora.process_points(frames[0], c0[:, 0], c0[:, 1], c0[:, 2])
+            c0 = clouds[0]; n0 = c0.shape[0]
+            coloured = bool(rng.random() < 0.35)                 # colours / intensity ride along: the attribute layers are compared too
+            if coloured:
+                attr_layers = ("intensity", "color_r", "color_g", "color_b")
+            oi = np.ascontiguousarray(rng.permutation(n0).astype(np.int32)) if rng.random() < 0.3 else None     # (the reject filter reads it)
+            entry = ("process_points + fuse (host arrays)" if how < 0.25 else ("add (device cloud)" if how < 0.65 else "add (host cloud)")) + \
+                    (", colours" if coloured else "") + (", orig_index" if oi is not None else "")
+            if how < 0.25:                                     # the node's two calls with host arrays (Process_points, then Fuse)
+                g = gpu.process_points(frames[0], c0[:, 0], c0[:, 1], c0[:, 2], orig_index=oi); o = ora.process_points(frames[0], c0[:, 0], c0[:, 1], c0[:, 2], orig_index=oi)
                 for k in ("index", "var", "x_ts", "y_ts", "height"):
                     if not np.array_equal(g[k], o[k]):
                         raise AssertionError(f"seed {seed} step {step}: process_points {k}")
-                gpu.fuse(g["index"], g["height"], g["var"]); ora.fuse(o["index"], o["height"], o["var"])
+                if coloured:
+                    R, G, B = (rng.integers(0, 3, n0).astype(np.int32) * 100 for _ in range(3)); I = rng.integers(0, 3, n0).astype(F32)
+                    gpu.fuse(g["index"], g["height"], g["var"], R, G, B, I); ora.fuse(o["index"], o["height"], o["var"], R, G, B, I)
+                else:
+                    gpu.fuse(g["index"], g["height"], g["var"]); ora.fuse(o["index"], o["height"], o["var"])
             else:
-                dev = torch.from_numpy(clouds[0]).cuda() if how < 0.75 else clouds[0]
-                gpu.add(frames[0], dev); ora.add(frames[0], clouds[0])
+                rgb = None
+                if coloured:
+                    rgb = ((rng.integers(0, 3, n0).astype(np.uint32) * 100) << 16) | ((rng.integers(0, 3, n0).astype(np.uint32) * 100) << 8) | (rng.integers(0, 3, n0).astype(np.uint32) * 100)
+                    c0 = c0.copy(); c0[:, 3] = rng.integers(0, 3, n0).astype(F32)
+                if how < 0.65:
+                    dv = lambda a, dt=None: None if a is None else torch.from_numpy(a if dt is None else a.view(dt)).cuda()
+                    gpu.add(frames[0], dv(c0), dv(rgb, np.int32), dv(oi))
+                else:
+                    gpu.add(frames[0], c0, rgb, oi)
+                ora.add(frames[0], c0, rgb, oi)
         else:
             off = np.concatenate([[0], np.cumsum([c.shape[0] for c in clouds])])
             gpu.add_batch(frames, torch.from_numpy(np.concatenate(clouds, 0)).cuda(), off, incs)
@@ -113,7 +130,7 @@ def scenario(seed):
                 if incs:
                     ora.mapvar_update(incs[k])
                 ora.add(frames[k], clouds[k])
-        compare(gpu, ora, f"seed {seed} step {step} after the fusion by {entry}, copy_threads {ct}, {[c.shape[0] for c in clouds]} points ({knobs}, L {L}, sweeps {n_sweeps})", ("elevation", "variance") + (("lowest",) if lowest else ()))
+        compare(gpu, ora, f"seed {seed} step {step} after the fusion by {entry}, copy_threads {ct}, {[c.shape[0] for c in clouds]} points ({knobs}, L {L}, sweeps {n_sweeps})", ("elevation", "variance") + attr_layers + (("lowest",) if lowest else ()))
         if lowest and rng.random() < 0.7:
             gpu.map_feature(fetch=False); ora.map_feature()
             gpu.debug_set("ray_lanes", int(rng.choice([1, 4, 8, 16]))); gpu.debug_set("ray_depth", int(rng.choice([4, 8])))
