@@ -475,9 +475,23 @@ def node_host_arrays(emap_cls, dev, reps: int = 40, copy_threads=None):
     m.synchronize(); m.close()
     us = {k: float(np.median(v)) for k, v in t.items()}
     total = sum(us.values())
+    # which socket the calling thread ran on, against the GPUs' (this frame costs ~10 % more from the far socket: tools/dbg/numa_ab.sh)
+    numa = {"caller_node": None, "gpu_nodes": []}
+    try:
+        import glob, os
+        cpu = os.sched_getcpu()
+        for nd in glob.glob("/sys/devices/system/node/node[0-9]*"):
+            lst = open(nd + "/cpulist").read().strip()
+            for part in lst.split(","):
+                a, _, b = part.partition("-")
+                if int(a) <= cpu <= int(b or a):
+                    numa["caller_node"] = int(nd.rsplit("node", 1)[1])
+        numa["gpu_nodes"] = sorted({int(open(f).read()) for f in glob.glob("/sys/class/drm/card*/device/numa_node") if open(f).read().strip() not in ("", "-1")})
+    except Exception:
+        pass
     return {"workload": "the node's frame with caller-owned HOST arrays: Mapvar_update + Process_points + Fuse (colours) + Map_feature (nine layers to the host) + "
                         "Raytracing, C2 sweep with the reference's reject filter, 600 x 600 map",
-            "copy_threads": m_threads, "us_per_frame": total, "us_per_call": us, "host_us_per_frame_in_transfers": xfer, "bytes_over_pcie_per_frame": 12.0 * n + 20.0 * n + 28.0 * n + 36.0 * L * L,
+            "copy_threads": m_threads, "numa": numa, "us_per_frame": total, "us_per_call": us, "host_us_per_frame_in_transfers": xfer, "bytes_over_pcie_per_frame": 12.0 * n + 20.0 * n + 28.0 * n + 36.0 * L * L,
             "value": n / (total * 1e-6), "unit": "points/s"}
 
 

@@ -1937,14 +1937,18 @@ int gem_show(gem_handle* h, double map_length, double resolution, const double p
                            visual ? reinterpret_cast<float*>(d + o_vis) : nullptr, (points_xyz || points_rgb) ? reinterpret_cast<float*>(d + o_xyz) : nullptr,
                            points_rgb ? d + o_rgb : nullptr, image_bgr ? d + o_img : nullptr, reinterpret_cast<uint32_t*>(d + o_total)));
     uint32_t n = 0;
-    GEM_HIP(h, hipMemcpyAsync(&n, d + o_total, 4, hipMemcpyDeviceToHost, h->stream));
-    if (visual) GEM_HIP(h, hipMemcpyAsync(visual, d + o_vis, cells * 36, hipMemcpyDeviceToHost, h->stream));
-    if (image_bgr) GEM_HIP(h, hipMemcpyAsync(image_bgr, d + o_img, cells * 3, hipMemcpyDeviceToHost, h->stream));
-    GEM_HIP(h, hipStreamSynchronize(h->stream));
+    {   // (through the pinned staging buffer like the node's other host arrays: download_arrays)
+        HostXfer down[3] = {{&n, d + o_total, 4}, {nullptr, nullptr, 0}, {nullptr, nullptr, 0}};
+        int nd = 1;
+        if (visual) down[nd++] = {visual, d + o_vis, cells * 36};
+        if (image_bgr) down[nd++] = {image_bgr, d + o_img, cells * 3};
+        if ((rc = download_arrays(h, down, nd, 0))) return rc;
+    }
     if (n) {                                            // only the kept cells' points travel
-        if (points_xyz) GEM_HIP(h, hipMemcpyAsync(points_xyz, d + o_xyz, (size_t)n * 12, hipMemcpyDeviceToHost, h->stream));
-        if (points_rgb) GEM_HIP(h, hipMemcpyAsync(points_rgb, d + o_rgb, (size_t)n * 3, hipMemcpyDeviceToHost, h->stream));
-        GEM_HIP(h, hipStreamSynchronize(h->stream));
+        HostXfer down[2]; int nd = 0;
+        if (points_xyz) down[nd++] = {points_xyz, d + o_xyz, (size_t)n * 12};
+        if (points_rgb) down[nd++] = {points_rgb, d + o_rgb, (size_t)n * 3};
+        if (nd && (rc = download_arrays(h, down, nd, 0))) return rc;
     }
     if (out_count) *out_count = (int)n;
     return GEM_OK;

@@ -1113,6 +1113,17 @@ __global__ __launch_bounds__(256) void k_update_height(float* __restrict__ eleva
 __global__ __launch_bounds__(256) void k_copy_list(CopyList l)
 {
     const CopyPiece pc = l.piece[blockIdx.y];
+    if ((reinterpret_cast<uintptr_t>(pc.src) | reinterpret_cast<uintptr_t>(pc.dst)) & 15) {        // (block-uniform) a source that is only word-aligned
+        const size_t n4 = pc.bytes / 4;
+        const uint32_t* __restrict__ s4 = static_cast<const uint32_t*>(pc.src);
+        uint32_t* __restrict__ d4 = static_cast<uint32_t*>(pc.dst);
+        const bool words = ((reinterpret_cast<uintptr_t>(pc.src) | reinterpret_cast<uintptr_t>(pc.dst)) & 3) == 0;
+        if (words) for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) d4[i] = s4[i];
+        const size_t done = words ? n4 * 4 : 0;
+        for (size_t i = done + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pc.bytes; i += (size_t)gridDim.x * blockDim.x)
+            static_cast<unsigned char*>(pc.dst)[i] = static_cast<const unsigned char*>(pc.src)[i];
+        return;
+    }
     const size_t n16 = pc.bytes / 16;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const u32x4* __restrict__ s = static_cast<const u32x4*>(pc.src);
