@@ -1834,7 +1834,8 @@ int gem_set_layer(gem_handle* h, int layer, const void* src_host)
     if (!dst) return fail(h, GEM_ERR_INVALID, "gem_set_layer: bad layer");
     int rc = flush_pending(h, false);
     if (rc) return rc;
-    GEM_HIP(h, hipMemcpyAsync(dst, src_host, (size_t)h->cells * 4, hipMemcpyHostToDevice, h->stream));
+    HostXfer up{const_cast<void*>(src_host), dst, (size_t)h->cells * 4};
+    if ((rc = upload_arrays(h, &up, 1))) return rc;
     GEM_HIP(h, hipStreamSynchronize(h->stream));
     if (layer == GEM_LAYER_VARIANCE) h->floor_dirty = true;
     return GEM_OK;
@@ -2038,13 +2039,11 @@ int gem_colorize(gem_handle* h, const gem_camera* cam, int n, float* xyzi, const
     int rc;
     if ((rc = ensure(h, h->stage, b_xyzi + b_rgb + b_img))) return rc;
     unsigned char* d = static_cast<unsigned char*>(h->stage.p);
-    GEM_HIP(h, hipMemcpyAsync(d, xyzi, N * 16, hipMemcpyHostToDevice, h->stream));
-    GEM_HIP(h, hipMemcpyAsync(d + b_xyzi + b_rgb, image_bgr, b_img, hipMemcpyHostToDevice, h->stream));
+    HostXfer up[2] = {{xyzi, d, N * 16}, {const_cast<unsigned char*>(image_bgr), d + b_xyzi + b_rgb, b_img}};
+    if ((rc = upload_arrays(h, up, 2))) return rc;
     if ((rc = colorize_device(h, cam, n, reinterpret_cast<float*>(d), d + b_xyzi + b_rgb, row_stride, reinterpret_cast<uint32_t*>(d + b_xyzi)))) return rc;
-    GEM_HIP(h, hipMemcpyAsync(xyzi, d, N * 16, hipMemcpyDeviceToHost, h->stream));
-    GEM_HIP(h, hipMemcpyAsync(rgb, d + b_xyzi, N * 4, hipMemcpyDeviceToHost, h->stream));
-    GEM_HIP(h, hipStreamSynchronize(h->stream));
-    return GEM_OK;
+    HostXfer down[2] = {{xyzi, d, N * 16}, {rgb, d + b_xyzi, N * 4}};
+    return download_arrays(h, down, 2, 0);
 }
 
 int gem_set_lowest_tracking(gem_handle* h, int enabled)
