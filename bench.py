@@ -478,8 +478,8 @@ def node_host_arrays(emap_cls, dev, reps: int = 40, copy_threads=None):
     # which socket the calling thread ran on, against the GPUs' (this frame costs ~10 % more from the far socket: tools/dbg/numa_ab.sh)
     numa = {"caller_node": None, "gpu_nodes": []}
     try:
-        import glob, os
-        cpu = os.sched_getcpu()
+        import ctypes, glob
+        cpu = ctypes.CDLL(None).sched_getcpu()
         for nd in glob.glob("/sys/devices/system/node/node[0-9]*"):
             lst = open(nd + "/cpulist").read().strip()
             for part in lst.split(","):
