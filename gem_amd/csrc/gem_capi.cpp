@@ -115,6 +115,7 @@ struct gem_handle {
     bool fast_laser = true;             // frames that qualify use the zero-rotation-variance form of the laser variance (fill_frame; debug knob)
     bool rank_by_ballot = false;        // k_sort_scatter ranks by ballot in every pass (debug knob)
     bool lane_sort = true;              // k_fuse_block: cells to threads by record count (debug knob)
+    bool ride_events = true;            // the sort's last dispatch carries the event the walk waits for (no marker behind it)
     int  walk_lds_pad = 0;              // k_fuse_block: extra dynamic LDS per workgroup (debug knob: fewer workgroups per CU)
     int  walk_prio = 4096;              // k_fuse_block: blocks of at least this many records run at raised issue priority (debug knob, 0 = off)
     bool light_fast = true;             // k_fuse_block's light rounds by arrival slots + sorting network (debug knob)
@@ -567,7 +568,7 @@ struct PassInput {
 
 // (hipEventDisableSystemFence on these events was measured -- no gain on C4 / C5 -- and is NOT used: the multi-XCD part needs the
 //  release / acquire a recorded event stands for, for one stream's kernels to see another stream's writes)
-constexpr unsigned  kDeviceEventFlags = hipEventDisableTiming;
+constexpr unsigned  kDeviceEventFlags = hipEventDisableTiming | hipEventDisableSystemFence;   // (events between the handle's own streams: nothing on the host reads data behind them)
 constexpr int       kUnit = 64;                      // points per unit (one wave of k_bin_wave)
 constexpr long long kSweepPoints = 2048ll * kUnit;   // a single cloud longer than this is processed as a batch of sweeps of this size
 
@@ -905,12 +906,18 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     wa.count_per_pass = batched ? 0 : 1;
 
     if (h->counting) GEM_HIP(h, hipMemsetAsync(h->d_counters, 0, 2 * sizeof(unsigned long long), h->stream));
+    bool ride_bin = false;
     {
         // (a third pass is accounted with the second: count / scan / scatter of the higher digits)
         // (event pairs only for the kernels that are launched: the elapsed time of a pair that was never recorded is an error)
         const bool two = geo.n_passes >= 2, three = geo.n_passes == 3;
         Timed t0(h, 3), t1(h, 4), t2(h, 5), t3(h, two ? 6 : -1), t4(h, two ? 7 : -1), t5(h, two ? 8 : -1), t6(h, three ? 6 : -1), t7(h, three ? 7 : -1), t8(h, three ? 8 : -1);
-        const LaunchEvents ev[9] = {t0.events(), t1.events(), t2.events(), t3.events(), t4.events(), t5.events(), t6.events(), t7.events(), t8.events()};
+        LaunchEvents ev[9] = {t0.events(), t1.events(), t2.events(), t3.events(), t4.events(), t5.events(), t6.events(), t7.events(), t8.events()};
+        // The walk waits for the sort across streams: as the STOP EVENT of the sort's last dispatch the event is seen 3 us earlier
+        // than a marker recorded behind it (tools/ubench/handover.hip: 7 against 10 us) -- when that kernel is the last thing on the
+        // sort's stream before the walk (no k_block_prefix, no strip search behind it) and nothing is being timed.
+        ride_bin = overlap && h->ride_events && !h->timing && !shard && !(geo.block_form && geo.n_passes > 1);
+        if (ride_bin) ev[3 * geo.n_passes - 1].stop = pb.bin_done;
         int src = in.src;
         if (src == 0 && batched) { if (batch_src > 0) src = batch_src; }
         else if (src == 0) {
@@ -959,7 +966,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
         wa.ranges = static_cast<const uint2*>(pb.s_ranges.p);
     }
     if (overlap) {
-        GEM_HIP(h, hipEventRecord(pb.bin_done, sbin));
+        if (!ride_bin) GEM_HIP(h, hipEventRecord(pb.bin_done, sbin));
         GEM_HIP(h, hipStreamWaitEvent(h->stream, pb.bin_done, 0));
     }
     h->dbg_rows = 0;
@@ -2156,6 +2163,7 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "cache_tables")       h->cache_tables = value != 0;
     else if (k == "light_fast")         h->light_fast = value != 0;
     else if (k == "walk_lds_pad")       { if (value < 0 || value > 100 * 1024) return fail(h, GEM_ERR_INVALID, "walk_lds_pad: 0 .. 102400 bytes"); h->walk_lds_pad = (int)value; }
+    else if (k == "ride_events")        { if (value < 0 || value > 1) return fail(h, GEM_ERR_INVALID, "ride_events: 0 or 1"); h->ride_events = value != 0; }
     else if (k == "copy_threads")       { if (value < 0 || value > gem::CopyPool::kMaxThreads) return fail(h, GEM_ERR_INVALID, "copy_threads: 0 (the runtime's pageable path) .. 16"); h->copy_threads = (int)value; }
     else if (k == "walk_prio")          { if (value < 0 || value > (1 << 30)) return fail(h, GEM_ERR_INVALID, "walk_prio: 0 (off) or a record count"); h->walk_prio = (int)value; }
     else if (k == "blk_batch")          { if (value != 0 && value != 512 && value != 2048) return fail(h, GEM_ERR_INVALID, "blk_batch: 0 (by pass), 512 or 2048"); h->blk_batch = (int)value; }

@@ -1422,7 +1422,7 @@ __global__ __launch_bounds__(256) void k_map_feature(const float* __restrict__ e
 // which measures the kernel alone -- no launch gap, no event-record overhead.
 #define GEM_LAUNCH(k, grid, block, lds, st, ev, ...)                                              \
     do {                                                                                           \
-        if ((ev).start) hipExtLaunchKernelGGL(k, grid, block, (uint32_t)(lds), st, (ev).start, (ev).stop, 0, __VA_ARGS__); \
+        if ((ev).start || (ev).stop) hipExtLaunchKernelGGL(k, grid, block, (uint32_t)(lds), st, (ev).start, (ev).stop, 0, __VA_ARGS__); \
         else hipLaunchKernelGGL(k, grid, block, lds, st, __VA_ARGS__);                             \
     } while (0)
 

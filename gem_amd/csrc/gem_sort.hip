@@ -1612,7 +1612,7 @@ __global__ __launch_bounds__(64) void k_strip_bounds(const uint32_t* __restrict_
 // ------------------------------------------------------------------------------------------
 #define GEM_LAUNCH(k, grid, block, lds, st, ev, ...)                                              \
     do {                                                                                           \
-        if ((ev).start) hipExtLaunchKernelGGL(k, grid, block, (uint32_t)(lds), st, (ev).start, (ev).stop, 0, __VA_ARGS__); \
+        if ((ev).start || (ev).stop) hipExtLaunchKernelGGL(k, grid, block, (uint32_t)(lds), st, (ev).start, (ev).stop, 0, __VA_ARGS__); \
         else hipLaunchKernelGGL(k, grid, block, lds, st, __VA_ARGS__);                             \
     } while (0)
 
