@@ -9,7 +9,8 @@
 // threads, a group of arrays at a time, so that the link works on one group while the threads move its neighbour.  This file is
 // only that thread pool: memcpy of a list of segments, cut into pieces, on the calling thread and `threads - 1` workers.
 //
-// Workers are process-lifetime, detached, asleep on a condition variable between frames; after a job they poll for the next one
+// Workers are process-lifetime (the library must stay loaded once a call with host arrays has been made), detached, asleep on a
+// condition variable between frames; after a job they poll for the next one
 // for kSpinNs (a frame's calls follow each other within that time) so that the wake-up latency is paid once per frame.  Each job
 // is its own object held by a shared_ptr: a worker that wakes late works on the job it was woken for -- by then empty -- and never
 // sees the next one half built.

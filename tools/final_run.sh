@@ -18,5 +18,6 @@ timeout -s KILL 60 tools/ubench/bin/chain_noslp > gpurun_out/final/ubench_chain.
 timeout -s KILL 100 python tools/dbg/host_cost.py > gpurun_out/final/host_cost.txt 2>/dev/null
 timeout -s KILL 300 bash tools/profile_host_path.sh r04 > gpurun_out/final/prof_host_path.log 2>&1
 timeout -s KILL 60 tools/ubench/bin/dispatch > gpurun_out/final/ubench_dispatch.txt 2>/dev/null
+timeout -s KILL 60 tools/ubench/bin/handover > gpurun_out/final/ubench_handover.txt 2>/dev/null
 timeout -s KILL 100 python tools/fuzz_parity.py --seconds 90 --seed 9 > gpurun_out/final/fuzz9.log 2>&1; tail -1 gpurun_out/final/fuzz9.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final/smoke.log 2>&1; tail -2 gpurun_out/final/smoke.log
