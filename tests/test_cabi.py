@@ -58,6 +58,16 @@ def test_the_product_reads_no_environment_variables():
         assert "getenv" not in text and "os.environ" not in text, p
 
 
+def test_every_debug_key_is_documented_in_the_debug_header():
+    """gem_debug_set / gem_debug_get accept a closed list of keys (gem_capi.cpp); include/gem_hip_debug.h names every one of them."""
+    import re
+    src = (ROOT / "gem_amd" / "csrc" / "gem_capi.cpp").read_text()
+    hdr = (ROOT / "include" / "gem_hip_debug.h").read_text()
+    keys = sorted(set(re.findall(r'k == "([a-z_0-9]+)"', src)))
+    assert len(keys) >= 40
+    assert [k for k in keys if f'"{k}"' not in hdr] == []
+
+
 def test_the_copy_thread_pool_moves_every_byte(tmp_path):
     """gem_amd/csrc/gem_hostcopy.hpp on its own (tests/cpp/hostcopy_pool.cpp): thread counts 1..8, sizes around the piece size, workers
     polling and asleep, concurrent callers."""
