@@ -89,5 +89,36 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     return LIB
 
 
+def build_variant(name: str, defines: str, verbose: bool = False) -> Path:
+    """An A/B build with extra -D flags into gem_amd/lib_ab/<name>/libgem_hip.so (tools only: tools/ab_run.sh copies it over the
+    library of the GPU box's scratch copy of the tree, variant by variant; the product library here is not touched)."""
+    out = ROOT / "lib_ab" / name
+    objdir = out / "obj"
+    objdir.mkdir(parents=True, exist_ok=True)
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cflags = [f for f in FLAGS if f != "-shared"] + defines.split()
+    jobs = []
+    for src in SOURCES:
+        obj = objdir / (src.stem + ".o")
+        cmd = [hipcc_path(), *cflags, "-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd))
+        jobs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, proc in jobs:
+        o, _ = proc.communicate()
+        if proc.returncode != 0:
+            raise RuntimeError(f"{src.name}: hipcc failed ({proc.returncode}):\n{o}")
+    lib = out / "libgem_hip.so"
+    res = subprocess.run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", *[str(objdir / (s.stem + ".o")) for s in SOURCES], "-o", str(lib),
+                          f"-L{rocm}/lib", "-lrccl", "-pthread", f"-Wl,-rpath,{rocm}/lib"], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc (link) failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    if len(sys.argv) >= 3 and sys.argv[1] == "--variant":          # python -m gem_amd.build --variant NAME "-DX=1 -DY=2"
+        print(build_variant(sys.argv[2], " ".join(sys.argv[3:]), verbose=True))
+    else:
+        print(build(force=True, verbose=True))

@@ -171,6 +171,7 @@ struct gem_handle {
         int nstrips = 0, n_global_sweeps = 0;
         long long points = 0;                                          // points this device sorted for the step
         int slot = -1;                                                 // pass-buffer set the sort ran in on a binning stream (its bin_done / fuse_done events), -1: on the handle's stream
+        hipStream_t stream = nullptr;                                  // the stream the sort was enqueued on
     } shard;
     // A step of gem_add_sharded_device whose SECOND HALF -- exchange, walk, all-gather of the layers if one was asked for -- is
     // still to come: the call returns once the step's sort and the all-gather of its strip boundaries are enqueued; the next call
@@ -212,6 +213,7 @@ struct gem_handle {
     unsigned ray_calls = 0;
     Arena color;        // gem_colorize: its own sort arrays and tables (never shared with a pass in flight on the binning stream)
     bool  dbg_on = false;
+    bool  dbg_frame = false;            // debug knob: with the stamps on, a stream of single sweeps still runs as k_frame (its tiles AND its binning blocks are stamped)
     long long sort_fallbacks = 0;      // passes whose forced sorted form / pass count did not fit the map and took the other form (gem_debug_get)
     long long arena_allocations = 0;   // hipMalloc calls of ensure() so far (gem_debug_get: a stream of frames after gem_reserve must not add any)
     int   dbg_rows = 0;  // rows of `dbg` the last pass wrote, if it was a block-sorted one (else h->T rows)
@@ -231,6 +233,12 @@ int fail(gem_handle* h, int code, const char* what, hipError_t e = hipSuccess)
 
 #define GEM_HIP(h, call)                                                        \
     do { hipError_t _e = (call); if (_e != hipSuccess) return fail(h, GEM_ERR_HIP, #call, _e); } while (0)
+
+// ... inside a multi-rank step, between its collectives: a rank that fails there takes the communicators down with it, so that the
+// peers' pending receives fail instead of waiting for it (step_abort)
+int step_abort(gem_handle* h, int rc);
+#define GEM_HIP_STEP(h, call)                                                   \
+    do { hipError_t _e = (call); if (_e != hipSuccess) return step_abort(h, fail(h, GEM_ERR_HIP, #call, _e)); } while (0)
 
 int ensure(gem_handle* h, Arena& a, size_t bytes)
 {
@@ -314,7 +322,10 @@ int upload_arrays(gem_handle* h, const HostXfer* x, int n)
     for (int i = 0; i < n;) {
         int e = i + 1;
         size_t len = pad(x[i].bytes);
-        while (e < n && static_cast<unsigned char*>(x[e].dev) == static_cast<unsigned char*>(x[i].dev) + len) len += pad(x[e++].bytes);
+        while (e < n && e - i < 16 && static_cast<unsigned char*>(x[e].dev) == static_cast<unsigned char*>(x[i].dev) + len) len += pad(x[e++].bytes);   // (a region has at most 16 members: segs[])
+        // the DMA ends with the region's last BYTE: the padding behind the last member belongs to nobody (the callers size their
+        // device arrays by what they hold, not by the staging buffer's stride)
+        const size_t real_len = len - pad(x[e - 1].bytes) + x[e - 1].bytes;
         const size_t group = pad(len <= (8u << 20) ? std::max<size_t>(len / 2, 512u << 10) : (4u << 20));
         for (size_t a = 0; a < len; a += group) {
             const size_t b = std::min(len, a + group);
@@ -322,13 +333,14 @@ int upload_arrays(gem_handle* h, const HostXfer* x, int n)
             size_t m_off = 0;
             for (int m = i; m < e; ++m) {                                           // the members' parts inside [a, b)
                 const size_t lo = std::max(a, m_off), hi = std::min(b, m_off + x[m].bytes);
-                if (lo < hi && ns < 16) segs[ns++] = {stg + off + lo, static_cast<const unsigned char*>(x[m].host) + (lo - m_off), hi - lo};
+                if (lo < hi) segs[ns++] = {stg + off + lo, static_cast<const unsigned char*>(x[m].host) + (lo - m_off), hi - lo};
                 m_off += pad(x[m].bytes);
             }
             const long long t0 = host_ns();
             gem::CopyPool::get().run(segs, ns, h->copy_threads);
             const long long t1 = host_ns();
-            GEM_HIP(h, hipMemcpyAsync(static_cast<unsigned char*>(x[i].dev) + a, stg + off + a, b - a, hipMemcpyHostToDevice, h->stream));
+            const size_t b_real = std::min(b, real_len);
+            if (a < b_real) GEM_HIP(h, hipMemcpyAsync(static_cast<unsigned char*>(x[i].dev) + a, stg + off + a, b_real - a, hipMemcpyHostToDevice, h->stream));
             h->xfer_ns[0] += t1 - t0; h->xfer_ns[1] += host_ns() - t1;
         }
         off += len;
@@ -504,6 +516,7 @@ int flush_deferred(gem_handle* h)
     if (!h->deferred.valid) return GEM_OK;
     h->deferred.valid = false;
     h->main_reads_pb = true;
+    if (h->dbg_frame) h->deferred.fa.dbg = nullptr;            // (the stamps of the last k_frame stay readable: this flush is not the launch being profiled)
     Timed t(h, 1);
     GEM_HIP(h, launch_fuse(h->stream, h->deferred.fa, h->deferred.ts, h->deferred.attr, h->fuse_variant, t.events()));
     return GEM_OK;
@@ -566,9 +579,12 @@ struct PassInput {
     const int* f_R = nullptr; const int* f_G = nullptr; const int* f_B = nullptr; const float* f_I = nullptr;
 };
 
-// (hipEventDisableSystemFence on these events was measured -- no gain on C4 / C5 -- and is NOT used: the multi-XCD part needs the
-//  release / acquire a recorded event stands for, for one stream's kernels to see another stream's writes)
-constexpr unsigned  kDeviceEventFlags = hipEventDisableTiming | hipEventDisableSystemFence;   // (events between the handle's own streams: nothing on the host reads data behind them)
+// Events between the handle's OWN streams on its own device (a pass's sort -> its walk, a walk -> the sort that reuses its buffers)
+// carry no system-scope fence: the kernel boundary already writes the producer's L2 lines back for the consumer's XCDs, and
+// nothing on the host or on another device reads data behind them (round 4: C3 -1.8 us, C4 -2.2 us per call).  Whatever a PEER
+// device or the host reads -- the record exchange and the all-gathers of the multi-rank step -- is ordered by events WITH the
+// fence (ev_sorted and the other step events, comm_attach), never by these.
+constexpr unsigned  kDeviceEventFlags = hipEventDisableTiming | hipEventDisableSystemFence;
 constexpr int       kUnit = 64;                      // points per unit (one wave of k_bin_wave)
 constexpr long long kSweepPoints = 2048ll * kUnit;   // a single cloud longer than this is processed as a batch of sweeps of this size
 
@@ -787,6 +803,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
         const size_t o_var = o_first + sizeof(long long) * (in.n_sweeps + 1);
         const size_t o_orig = o_var + sizeof(float) * in.n_sweeps;
         const size_t total = o_orig + sizeof(int) * in.n_sweeps;
+        if (total > pb.tables.cap) pb.tab_key.clear();               // (a new allocation holds nothing, even at the old address)
         if ((rc = ensure(h, pb.tables, total))) return rc;
         batch_tables_key(h, in, 0, pb.tables.p, chunk0, h->key_scratch);
         const bool tables_cached = h->cache_tables && h->key_scratch == pb.tab_key;
@@ -944,7 +961,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
         GEM_HIP(h, launch_block_prefix(sbin, sa.blk_cnt, 4 * T, static_cast<uint2*>(pb.s_ranges.p)));
         pb.blkcnt_dirty = false;
         sd.hv = final_b ? sa.hv_b : sa.hv_a; sd.key = keys; sd.ranges = static_cast<const uint2*>(pb.s_ranges.p);
-        sd.d_bounds = d_bounds; sd.nstrips = shard->nstrips; sd.slot = overlap ? (int)slot : -1;
+        sd.d_bounds = d_bounds; sd.nstrips = shard->nstrips; sd.slot = overlap ? (int)slot : -1; sd.stream = sbin;
         h->stats.points_in = in.n;
         if (shard->bounds_stay_on_device) {                  // gem_add_sharded_device all-gathers them from where they are
             for (int k = 0; k <= shard->nstrips; ++k) sd.bounds[k] = 0;
@@ -1087,7 +1104,7 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     bool overlap = h->overlap && in.n >= h->overlap_min_points && h->stream == h->own_stream && !h->counting && !h->dbg_on;
     // one launch per frame for a stream of single sweeps (k_frame): needs the other half of the double buffer
     const bool defer = h->defer && in.device_input && in.src == 0 && !batched && (attr & 3) == 0 && ts == 4 && !overlap &&
-                       !h->counting && !h->dbg_on;
+                       !h->counting && (!h->dbg_on || h->dbg_frame);
     if (!defer) { const int rcd = flush_deferred(h); if (rcd) return rcd; }
     gem_handle::PassBuffers& pb = h->pb[(overlap || defer) ? (h->pass++ & 1u) : 0u];
     hipStream_t sbin = overlap ? h->bin_stream : h->stream;
@@ -1141,6 +1158,7 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
         const size_t o_orig = o_first + sizeof(long long) * (in.n_sweeps + 1);
         const size_t o_var = o_orig + sizeof(int) * in.n_sweeps;
         const size_t total = o_var + sizeof(float) * in.n_sweeps;
+        pb.tab_key.clear();                                          // (the sorted pipeline's cached tables of this buffer set are overwritten below)
         if ((rc = ensure(h, pb.tables, total))) return rc;
         // staged in pinned memory so that the upload does not make the host wait for the stream (a pageable source would:
         // the call then cost a whole k_bin of host time, 240 us per C4 batch)
@@ -1204,9 +1222,12 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
     fa.dbg = nullptr;
     fa.dbg_sweep = h->dbg_sweep;
     if (h->dbg_on) {
-        if ((rc = ensure(h, h->dbg, (size_t)T * 16 * 8))) return rc;
-        GEM_HIP(h, hipMemsetAsync(h->dbg.p, 0, (size_t)T * 16 * 8, h->stream));
+        // rows [0, T): the tiles' stamps; [T, T + binning blocks): the binning blocks' (k_frame with "dbg_frame": both halves of one launch)
+        const int nbin = (B + 3) / 4;
+        if ((rc = ensure(h, h->dbg, (size_t)(T + nbin) * 16 * 8))) return rc;
+        GEM_HIP(h, hipMemsetAsync(h->dbg.p, 0, (size_t)(T + nbin) * 16 * 8, h->stream));
         fa.dbg = static_cast<unsigned long long*>(h->dbg.p);
+        if (h->dbg_frame) { ba.dbg = fa.dbg + (size_t)T * 16; h->dbg_rows = T + nbin; }
     }
 
     if (defer) {
@@ -1681,6 +1702,7 @@ int gem_reserve(gem_handle* h, long long max_points, int max_sweeps, int with_co
         const size_t tables = sizeof(FrameConst) * sweeps + (sizeof(int) + sizeof(long long)) * (sweeps + 1) + (sizeof(float) + sizeof(int)) * sweeps + 64;
         for (auto& pb : h->pb) {
             int r;
+            if (tables > pb.tables.cap) pb.tab_key.clear();          // (the cached tables of this buffer set go with the old allocation)
             if ((r = ensure(h, pb.tables, tables))) return r;
             if (tables > pb.host_cap) {
                 if (pb.tables_recorded) GEM_HIP(h, hipEventSynchronize(pb.tables_done));
@@ -2136,6 +2158,7 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "defer")              h->defer = value != 0;
     else if (k == "dense_min")          { if (value < 0 || value > 0xffffffffll) return fail(h, GEM_ERR_INVALID, "dense_min: 0 .. 2^32 - 1"); h->dense_min = (unsigned)value; }
     else if (k == "dbg_sweep")          h->dbg_sweep = (int)value;
+    else if (k == "dbg_frame")          h->dbg_frame = value != 0;
     else if (k == "overlap")            h->overlap = value != 0;
     else if (k == "overlap_min_points") { if (value < 0) return fail(h, GEM_ERR_INVALID, "overlap_min_points: >= 0"); h->overlap_min_points = value; h->sort_overlap_min_points = value; }
     else if (k == "sort_path")          h->sort_path = value != 0;
@@ -2353,17 +2376,17 @@ int gather_layers_locked(gem_handle* h, int with_attributes)
     const size_t own = (size_t)(h->strip_row[h->rank + 1] - h->strip_row[h->rank]) * h->L;       // 4-byte elements of this rank's strip
     const int g = (int)(h->gather_seq++ & 1u);
     int rc;
-    if ((rc = ensure(h, h->published[g], own * 4 * 6 + 256))) { h->tp_x->abort(); h->tp_g->abort(); return rc; }    // (sized by gem_comm_init*: no allocation here)
+    if ((rc = ensure(h, h->published[g], own * 4 * 6 + 256))) return step_abort(h, rc);    // (sized by gem_comm_init*: no allocation here)
     unsigned char* pub = static_cast<unsigned char*>(h->published[g].p);
-    if (h->gathered_recorded[g]) GEM_HIP(h, hipStreamWaitEvent(h->stream, h->ev_gathered[g], 0));       // the gather before last has sent this copy
-    if (h->step_timed) GEM_HIP(h, hipEventRecord(h->ev_t[6], h->stream));
+    if (h->gathered_recorded[g]) GEM_HIP_STEP(h, hipStreamWaitEvent(h->stream, h->ev_gathered[g], 0));       // the gather before last has sent this copy
+    if (h->step_timed) GEM_HIP_STEP(h, hipEventRecord(h->ev_t[6], h->stream));
     if (own)
         for (int l = 0; l < nl; ++l)
-            GEM_HIP(h, hipMemcpyAsync(pub + (size_t)l * own * 4, static_cast<unsigned char*>(ptrs[l]) + (size_t)h->strip_row[h->rank] * h->L * 4, own * 4,
+            GEM_HIP_STEP(h, hipMemcpyAsync(pub + (size_t)l * own * 4, static_cast<unsigned char*>(ptrs[l]) + (size_t)h->strip_row[h->rank] * h->L * 4, own * 4,
                                       hipMemcpyDeviceToDevice, h->stream));
-    GEM_HIP(h, hipEventRecord(h->ev_published[g], h->stream));
-    GEM_HIP(h, hipStreamWaitEvent(h->gather_stream, h->ev_published[g], 0));
-    if (h->step_timed) GEM_HIP(h, hipEventRecord(h->ev_t[7], h->gather_stream));
+    GEM_HIP_STEP(h, hipEventRecord(h->ev_published[g], h->stream));
+    GEM_HIP_STEP(h, hipStreamWaitEvent(h->gather_stream, h->ev_published[g], 0));
+    if (h->step_timed) GEM_HIP_STEP(h, hipEventRecord(h->ev_t[7], h->gather_stream));
     Transport& tp = *h->tp_g;
     bool ok = tp.group_begin();
     for (int p = 0; p < W && ok; ++p) {
@@ -2375,9 +2398,9 @@ int gather_layers_locked(gem_handle* h, int with_attributes)
         }
     }
     ok = tp.group_end(h->gather_stream) && ok;
-    if (!ok) return fail(h, GEM_ERR_COMM, tp.err.c_str());
-    GEM_HIP(h, hipEventRecord(h->ev_gathered[g], h->gather_stream));
-    if (h->step_timed) GEM_HIP(h, hipEventRecord(h->ev_t[8], h->gather_stream));
+    if (!ok) return step_abort(h, fail(h, GEM_ERR_COMM, tp.err.c_str()));
+    GEM_HIP_STEP(h, hipEventRecord(h->ev_gathered[g], h->gather_stream));
+    if (h->step_timed) GEM_HIP_STEP(h, hipEventRecord(h->ev_t[8], h->gather_stream));
     h->gathered_recorded[g] = true;
     h->gather_outstanding[g] = true;
     return GEM_OK;
@@ -2601,7 +2624,7 @@ int shard_finish_locked(gem_handle* h)
     const int W = h->nranks, q = st.parity;
     gem_handle::Shard& sd = st.sd;
     uint32_t* host = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(h->sh_host) + 4096 * q);
-    GEM_HIP(h, hipEventSynchronize(h->ev_bounds[q]));
+    GEM_HIP_STEP(h, hipEventSynchronize(h->ev_bounds[q]));
     for (int k = 0; k <= W; ++k) sd.bounds[k] = host[64 + h->rank * 16 + k];
     const int tpr = (h->L + 31) / 32;
     const size_t my_blocks = strip_blocks_of(h, h->rank);
@@ -2622,8 +2645,8 @@ int shard_finish_locked(gem_handle* h)
     uint2* rhv = static_cast<uint2*>(h->sh_recv_hv[q].p); uint32_t* rkey = static_cast<uint32_t*>(h->sh_recv_key[q].p);
     uint2* rrng = static_cast<uint2*>(h->sh_recv_rng[q].p);
     // the walk before last has read this parity's receive buffers
-    if (h->walk_recorded[q]) GEM_HIP(h, hipStreamWaitEvent(h->comm_stream, h->ev_walked[q], 0));
-    if (h->step_timed) GEM_HIP(h, hipEventRecord(h->ev_t[2], h->comm_stream));
+    if (h->walk_recorded[q]) GEM_HIP_STEP(h, hipStreamWaitEvent(h->comm_stream, h->ev_walked[q], 0));
+    if (h->step_timed) GEM_HIP_STEP(h, hipEventRecord(h->ev_t[2], h->comm_stream));
     // the exchange: every strip's records and their block ranges to the strip's owner
     Transport& tp = *h->tp_x;
     bool ok = tp.group_begin();
@@ -2642,10 +2665,10 @@ int shard_finish_locked(gem_handle* h)
                  tp.recv(rrng + (size_t)p * my_blocks, my_blocks * 2, p, h->comm_stream);
     }
     ok = tp.group_end(h->comm_stream) && ok;
-    if (!ok) return fail(h, GEM_ERR_COMM, tp.err.c_str());
-    GEM_HIP(h, hipEventRecord(h->ev_exchanged, h->comm_stream));
-    if (h->step_timed) GEM_HIP(h, hipEventRecord(h->ev_t[3], h->comm_stream));
-    GEM_HIP(h, hipStreamWaitEvent(h->stream, h->ev_exchanged, 0));
+    if (!ok) return step_abort(h, fail(h, GEM_ERR_COMM, tp.err.c_str()));
+    GEM_HIP_STEP(h, hipEventRecord(h->ev_exchanged, h->comm_stream));
+    if (h->step_timed) GEM_HIP_STEP(h, hipEventRecord(h->ev_t[3], h->comm_stream));
+    GEM_HIP_STEP(h, hipStreamWaitEvent(h->stream, h->ev_exchanged, 0));
     const void* phv[kMaxRanks]; const void* pkey[kMaxRanks]; const void* prng[kMaxRanks];
     for (int s = 0; s < W; ++s) {
         const bool mine = s == h->rank;
@@ -2653,7 +2676,7 @@ int shard_finish_locked(gem_handle* h)
         pkey[s] = cnt[s] ? (mine ? (const void*)(sd.key + base[s]) : (const void*)(rkey + off[s])) : nullptr;
         prng[s] = cnt[s] ? (mine ? (const void*)(sd.ranges + my_blk0) : (const void*)(rrng + (size_t)s * my_blocks)) : nullptr;
     }
-    if ((rc = shard_fuse_locked(h, W, phv, pkey, cnt, prng, base, st.n_global_sweeps, st.has_vu ? st.vu : nullptr, nullptr, sd.slot, q, arriving))) return rc;
+    if ((rc = shard_fuse_locked(h, W, phv, pkey, cnt, prng, base, st.n_global_sweeps, st.has_vu ? st.vu : nullptr, nullptr, sd.slot, q, arriving))) return step_abort(h, rc);
     if (st.gather) { st.gather = false; return gather_layers_locked(h, st.gather_attrs); }
     return GEM_OK;
 }
@@ -2738,18 +2761,20 @@ int gem_add_sharded_device(gem_handle* h, int n_local_sweeps, const gem_frame_pa
         return shard_fuse_locked(h, 1, none, none, cnt, nullptr, nullptr, n_global_sweeps, var_updates_global, &sd, sd.slot);
     }
     // the second half of the step before (its boundaries are on the host, or will be as soon as its sort is through)
-    if ((rc = shard_finish_locked(h))) return rc;
+    if ((rc = shard_finish_locked(h))) return rc;                     // (aborts the communicators itself when it fails)
     // ... and every rank learns what it receives from whom -- and what it sends -- from ONE all-gather of them (16 words per rank),
     // copied to the host behind it on the communication stream; the next call (or settle) picks them up
     const int q = (int)(h->step_seq++ & 1u);
     uint32_t* host = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(h->sh_host) + 4096 * q);
     uint32_t* d_all = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(h->sh_dev.p) + 4096 * q) + 64;   // [W][16]
-    if (sorted_on) { GEM_HIP(h, hipEventRecord(h->ev_sorted, sorted_on)); GEM_HIP(h, hipStreamWaitEvent(h->comm_stream, h->ev_sorted, 0)); }
-    else GEM_HIP(h, hipStreamWaitEvent(h->comm_stream, h->pb[sd.slot].bin_done, 0));
-    if (h->step_timed) { GEM_HIP(h, hipEventRecord(h->ev_t[1], h->comm_stream)); }
-    if (!h->tp_x->all_gather(sd.d_bounds, d_all, 16, h->comm_stream)) return fail(h, GEM_ERR_COMM, h->tp_x->err.c_str());
-    GEM_HIP(h, hipMemcpyAsync(host + 64, d_all, (size_t)W * 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->comm_stream));
-    GEM_HIP(h, hipEventRecord(h->ev_bounds[q], h->comm_stream));
+    // (the peers read this rank's sorted records over xGMI behind this edge: an event WITH the system-scope fence, recorded on the
+    //  stream the sort ran on -- not the fence-less bin_done of the pass buffers, which orders this device's own streams only)
+    if (!sorted_on) sorted_on = sd.stream ? sd.stream : h->stream;
+    GEM_HIP_STEP(h, hipEventRecord(h->ev_sorted, sorted_on)); GEM_HIP_STEP(h, hipStreamWaitEvent(h->comm_stream, h->ev_sorted, 0));
+    if (h->step_timed) { GEM_HIP_STEP(h, hipEventRecord(h->ev_t[1], h->comm_stream)); }
+    if (!h->tp_x->all_gather(sd.d_bounds, d_all, 16, h->comm_stream)) return step_abort(h, fail(h, GEM_ERR_COMM, h->tp_x->err.c_str()));
+    GEM_HIP_STEP(h, hipMemcpyAsync(host + 64, d_all, (size_t)W * 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->comm_stream));
+    GEM_HIP_STEP(h, hipEventRecord(h->ev_bounds[q], h->comm_stream));
     gem_handle::Step& st = h->step;
     st.valid = true; st.parity = q; st.n_global_sweeps = n_global_sweeps; st.sd = sd; st.gather = false; st.gather_attrs = 0;
     st.has_vu = var_updates_global != nullptr;

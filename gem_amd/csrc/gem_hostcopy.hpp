@@ -78,7 +78,14 @@ private:
         int workers = 0;
     };
 
-    static void cpu_relax() { __builtin_ia32_pause(); }
+    static void cpu_relax()
+    {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#elif defined(__aarch64__)
+        asm volatile("yield");
+#endif
+    }
 
     static void help(Job& j)
     {

@@ -69,13 +69,13 @@ template <int W> __device__ __forceinline__ uint32_t rec_load_cell(const uint4* 
     return reinterpret_cast<const uint32_t*>(rec)[(size_t)i * W + 2];
 }
 
+// one unit = 64 consecutive points, binned by one wave
 template <int SRC, int TS, bool BATCH>
-__device__ __forceinline__ void bin_wave_body(const BinArgs& a, int block)
+__device__ __forceinline__ void bin_unit(const BinArgs& a, int unit)
 {
     constexpr int TE = 1 << TS;
     constexpr int U = 64;
     const int lane = lane_id();
-    const int unit = (int)(block * 4 + (threadIdx.x >> 6));
     if (unit >= a.B) return;                               // whole wave leaves together
     if (unit == 0 && lane == 0) *a.srt_top = 0u;            // bump pointer of the sorted arena (dense tiles of k_fuse_list, same pass)
 
@@ -159,6 +159,30 @@ __device__ __forceinline__ void bin_wave_body(const BinArgs& a, int block)
         const uint32_t nb = (uint32_t)__popcll(__ballot(valid));
         if (lane == 0 && nb) atomicAdd(&a.counters[0], (unsigned long long)nb);
     }
+}
+
+__device__ __forceinline__ void bin_stamp_begin(const BinArgs& a, int block)
+{
+    if (a.dbg && threadIdx.x == 0) {
+        a.dbg[(size_t)block * 16] = (unsigned long long)__builtin_readcyclecounter(); a.dbg[(size_t)block * 16 + 15] = (unsigned long long)blockIdx.x + 1ull;
+        a.dbg[(size_t)block * 16 + 12] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+        a.dbg[(size_t)block * 16 + 14] = (unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) + 1ull;      // HW_REG_XCC_ID
+    }
+}
+__device__ __forceinline__ void bin_stamp_end(const BinArgs& a, int block)
+{
+    if (a.dbg && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        a.dbg[(size_t)block * 16 + 1] = (unsigned long long)__builtin_readcyclecounter(); a.dbg[(size_t)block * 16 + 13] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+    }
+}
+
+template <int SRC, int TS, bool BATCH>
+__device__ __forceinline__ void bin_wave_body(const BinArgs& a, int block)
+{
+    bin_stamp_begin(a, block);
+    bin_unit<SRC, TS, BATCH>(a, (int)(block * 4 + (threadIdx.x >> 6)));
+    bin_stamp_end(a, block);
 }
 
 template <int SRC, int TS, bool BATCH>
@@ -346,7 +370,7 @@ template <int CPT> struct TileState { float e[CPT], s[CPT], lw[CPT]; uint32_t tm
 
 // FLAGS: bits 0-1 = ATTR (0 none, 1 colours from the cloud, 2 colours from gem_fuse's arrays), bit 2 = LOWEST (also maintain the
 // map_lowest layer, GPU:432-439, for gem_raytracing)
-template <int TS, int NT, int PB, int FLAGS, bool BATCH, int MODE>
+template <int TS, int NT, int PB, int FLAGS, bool BATCH, int MODE, bool RANKED = false>
 __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsigned char* lds_raw, TileState<(1 << (2 * TS)) / NT>& st)
 {
     constexpr int ATTR = FLAGS & 3;
@@ -402,10 +426,12 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
     // (measured: 11.7 -> 10.6 us per C2 frame; plain centre-first order, which stacks heavy tiles on a CU: 12.1 us).
     // A batch keeps the identity mapping (every tile loops over all sweeps; the permutation cost 15 % there).
     const int tpr = a.tiles_per_row;
+    const int block_in = (int)blockIdx.x;                                  // (profiling aid: stamp row word 15)
     int tr, tc;
     if constexpr (!BATCH) {
         const int q4 = (a.T + 3) >> 2;
-        const int rnk = (tile & 3) * q4 + (tile >> 2);
+        // (RANKED: k_frame, whose tiles are all resident at once, starts them in plain centre-first order -- see k_frame)
+        const int rnk = RANKED ? tile : (tile & 3) * q4 + (tile >> 2);
         if (rnk >= a.T) return false;
         const int bi = rnk / tpr, bj = rnk - bi * tpr;
         const int oi = (bi & 1) ? -((bi + 1) >> 1) : (bi >> 1), oj = (bj & 1) ? -((bj + 1) >> 1) : (bj >> 1);
@@ -421,8 +447,9 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
     const uint32_t epoch = a.epoch;                                      // stamps the touched flags of this pass
     const uint64_t lt = lanemask_lt();
     int dbg_k = 0;
-#define GEM_STAMP() do { if (a.dbg && tid == 0 && dbg_k < 16) a.dbg[(size_t)tile * 16 + dbg_k++] = (unsigned long long)__builtin_readcyclecounter(); } while (0)
+#define GEM_STAMP() do { if (a.dbg && tid == 0 && dbg_k < 12) a.dbg[(size_t)tile * 16 + dbg_k++] = (unsigned long long)__builtin_readcyclecounter(); } while (0)
     GEM_STAMP();                                                         // 0: start
+    if (a.dbg && tid == 0) a.dbg[(size_t)tile * 16 + 12] = (unsigned long long)__builtin_amdgcn_s_memrealtime();   // (100 MHz, one clock for the chip)
 
     // which sweeps put a record into this tile?  flag[tile][sweep] == epoch (stamped by k_bin): one
     // coalesced load per 64 sweeps, turned into a wave-uniform bit mask
@@ -1023,6 +1050,11 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
         }
     }
     GEM_STAMP();                                                         // 6: stores issued
+    if (a.dbg && tid == 0) {
+        a.dbg[(size_t)tile * 16 + 13] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+        a.dbg[(size_t)tile * 16 + 15] = (unsigned long long)block_in + 1ull;
+        a.dbg[(size_t)tile * 16 + 14] = (unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) + 1ull;      // HW_REG_XCC_ID: the XCD's clock is its own
+    }
 #undef GEM_STAMP
     return false;
 }
@@ -1050,12 +1082,24 @@ __global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_
 // the CUs the fuse leaves idle.
 // ------------------------------------------------------------------------------------------
 // FLAGS: 0, or 4 = the fusion also maintains map_lowest (GPU:432-439; the adapter of the unmodified node turns it on for Raytracing).
+// Round 5, from the launch's own time line (tools/frame_phases.py, profiles/r05_c2_frame_phases.txt: every workgroup's start and
+// end on the chip-wide 100 MHz clock): the chip starts about 850 workgroups of this kernel per microsecond, a tile lives 3.5 us
+// whatever it holds (three dependent memory round trips, five barrier-separated phases), and with 85 VGPRs / 31 KB of LDS five
+// workgroups fit a CU -- 1280 of the launch's 1956, so the rest waited for the first tiles to END and the launch took two tile
+// lifetimes.  Now: rounds of kFramePB = 768 records (24 KB) and at most 80 VGPRs -- six workgroups per CU, 1536 slots: every tile
+// is resident from the start, the binning blocks follow as the light tiles leave -- and the tiles in plain centre-first order
+// (the heaviest are dispatched first; the round-1 interleave by quarters spread them over the whole 1.5 us ramp): 9.1 -> 7.9 us.
+// Measured and dropped: the binning blocks first (+0.9 us: every tile starts later), two or eight units per binning wave
+// (+0.7 / +6 us: a unit is ~3 k cycles of a wave's issue, the blocks became the launch's tail), rounds of 512 records with
+// 64 VGPRs and eight workgroups per CU (+3.5 us: the fuse body spills).
+constexpr int kFramePB = 768;        // records per LDS round of k_frame's fuse half (k_fuse_list alone keeps 1024)
+constexpr int kFrameWG = 6;          // workgroups per CU the register budget is set for
 template <int FLAGS>
-__global__ __launch_bounds__(256, 4) void k_frame(FuseArgs fa, BinArgs ba)
+__global__ __launch_bounds__(256, kFrameWG) void k_frame(FuseArgs fa, BinArgs ba)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
     const int nf = (fa.T + 3) & ~3;                                      // fuse blocks (see the block -> tile mapping)
-    if ((int)blockIdx.x < nf) { TileState<1> st; fuse_list_body<4, 256, 1024, FLAGS, false, 0>(fa, (int)blockIdx.x, lds_dyn, st); }
+    if ((int)blockIdx.x < nf) { TileState<1> st; fuse_list_body<4, 256, kFramePB, FLAGS, false, 0, true>(fa, (int)blockIdx.x, lds_dyn, st); }
     else bin_wave_body<0, 4, false>(ba, (int)blockIdx.x - nf);
 }
 
@@ -1554,8 +1598,8 @@ hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr, int 
 hipError_t launch_frame(hipStream_t st, const FuseArgs& fa, const BinArgs& ba, int attr, LaunchEvents ev)
 {
     const dim3 grid(((fa.T + 3) & ~3) + (ba.B + 3) / 4), block(256);
-    if (attr == 4)      GEM_LAUNCH((k_frame<4>), grid, block, fuse_list_lds(256, 4, 1024, 0), st, ev, fa, ba);
-    else if (attr == 0) GEM_LAUNCH((k_frame<0>), grid, block, fuse_list_lds(256, 4, 1024, 0), st, ev, fa, ba);
+    if (attr == 4)      GEM_LAUNCH((k_frame<4>), grid, block, fuse_list_lds(256, 4, kFramePB, 0), st, ev, fa, ba);
+    else if (attr == 0) GEM_LAUNCH((k_frame<0>), grid, block, fuse_list_lds(256, 4, kFramePB, 0), st, ev, fa, ba);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -54,6 +54,7 @@ struct BinArgs {
     unsigned long long* counters;      // optional: [0] += binned points
     uint32_t*         srt_top;         // bump pointer of the sorted arena (reset here, used by the fuse of the same pass)
     int               keep_sentinel;   // keep records with h == -1 (GPU:482) for the LOWEST fuse variants
+    unsigned long long* dbg;           // optional: [blocks][16] cycle stamps of the binning blocks (word 0 start, 1 end, 15 = block index + 1; profiling aid)
 };
 
 struct FuseArgs {

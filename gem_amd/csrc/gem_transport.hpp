@@ -56,10 +56,15 @@ struct RcclTransport final : Transport {
     bool fail(ncclResult_t r) { err = ncclGetErrorString(r); return false; }
     bool all_gather(const uint32_t* send, uint32_t* recv, size_t words, hipStream_t st) override
     {
+        if (!comm) { err = "communicator aborted"; return false; }
         const ncclResult_t r = ncclAllGather(send, recv, words, ncclUint32, comm, st);
         return r == ncclSuccess ? true : fail(r);
     }
-    bool group_begin() override { r_group = ncclGroupStart(); return r_group == ncclSuccess ? true : fail(r_group); }
+    bool group_begin() override
+    {
+        if (!comm) { err = "communicator aborted"; r_group = ncclInvalidUsage; return false; }
+        r_group = ncclGroupStart(); return r_group == ncclSuccess ? true : fail(r_group);
+    }
     bool send(const void* p, size_t words, int peer, hipStream_t st) override
     {
         if (r_group == ncclSuccess) r_group = ncclSend(p, words, ncclUint32, peer, comm, st);
@@ -72,11 +77,14 @@ struct RcclTransport final : Transport {
     }
     bool group_end(hipStream_t) override
     {
+        if (!comm) return false;                                       // (group_begin refused: no group is open)
         const ncclResult_t r2 = ncclGroupEnd();                        // (always closed, also after a failed send / recv)
         if (r_group != ncclSuccess) return fail(r_group);
         return r2 == ncclSuccess ? true : fail(r2);
     }
-    void abort() override { if (comm) { ncclCommAbort(comm); comm = nullptr; } }
+    // (a transport that only BORROWS its communicator -- the gather transport when ncclCommSplit is not available -- leaves the
+    //  abort to the owner and just lets go of the pointer: one ncclCommAbort per communicator)
+    void abort() override { if (comm && owns) ncclCommAbort(comm); comm = nullptr; }
 };
 
 // ---- loopback ------------------------------------------------------------------------------------------------------------------

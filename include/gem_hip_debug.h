@@ -14,7 +14,8 @@ extern "C" {
 
 /* keys: "fuse_variant" (10..12: k_fuse_list geometry on 32x32 tiles), "tile_shift" (0 = per pass, 4, 5),
  *       "defer" (0/1: one launch per frame for streams of single sweeps), "dense_min" (records of one sweep in one
- *       16x16 tile above which the tile is counting-sorted), "dbg_sweep", "overlap" (0/1: binning of big passes on a
+ *       16x16 tile above which the tile is counting-sorted), "dbg_sweep", "dbg_frame" (0/1: with gem_debug_fuse_stamps on, a stream of
+ *       single sweeps still runs as k_frame and its binning blocks are stamped too: rows [T, T + blocks)), "overlap" (0/1: binning of big passes on a
  *       second stream), "overlap_min_points", "sort_path" (0/1: the sorted pipeline for big passes), "sort_min_points",
  *       "sort_passes" (0 = by map size and form, 1..3: counting-sort passes), "sort_form" (0 = by pass: batches of sweeps block-sorted
  *       (k_fuse_block), single clouds cell-sorted (k_fuse_walk); 1 / 2 force cell / block), "fast_laser" (0/1: the
