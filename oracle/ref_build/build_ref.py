@@ -116,7 +116,7 @@ def build_sensors(reference: Path = Path("/root/reference"), force: bool = False
     if not all(s.exists() for s in srcs):
         return OUT_SENSORS if OUT_SENSORS.exists() else None
     m = HERE / "sensors"
-    deps = srcs + [Path(__file__)] + [f for f in m.rglob("*") if f.is_file()]
+    deps = srcs + [reference / REL_SENSORS / "SensorProcessorBase.cpp", Path(__file__)] + [f for f in m.rglob("*") if f.is_file()]
     if OUT_SENSORS.exists() and not force and all(OUT_SENSORS.stat().st_mtime >= d.stat().st_mtime for d in deps):
         return OUT_SENSORS
     OUT_SENSORS.parent.mkdir(exist_ok=True)
@@ -126,8 +126,19 @@ def build_sensors(reference: Path = Path("/root/reference"), force: bool = False
                                                     "Eigen/Core", "kindr/Core", "ros/ros.h", "tf/transform_listener.h", "pcl/point_cloud.h",
                                                     "pcl/filters/filter.h", "pcl/filters/passthrough.h", "boost/shared_ptr.hpp"))
         body = "\n".join(f'#include "{s}"' for s in srcs)
+        # SensorProcessorBase::readcomputerparam (SPB.cpp:270-290): the function's own text, cut out of the reference's file where it
+        # lies (the rest of that file needs TF look-ups, PCL transforms and the GPU entry points) into this temporary translation
+        # unit -- never into the repository
+        spb = (reference / REL_SENSORS / "SensorProcessorBase.cpp").read_text()
+        at = spb.index("void SensorProcessorBase::readcomputerparam(")
+        depth, end = 0, None
+        for i in range(spb.index("{", at), len(spb)):
+            depth += spb[i] == "{"; depth -= spb[i] == "}"
+            if depth == 0:
+                end = i + 1; break
+        rcp = "namespace elevation_mapping {\n" + spb[at:end] + "\n}\n"
         tu.write_text(f'{std}\n#define private public\n#define protected public\n{body}\n#undef private\n#undef protected\n'
-                      f'#include "{m / "sensor_exports.inc"}"\n')
+                      f'#include "{m / "sensor_exports.inc"}"\n{rcp}')
         cmd = ["g++", "-O2", "-ffp-contract=off", "-fno-fast-math", "-std=c++14", "-w", "-fPIC", "-shared",
                f"-I{m}", f"-I{reference / REL_INCLUDE}", str(tu), "-o", str(OUT_SENSORS)]
         if verbose:

@@ -17,6 +17,8 @@ sys.path.insert(0, str(ROOT / "oracle"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
+    config.addinivalue_line("markers", "one_pipeline: a GPU test that does not depend on the pipeline knobs (child processes build their own maps, "
+                                       "or no map is fused at all): it runs once, not once per entry of PIPELINES")
 
 
 def _has_gpu() -> bool:
@@ -71,7 +73,8 @@ def pytest_generate_tests(metafunc):
     # every GPU test runs on every pipeline (see the `pipeline` fixture)
     if metafunc.definition.get_closest_marker("gpu") is not None:
         metafunc.fixturenames.append("pipeline")
-        metafunc.parametrize("pipeline", list(PIPELINES), indirect=True)
+        one = metafunc.definition.get_closest_marker("one_pipeline") is not None
+        metafunc.parametrize("pipeline", ["default"] if one else list(PIPELINES), indirect=True)
 
 
 @pytest.fixture

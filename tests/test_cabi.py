@@ -135,6 +135,7 @@ def test_cpp_host_side_links_and_fails_loudly_without_gpu(lib, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.one_pipeline            # (a C++ child process: the fixture's knobs never reach it)
 def test_cpp_host_side_known_answers_on_gpu(lib, tmp_path):
     exe = build_facade_check(tmp_path)
     res = subprocess.run([str(exe), "1"], capture_output=True, text=True)
@@ -219,6 +220,7 @@ int main(int argc, char**) { return argc > 100 ? call_all(argc) : 0; }       // 
 
 
 @pytest.mark.gpu
+@pytest.mark.one_pipeline            # (a C++ child process: the fixture's knobs never reach it)
 def test_reference_motion_updater_drives_the_adapters_mapvar_update(lib, tmp_path, oracle_mod):
     """The reference's own RobotMotionMapUpdater::update (compiled from where it lies, oracle/_ref/libgem_ref_motion.so) computes the
     increments; each is handed to the ADAPTER's Mapvar_update (the symbol RMU.cpp:81 calls) on a populated GPU map; the variance layer
@@ -272,3 +274,26 @@ def test_reference_motion_updater_drives_the_adapters_mapvar_update(lib, tmp_pat
     getattr(ad, names["Map_feature"])(L, p(out[0], F), p(out[1], F), p(outi[0], I), p(outi[1], I), p(outi[2], I), p(out[2], F), p(out[3], F), p(out[4], F), p(out[5], F))
     assert np.array_equal(out[0].reshape(L, L), om.layer("elevation")) and np.array_equal(out[1].reshape(L, L), om.layer("variance"))
     assert (om.layer("variance") > 1e-4).sum() > 1000
+
+
+# ---- the C++ header's host math against the reference's own code ---------------------------------------------------
+def test_cpp_header_host_math_matches_the_references_code(lib, tmp_path):
+    """include/gem/gem.hpp -- gem::RobotMotionMapUpdater::compute and gem::SensorProcessorBase::frameParams, what a C++ user of the
+    header gets -- against RobotMotionMapUpdater.cpp (RMU.cpp:42-145) and SensorProcessorBase::readcomputerparam (SPB.cpp:270-290)
+    compiled where they lie (oracle/_ref, oracle/ref_build/build_ref.py): random trajectories / transformations, <= 1 float ulp
+    (tests/cpp/header_pin.cpp).  The header's Python twin has tests/test_motion_update.py."""
+    sys.path.insert(0, str(ROOT / "oracle" / "ref_build"))
+    import build_ref
+    motion, sensors = build_ref.build_motion(), build_ref.build_sensors()
+    if motion is None or sensors is None:
+        pytest.skip("no /root/reference to build from and no prebuilt oracle/_ref libraries")
+    if b"gemref_readcomputerparam" not in Path(sensors).read_bytes():
+        pytest.skip("the prebuilt oracle/_ref/libgem_ref_sensors.so predates gemref_readcomputerparam and /root/reference is not here to rebuild it")
+    exe = tmp_path / "header_pin"
+    libdir = ROOT / "gem_amd" / "lib"
+    cmd = ["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-Wall", "-Werror", "-I", str(ROOT / "include"), str(ROOT / "tests" / "cpp" / "header_pin.cpp"), "-o", str(exe),
+           f"-L{libdir}", "-lgem_hip", "-ldl", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    run = subprocess.run([str(exe), str(motion), str(sensors)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and run.stdout.strip().endswith("ok"), run.stdout + run.stderr

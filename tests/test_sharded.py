@@ -331,6 +331,7 @@ def _worker_rccl(rank, world, port, q, L, res):
 
 
 @pytest.mark.gpu
+@pytest.mark.one_pipeline            # (the ranks are processes of their own: the fixture's knobs never reach them)
 @pytest.mark.parametrize("world,L,res", [(2, 96, 0.1), (2, 75, 0.2), (8, 75, 0.2), (8, 2400, 0.05)])
 def test_real_rccl_ranks_stage_a_and_b(world, L, res):
     """One process per GPU through gem_comm_init(_tiles) / gem_add_sharded_device / gem_allgather_layers: the real RCCL path,
