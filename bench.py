@@ -466,8 +466,26 @@ def c2_variants(emap_cls, dev, torch, reps: int = 400):
     for _ in range(reps // 4):
         m.add(wl.frames[0], host)
     m.synchronize(); dt = (time.perf_counter() - t0) / (reps // 4)
-    out["e2e_with_h2d"] = {"workload": "C2 sweep handed over as a HOST array (gem_add: staging copy + H2D + the same kernels)", "value": n / dt, "unit": "points/s",
+    out["e2e_with_h2d"] = {"workload": "C2 sweep handed over as a HOST array, call after call (gem_add: a copy into the pinned staging buffer, which the kernels read over the link)", "value": n / dt, "unit": "points/s",
                            "us_per_step": dt * 1e6, "parity_checked": bool(ok), "parity": "first sweep into a fresh map == tests/golden/digests.json c2"}
+    m.close()
+    # BASELINE configs[3] handed over as 32 HOST arrays (gem_add_batch): the link carries 67 MB per batch -- its rate, not
+    # the kernels', sets this figure; never `value`
+    wl4 = synth.config_c4(n_sweeps=32)
+    m = emap_cls(wl4.length, wl4.resolution, device=dev.index)
+    pb = m.pack_batch(wl4.frames, np.concatenate([[0], np.cumsum([c.shape[0] for c in wl4.clouds])]), wl4.var_updates)
+    m.add_batch_host(pb, wl4.clouds)
+    ok = sha(m.layer("elevation")) == d["c4_32"]["elevation"] and sha(m.layer("variance")) == d["c4_32"]["variance"]
+    for _ in range(2):
+        m.add_batch_host(pb, wl4.clouds)
+    m.synchronize(); t0 = time.perf_counter()
+    for _ in range(8):
+        m.add_batch_host(pb, wl4.clouds)
+    m.synchronize(); dt = (time.perf_counter() - t0) / 8
+    n4 = sum(c.shape[0] for c in wl4.clouds)
+    out["c4_host_batch"] = {"workload": "C4 batch handed over as 32 HOST arrays (gem_add_batch: staging copies + DMA of sweep k + 1 beside sweep k, one batched pass)",
+                            "value": n4 / dt, "unit": "points/s", "us_per_batch": dt * 1e6, "bytes_over_pcie_per_batch": 16.0 * n4,
+                            "link_GBps": 16.0 * n4 / dt / 1e9, "parity_checked": bool(ok), "parity": "first batch into a fresh map == tests/golden/digests.json c4_32"}
     m.close()
     out["node_host_arrays"] = node_host_arrays(emap_cls, dev)
     return out
@@ -855,7 +873,7 @@ def main():
         out["c5_one_gpu"] = c5_one_gpu(ElevationMap, dev, torch)
         out["c3"] = c3_stream(ElevationMap, dev, torch)
         out.update(c2_variants(ElevationMap, dev, torch))
-        extras = ("batched_c4", "c5_one_gpu", "c3", "c2_reference_filter_on", "e2e_with_h2d")       # (node_host_arrays carries no digest: the same entry points are parity-tested in tests/)
+        extras = ("batched_c4", "c5_one_gpu", "c3", "c2_reference_filter_on", "e2e_with_h2d", "c4_host_batch")       # (node_host_arrays carries no digest: the same entry points are parity-tested in tests/)
         out["parity_checked"] = bool(out["parity_checked"] and all(out[k]["parity_checked"] for k in extras))
         out["parity"] += "; C4 batch (twice into a fresh map) vs c4_32 / c4_32_twice; C5 on one GPU vs c5_full; C3 vs c3; C2 with the reference filter vs c2_filter; host-array C2 vs c2"
         failed = failed or not out["parity_checked"]

@@ -64,6 +64,7 @@ SIGNATURES = {
     "gem_add": (c_int, [c_void_p, POINTER(FrameParams), c_int, c_void_p, c_void_p, c_void_p]),
     "gem_add_device": (c_int, [c_void_p, POINTER(FrameParams), c_int, c_void_p, c_void_p, c_void_p]),
     "gem_add_batch_device": (c_int, [c_void_p, c_int, POINTER(FrameParams), c_void_p, POINTER(c_longlong), POINTER(c_float)]),
+    "gem_add_batch": (c_int, [c_void_p, c_int, POINTER(FrameParams), POINTER(c_void_p), POINTER(c_int), POINTER(c_float)]),
     "gem_mapvar_update": (c_int, [c_void_p, c_float]),
     "gem_get_layer": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "gem_set_layer": (c_int, [c_void_p, c_int, c_void_p]),

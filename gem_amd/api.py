@@ -360,6 +360,24 @@ class ElevationMap:
         self._check(self._lib.gem_add_batch_device(self._h, pb.n, pb.frames, C.c_void_p(xyzi_device.data_ptr()), pb.offsets,
                                                    pb.var_updates), "gem_add_batch_device")
 
+    def add_batch_host(self, frames, clouds, var_updates=None) -> None:
+        """The same from HOST memory (gem_add_batch): `clouds` is a sequence of float32 [n_s, 4] numpy arrays, one per
+        sweep; `frames` a sequence of Frame or a PackedBatch (whose offsets are not used: the arrays carry their own lengths)."""
+        arrs = [np.ascontiguousarray(c, np.float32).reshape(-1, 4) for c in clouds]
+        ns = len(arrs)
+        if isinstance(frames, PackedBatch):
+            if frames.n != ns:
+                raise ValueError("one cloud per frame")
+            fr, vu = frames.frames, frames.var_updates
+        else:
+            if len(frames) != ns:
+                raise ValueError("one cloud per frame")
+            fr = (_lib.FrameParams * ns)(*[f.to_struct() for f in frames])
+            vu = (C.c_float * ns)(*[float(v) for v in var_updates]) if var_updates is not None else None
+        ptrs = (C.c_void_p * ns)(*[a.ctypes.data for a in arrs])
+        counts = (C.c_int * ns)(*[a.shape[0] for a in arrs])
+        self._check(self._lib.gem_add_batch(self._h, ns, fr, ptrs, counts, vu), "gem_add_batch")
+
     # -- Mapvar_update (RMU.cpp:81) ------------------------------------------------------------------
     def reserve(self, max_points: int, max_sweeps: int = 1, with_colours: bool = False) -> None:
         """Pre-size the device arenas for the largest pass to come (gem_reserve): no pass within these bounds allocates afterwards."""

@@ -150,6 +150,12 @@ struct gem_handle {
     hipEvent_t ev_stage[kStageEvents] = {};      // host-visible: a segment's DMA into the staging buffer is done
     hipEvent_t stage_read = nullptr;    // the last DMA OUT of the staging buffer is done (it may be written again)
     bool   stage_read_pending = false;
+    // deferred uploads (gem_add, gem_add_batch): the call returns once the caller's arrays have been READ into one half of the staging
+    // buffer and the DMA out of it is enqueued; the next call fills the other half meanwhile.  A half is reused when the DMA that read
+    // it two calls ago is done.
+    hipEvent_t ev_half[2] = {nullptr, nullptr};
+    bool   half_pending[2] = {false, false};
+    unsigned stage_par = 0;
     long long hstage_allocations = 0;
     long long xfer_ns[5] = {0, 0, 0, 0, 0};    // host time so far: upload memcpy, upload enqueue, download enqueue, download wait, download memcpy
 
@@ -287,7 +293,7 @@ unsigned char* host_stage(gem_handle* h, size_t bytes)
     if (bytes > h->hstage_cap) {
         if (h->hstage) {
             if (hipStreamSynchronize(h->stream) != hipSuccess) return nullptr;       // a DMA may still read it
-            h->stage_read_pending = false;
+            h->stage_read_pending = false; h->half_pending[0] = h->half_pending[1] = false;
             hipHostFree(h->hstage); h->hstage = nullptr; h->hstage_cap = 0;
         }
         const size_t want = bytes + bytes / 4 + 4096;
@@ -300,20 +306,60 @@ unsigned char* host_stage(gem_handle* h, size_t bytes)
     return static_cast<unsigned char*>(h->hstage);
 }
 
-// Host arrays -> device, on h->stream.  On return the caller's arrays have been READ (they may be stack arrays that die with the
-// call, EMg.cpp:260-267); the device copies are enqueued.  `stage_off`: where in the staging buffer this call's uploads begin.
-int upload_arrays(gem_handle* h, const HostXfer* x, int n)
+// every DMA out of the staging buffer that a deferred upload left in flight is done (whoever uses the buffer from its start comes here first)
+int drain_staging(gem_handle* h)
 {
+    for (int p = 0; p < 2; ++p) if (h->half_pending[p]) { GEM_HIP(h, hipEventSynchronize(h->ev_half[p])); h->half_pending[p] = false; }
+    if (h->stage_read_pending) { GEM_HIP(h, hipEventSynchronize(h->stage_read)); h->stage_read_pending = false; }
+    return GEM_OK;
+}
+
+// Host arrays -> device, on h->stream.  On return the caller's arrays have been READ (they may be stack arrays that die with the
+// call, EMg.cpp:260-267); the device copies are enqueued.  defer_ok: the caller enqueues its kernels behind the copies ON h->stream
+// (or on streams ordered behind it: main_reads_pb) and nothing on the host needs them done -- the call then does not wait for the
+// DMA: it leaves it reading one half of the staging buffer while the next call's arrays are copied into the other half (a stream of
+// gem_add calls: staging copy, link and kernels of consecutive sweeps overlap; before, each call ran them back to back).
+int upload_arrays(gem_handle* h, const HostXfer* x, int n, bool defer_ok = false, unsigned char** zero_copy_region = nullptr, int* zero_copy_half = nullptr)
+{
+    if (zero_copy_region) *zero_copy_region = nullptr;
     size_t total = 0;
     for (int i = 0; i < n; ++i) total += (x[i].bytes + 255) & ~(size_t)255;
-    unsigned char* stg = total >= (128u << 10) ? host_stage(h, total) : nullptr;
+    unsigned char* stg = total >= (128u << 10) ? host_stage(h, defer_ok ? 2 * total + 512 : total) : nullptr;
     if (!stg) {
         for (int i = 0; i < n; ++i) if (x[i].bytes) GEM_HIP(h, hipMemcpyAsync(x[i].dev, x[i].host, x[i].bytes, hipMemcpyHostToDevice, h->stream));
         GEM_HIP(h, hipEventRecord(h->copy_done, h->stream));
         GEM_HIP(h, hipEventSynchronize(h->copy_done));
         return GEM_OK;
     }
-    if (h->stage_read_pending) { GEM_HIP(h, hipEventSynchronize(h->stage_read)); h->stage_read_pending = false; }
+    int par = -1;
+    if (defer_ok) {
+        for (auto& ev : h->ev_half) if (!ev) GEM_HIP(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        if (h->stage_read_pending) { GEM_HIP(h, hipEventSynchronize(h->stage_read)); h->stage_read_pending = false; }
+        par = (int)(h->stage_par++ & 1u);
+        // the halves are the two halves of the BUFFER (not of this call's bytes: calls of different sizes must not overlap)
+        const size_t half_at = (h->hstage_cap / 2) & ~(size_t)255;
+        if (h->half_pending[par]) { GEM_HIP(h, hipEventSynchronize(h->ev_half[par])); h->half_pending[par] = false; }
+        // a half that does not hold the call (the buffer was sized by a smaller deferred call and has not grown): the other half's reader first
+        if (half_at < total || h->hstage_cap - half_at < total) { const int rcd = drain_staging(h); if (rcd) return rcd; par = 0; }
+        else stg += (size_t)par * half_at;
+        if (zero_copy_region) {
+            // ZERO COPY: the arrays go into the half at the stride they would have on the device and the pass's kernels read them
+            // THERE, over the link (the buffer is device-visible pinned memory) -- no DMA command, hence no hand-over between the
+            // copy engine and the compute queue on either side of it (a H2D command between two kernels of one stream cost
+            // ~10 us each way: 80 us per 2 MB sweep where link + kernel are 57).  The caller records the half's event behind its kernels.
+            size_t off = 0;
+            gem::CopySeg segs[16]; int ns = 0;
+            const long long t0 = host_ns();
+            for (int i = 0; i < n; ++i) {
+                if (x[i].bytes) segs[ns++] = {stg + off, x[i].host, x[i].bytes};
+                off += (x[i].bytes + 255) & ~(size_t)255;
+                if (ns == 16 || i == n - 1) { if (ns) gem::CopyPool::get().run(segs, ns, h->copy_threads); ns = 0; }
+            }
+            h->xfer_ns[0] += host_ns() - t0;
+            *zero_copy_region = stg; *zero_copy_half = par;
+            return GEM_OK;
+        }
+    } else { const int rcd = drain_staging(h); if (rcd) return rcd; }
     // Arrays that follow each other on the device at the staging buffer's own 256-byte stride form one region, copied by DMA
     // commands that ignore the array boundaries (a command costs ~9 us before its first byte: seven 0.5 MB arrays one by one run at
     // 29 GB/s, as two commands at 43); the DMA of one group runs under the memcpy of the next.
@@ -326,7 +372,9 @@ int upload_arrays(gem_handle* h, const HostXfer* x, int n)
         // the DMA ends with the region's last BYTE: the padding behind the last member belongs to nobody (the callers size their
         // device arrays by what they hold, not by the staging buffer's stride)
         const size_t real_len = len - pad(x[e - 1].bytes) + x[e - 1].bytes;
-        const size_t group = pad(len <= (8u << 20) ? std::max<size_t>(len / 2, 512u << 10) : (4u << 20));
+        // (deferred: the DMA of this call runs beside the NEXT call's copy, so a region of up to 8 MB goes as ONE command -- a command
+        //  costs ~9 us before its first byte; not deferred: in two, the second copy beside the first command)
+        const size_t group = pad(len <= (8u << 20) ? (par >= 0 ? len : std::max<size_t>(len / 2, 512u << 10)) : (4u << 20));
         for (size_t a = 0; a < len; a += group) {
             const size_t b = std::min(len, a + group);
             gem::CopySeg segs[16]; int ns = 0;
@@ -346,6 +394,14 @@ int upload_arrays(gem_handle* h, const HostXfer* x, int n)
         off += len;
         i = e;
     }
+    if (par >= 0) {
+        // deferred: the DMA stays in flight; the pass's kernels follow it on h->stream, and the binning streams of an overlapped pass
+        // are put behind h->stream before they read the arena (main_reads_pb: run_pipeline / run_sort_pipeline)
+        GEM_HIP(h, hipEventRecord(h->ev_half[par], h->stream));
+        h->half_pending[par] = true;
+        h->main_reads_pb = true;
+        return GEM_OK;
+    }
     // The pipeline reads the arena on its binning streams too, which are not ordered behind h->stream by anything but the host:
     // the copies are waited for, as they were when the runtime staged the arrays.
     GEM_HIP(h, hipEventRecord(h->stage_read, h->stream));
@@ -361,6 +417,7 @@ int download_arrays(gem_handle* h, const HostXfer* x, int n, size_t stage_off)
     size_t total = 0;
     for (int i = 0; i < n; ++i) total += (x[i].bytes + 255) & ~(size_t)255;
     stage_off = (stage_off + 255) & ~(size_t)255;
+    { const int rcd = drain_staging(h); if (rcd) return rcd; }
     unsigned char* stg = total >= (128u << 10) ? host_stage(h, stage_off + total) : nullptr;
     if (!stg) {
         for (int i = 0; i < n; ++i) if (x[i].bytes) GEM_HIP(h, hipMemcpyAsync(x[i].host, x[i].dev, x[i].bytes, hipMemcpyDeviceToHost, h->stream));
@@ -1369,6 +1426,7 @@ void gem_destroy(gem_handle* h)
     if (h->hstage) hipHostFree(h->hstage);
     for (auto& ev : h->ev_stage) if (ev) hipEventDestroy(ev);
     if (h->stage_read) hipEventDestroy(h->stage_read);
+    for (auto& ev : h->ev_half) if (ev) hipEventDestroy(ev);
     if (h->switch_done) hipEventDestroy(h->switch_done);
     release_streams(h->device, h->streams);            // back to the pool, as a set
     delete h;
@@ -1489,7 +1547,7 @@ int gem_process_points(gem_handle* h, const gem_frame_params* p, int n, float* x
     const size_t SP = (S + 255) & ~(size_t)255;
     unsigned char* stg = S >= (64u << 10) ? host_stage(h, SP * 9) : nullptr;
     if (stg && (n + kRange - 1) / kRange <= gem_handle::kStageEvents) {
-        if (h->stage_read_pending) { GEM_HIP(h, hipEventSynchronize(h->stage_read)); h->stage_read_pending = false; }
+        { const int rcd = drain_staging(h); if (rcd) return rcd; }
         float* sx = reinterpret_cast<float*>(stg);            float* sy = reinterpret_cast<float*>(stg + SP);
         float* sz = reinterpret_cast<float*>(stg + 2 * SP);   int* sorig = reinterpret_cast<int*>(stg + 3 * SP);
         int* sidx = reinterpret_cast<int*>(stg + 4 * SP);     float* svar = reinterpret_cast<float*>(stg + 5 * SP);
@@ -1575,12 +1633,23 @@ int gem_fuse(gem_handle* h, int n, const int* index, const int* R, const int* G,
                           {const_cast<int*>(R), d + 3 * P, S}, {const_cast<int*>(G), d + 4 * P, S}, {const_cast<int*>(B), d + 5 * P, S},
                           {const_cast<float*>(intensity), d + 6 * P, S}};
         // the caller's arrays are only valid for the call (they are stack VLAs in the reference, EMg.cpp:260-267): read before it returns
-        if ((rc = upload_arrays(h, up, attr ? 7 : 3))) return rc;
+        // -- into a half of the staging buffer, where the pass's kernels read them over the link (zero copy, see upload_arrays), or,
+        // when the staging buffer does not take them, into the arena by the runtime's copies
+        unsigned char* region = nullptr; int half = -1;
+        if ((rc = upload_arrays(h, up, attr ? 7 : 3, true, &region, &half))) return rc;
+        if (region) d = region;
         in.f_index = reinterpret_cast<const int*>(d); in.f_height = reinterpret_cast<const float*>(d + P);
         in.f_var = reinterpret_cast<const float*>(d + 2 * P);
         if (attr) {
             in.f_R = reinterpret_cast<const int*>(d + 3 * P); in.f_G = reinterpret_cast<const int*>(d + 4 * P);
             in.f_B = reinterpret_cast<const int*>(d + 5 * P); in.f_I = reinterpret_cast<const float*>(d + 6 * P);
+        }
+        if (region) {
+            rc = run_pipeline(h, in);
+            const hipError_t e = hipEventRecord(h->ev_half[half], h->stream);       // (the half is free when the pass's kernels have read it)
+            if (e != hipSuccess && rc == GEM_OK) rc = fail(h, GEM_ERR_HIP, "hipEventRecord(staging half)", e);
+            h->half_pending[half] = true;
+            return rc;
         }
     }
     return run_pipeline(h, in);
@@ -1616,8 +1685,74 @@ int gem_add(gem_handle* h, const gem_frame_params* p, int n, const float* xyzi, 
         unsigned char* next = d + P4;
         if (rgb) { up[nu++] = {const_cast<uint32_t*>(rgb), next, S}; in.rgb = reinterpret_cast<const uint32_t*>(next); next += P; }
         if (orig_index) { up[nu++] = {const_cast<int*>(orig_index), next, S}; in.orig = reinterpret_cast<const int*>(next); }
-        if ((rc = upload_arrays(h, up, nu))) return rc;
+        // (the cloud is in the handle's own memory when the kernels run: like a device-resident one, it may take the one-launch-per-frame
+        //  path whose deferred fuse reads the binned records only)
+        unsigned char* region = nullptr; int half = -1;
+        if ((rc = upload_arrays(h, up, nu, true, &region, &half))) return rc;
+        in.device_input = true;
+        if (region) {
+            // the kernels read the staging half itself (upload_arrays): same strides as the arena's
+            in.xyzi = reinterpret_cast<const float4*>(region);
+            unsigned char* nxt = region + P4;
+            if (rgb) { in.rgb = reinterpret_cast<const uint32_t*>(nxt); nxt += P; }
+            if (orig_index) in.orig = reinterpret_cast<const int*>(nxt);
+            rc = run_pipeline(h, in);
+            // the half is free again when everything enqueued so far has run (the pass's kernels read it; a deferred fuse does not)
+            // (a pass that put its binning on another stream: that stream's work is ordered before the walk / fuse on h->stream)
+            const hipError_t e = hipEventRecord(h->ev_half[half], h->stream);
+            if (e != hipSuccess && rc == GEM_OK) rc = fail(h, GEM_ERR_HIP, "hipEventRecord(staging half)", e);
+            h->half_pending[half] = true;
+            return rc;
+        }
     }
+    return run_pipeline(h, in);
+}
+
+// BASELINE config 4 from HOST memory (gem_add_batch): sweep s = clouds[s][0 .. counts[s]) XYZI points, frames and
+// increments as gem_add_batch_device.  The sweeps are copied into the handle's arena one behind the other -- staging copy of sweep
+// s + 1 beside the DMA of sweep s -- and fused by ONE batched pass; the caller's arrays have been read when the call returns.
+int gem_add_batch(gem_handle* h, int n_sweeps, const gem_frame_params* params, const float* const* clouds, const int* counts, const float* var_updates)
+{
+    if (!h || n_sweeps <= 0 || !params || !clouds || !counts) return h ? fail(h, GEM_ERR_INVALID, "gem_add_batch: bad argument") : GEM_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(h->mu);
+    hipSetDevice(h->device);
+    { const int rcs = shard_finish_locked(h); if (rcs) return rcs; }
+    std::vector<long long> offsets(n_sweeps + 1, 0);
+    for (int s = 0; s < n_sweeps; ++s) {
+        if (counts[s] < 0 || (counts[s] > 0 && !clouds[s])) return fail(h, GEM_ERR_INVALID, "gem_add_batch: bad sweep");
+        offsets[s + 1] = offsets[s] + counts[s];
+    }
+    const long long N = offsets[n_sweeps];
+    if (N >= (1ll << 31)) return fail(h, GEM_ERR_INVALID, "gem_add_batch: batch too large");
+    int rc;
+    if ((rc = ensure(h, h->stage, (size_t)N * 16 + 256))) return rc;
+    unsigned char* d = static_cast<unsigned char*>(h->stage.p);
+    if (N > 0) {
+        std::vector<HostXfer> up;
+        for (int s = 0; s < n_sweeps; ++s)
+            if (counts[s] > 0) up.push_back({const_cast<float*>(clouds[s]), d + (size_t)offsets[s] * 16, (size_t)counts[s] * 16});
+        // (in pieces of at most 64 MB of staging: the pinned buffer stays modest, and a piece's DMA runs beside the next piece's copy)
+        size_t i0 = 0;
+        while (i0 < up.size()) {
+            size_t i1 = i0, bytes = 0;
+            while (i1 < up.size() && (i1 == i0 || bytes + up[i1].bytes <= (64u << 20))) bytes += (up[i1++].bytes + 255) & ~(size_t)255;
+            if ((rc = upload_arrays(h, up.data() + i0, (int)(i1 - i0), true))) return rc;
+            i0 = i1;
+        }
+    }
+    if (n_sweeps == 1) {
+        if (var_updates) {
+            if (!(var_updates[0] >= 0.f)) h->floor_dirty = true;
+            if (h->n_pending == kMaxPending) { rc = flush_pending(h, false); if (rc) return rc; }
+            h->pending[h->n_pending++] = var_updates[0];
+        }
+        PassInput in; in.src = 0; in.n = N; in.params = params; in.device_input = true;
+        in.xyzi = reinterpret_cast<const float4*>(d);
+        return run_pipeline(h, in);
+    }
+    PassInput in; in.src = 0; in.n_sweeps = n_sweeps; in.n = N; in.params = params;
+    in.offsets = offsets.data(); in.var_updates = var_updates;
+    in.xyzi = reinterpret_cast<const float4*>(d);
     return run_pipeline(h, in);
 }
 

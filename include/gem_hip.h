@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GEM_ABI_VERSION 8
+#define GEM_ABI_VERSION 9
 
 typedef enum gem_status {
     GEM_OK = 0,
@@ -170,6 +170,13 @@ int  gem_add_aos(gem_handle* h, const gem_frame_params* p, int n, const void* po
  *      cloud s = d_xyzi + 16*offsets[s], offsets has n_sweeps+1 entries.                           */
 int  gem_add_batch_device(gem_handle* h, int n_sweeps, const gem_frame_params* params,
                           const void* d_xyzi, const long long* offsets, const float* var_updates);
+
+/* ... the same from HOST memory (the reference's caller owns host arrays, EMg.cpp:260-283, GPU:1096-1141):
+ *      sweep s = clouds_host[s][0 .. 4 * counts[s]) floats (XYZI points).  The sweeps are copied into the handle's own
+ *      device arena one behind the other -- the staging copy of a sweep beside the DMA of the one before -- and fused by
+ *      one batched pass; the caller's arrays have been read when the call returns.                                */
+int  gem_add_batch(gem_handle* h, int n_sweeps, const gem_frame_params* params, const float* const* clouds_host,
+                   const int* counts, const float* var_updates);
 
 /* ---- Mapvar_update (GPU:1146-1152, called RMU.cpp:81) ------------------------------------------ */
 int  gem_mapvar_update(gem_handle* h, float var_update);

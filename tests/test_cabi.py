@@ -45,7 +45,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in gem_hip.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes prototype"
-    assert lib.gem_abi_version() == 8
+    assert lib.gem_abi_version() == 9
     dbg = declared_symbols(ROOT / "include" / "gem_hip_debug.h")         # knobs / profiling aids: exported, bound, not in gem_hip.h
     assert dbg and not set(dbg) & set(names)
     for n in dbg:

@@ -988,3 +988,49 @@ def test_device_sweep_stream(oracle_mod):
     for _ in range(2):
         gpu.add(f, torch.from_numpy(c).to("cuda:0")); ref.add(f, c)
     assert_maps_match(gpu, ref)
+
+
+# ---- the host-pointer entry points with their uploads left in flight (round 5) ---------------------------------------------------
+def test_add_batch_from_host_arrays(oracle_mod):
+    """gem_add_batch: the sweeps as separate HOST arrays -- ragged, one empty, one too short for the staging buffer --
+    against the oracle and against the device-resident batch."""
+    import torch
+    wl = synth.config_c4(n_sweeps=5)
+    gpu, ref = make_pair(oracle_mod, wl.length, wl.resolution)
+    sizes = [131072, 100003, 7, 0, 131072]
+    clouds = [np.ascontiguousarray(c[:n]) for c, n in zip(wl.clouds, sizes)]
+    gpu.mapvar_update(7e-6); ref.mapvar_update(7e-6)
+    gpu.add_batch_host(wl.frames, clouds, wl.var_updates)
+    for k in range(5):
+        ref.mapvar_update(wl.var_updates[k]); ref.add(wl.frames[k], clouds[k])
+    assert_maps_match(gpu, ref)
+    dev = ElevationMap(wl.length, wl.resolution)
+    dev.mapvar_update(7e-6)
+    dev.add_batch(wl.frames, torch.from_numpy(np.concatenate(clouds, 0)).to("cuda:0"), np.concatenate([[0], np.cumsum(sizes)]), wl.var_updates)
+    assert np.array_equal(dev.layer("elevation"), gpu.layer("elevation")) and np.array_equal(dev.layer("variance"), gpu.layer("variance"))
+    # twice in a row (the second call's copies go into the other half of the staging buffer while the first's DMA may still run),
+    # then a single-sweep batch with its increment
+    gpu.add_batch_host(wl.frames, clouds, wl.var_updates); gpu.add_batch_host(wl.frames[:1], clouds[:1], wl.var_updates[:1])
+    for k in list(range(5)) + [0]:
+        ref.mapvar_update(wl.var_updates[k]); ref.add(wl.frames[k], clouds[k])
+    assert_maps_match(gpu, ref)
+
+
+def test_stream_of_host_sweeps_with_the_uploads_in_flight(oracle_mod):
+    """gem_add from host arrays, call after call without a synchronisation in between: every call returns with its DMA in flight and
+    the next one fills the other half of the staging buffer; clouds of different sizes (a later, larger one makes the buffer grow;
+    small ones take the runtime's path), a caller that overwrites its array right after the call, map reads in between."""
+    wl = synth.config_c4(n_sweeps=8)
+    gpu, ref = make_pair(oracle_mod, wl.length, wl.resolution)
+    sizes = [40000, 131072, 9000, 131072, 65536, 131072, 131072, 120001]
+    buf = np.empty((131072, 4), np.float32)
+    for k in range(8):
+        n = sizes[k]
+        buf[:n] = wl.clouds[k][:n]
+        if k == 5:
+            gpu.mapvar_update(3e-5); ref.mapvar_update(3e-5)
+        gpu.add(wl.frames[k], buf[:n]); ref.add(wl.frames[k], wl.clouds[k][:n])
+        buf[:n] = np.nan                                                 # the caller's array is its own again when the call returns
+        if k in (2, 6):
+            assert_maps_match(gpu, ref)
+    assert_maps_match(gpu, ref)

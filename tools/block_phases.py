@@ -46,6 +46,7 @@ vals = np.stack([s[:, 1] - s[:, 0], s[:, 2], s[:, 3], s[:, 4], s[:, 5]], 1)
 print("sum over blocks (Mcycles):", {k: round(float(v) / 1e6, 2) for k, v in zip(names, vals.sum(0))}, "total", round(float(tot.sum()) / 1e6, 2))
 print("records/block: mean %.0f max %d; batches: mean %.2f max %d; sum of longest chains (wave 0): mean %.1f max %d" %
       (s[:, 7].mean(), s[:, 7].max(), s[:, 8].mean(), s[:, 8].max(), s[:, 9].mean(), s[:, 9].max()))
+print("blocks by records: " + ", ".join(f">= {t}: {int((s[:, 7] >= t).sum())}" for t in (2048, 4096, 6144, 8192, 12288)))
 order = np.argsort(-tot)
 for i in order[:8]:
     print(f"  ticks per chain step {vals[i][4] / max(s[i, 9], 1):.0f} rare steps {s[i, 10]} before-the-loops {s[i, 11]}", end=" ")
