@@ -118,6 +118,7 @@ struct gem_handle {
     bool ride_events = true;            // the sort's last dispatch carries the event the walk waits for (no marker behind it)
     int  walk_lds_pad = 0;              // k_fuse_block: extra dynamic LDS per workgroup (debug knob: fewer workgroups per CU)
     int  walk_prio = 4096;              // k_fuse_block: blocks of at least this many records run at raised issue priority (debug knob, 0 = off)
+    int  sort_chunk = 0;                // records per counting-sort chunk: 0 = by the pass's size (sort_chunk_for), 1024 / 4096 forced (debug knob)
     bool light_fast = true;             // k_fuse_block's light rounds by arrival slots + sorting network (debug knob)
     bool cache_tables = true;           // batched calls: skip building / uploading tables equal to the ones the buffer set already holds (debug knob)
     std::vector<unsigned char> key_scratch;
@@ -753,7 +754,7 @@ SortGeometry sort_geometry(const gem_handle* h, int n_sweeps, bool block_form)
     g.ok = g.id_bits <= 26 && n_sweeps <= max_sweeps && g.dshift[g.n_passes - 1] >= 8 && shift == g.id_bits;
     for (int i = 0; i < g.n_passes; ++i) {
         g.ok = g.ok && g.dbins[i] <= kSortMaxBins && g.dbits[i] >= 1;
-        g.ok = g.ok && sort_shape(g.dbins[i], true).lds <= 160 * 1024;                      // what launch_sort checks (a forced pass count may not fit)
+        g.ok = g.ok && sort_shape(g.dbins[i], true, kSortChunkRecords).lds <= 160 * 1024;   // what launch_sort checks (a forced pass count may not fit; the big chunk needs the most)
     }
     return g;
 }
@@ -784,7 +785,8 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
 {
     const bool batched = in.n_sweeps > 1;
     const bool with_src = (attr & 3) != 0;
-    const SortShape sh1 = sort_shape(geo.dbins[0], with_src);
+    const int chunk = sort_chunk_for(in.n, h->sort_chunk);              // 1024-record chunks for passes that 4096-record ones would leave on a third of the chip
+    const SortShape sh1 = sort_shape(geo.dbins[0], with_src, chunk);
     std::vector<int> chunk0(in.n_sweeps + 1, 0);
     for (int s = 0; s < in.n_sweeps; ++s) {
         const long long cnt = batched ? in.offsets[s + 1] - in.offsets[s] : in.n;
@@ -926,7 +928,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     sa.tiles_per_row = geo.tiles_per_row; sa.T = T;
     sa.id_bits = geo.id_bits; sa.n_passes = geo.n_passes;
     for (int i = 0; i < 3; ++i) { sa.dshift[i] = geo.dshift[i]; sa.dbits[i] = geo.dbits[i]; sa.dbins[i] = geo.dbins[i]; }
-    sa.n_chunks1 = NC1;
+    sa.n_chunks1 = NC1; sa.chunk = chunk;
     unsigned char* misc = static_cast<unsigned char*>(pb.s_misc.p);
     for (int i = 0; i < geo.n_passes; ++i) {
         sa.cnt[i] = static_cast<uint32_t*>(i == 0 ? pb.s_cnt1.p : pb.s_cnt2.p);
@@ -1853,8 +1855,14 @@ int gem_reserve(gem_handle* h, long long max_points, int max_sweeps, int with_co
         SortGeometry geo = sort_geometry(h, sweeps, block_form);
         if (!geo.ok) geo = sort_geometry(h, sweeps, !block_form);
         if (!geo.ok) return GEM_OK;                                      // (such a pass takes the tile pipeline)
-        const size_t N = (size_t)points, chunk = (size_t)kSortChunkRecords;
-        const size_t NC1 = (N + chunk - 1) / chunk + (size_t)sweeps, nc2 = (N + chunk - 1) / chunk;
+        // chunks: a pass of fewer points may take the small chunk (sort_chunk_for) and then has MORE chunks than the largest pass
+        const size_t N = (size_t)points;
+        size_t nc_max = 0;
+        for (const long long pts : {points, std::min<long long>(points, 2ll * 256 * kSortChunkRecords - 1)}) {
+            const size_t c = (size_t)sort_chunk_for(pts, h->sort_chunk);
+            nc_max = std::max(nc_max, ((size_t)pts + c - 1) / c);
+        }
+        const size_t NC1 = nc_max + (size_t)sweeps, nc2 = nc_max;
         int bins_hi = 1;
         for (int i = 1; i < geo.n_passes; ++i) bins_hi = std::max(bins_hi, geo.dbins[i]);
         size_t misc = 0;
@@ -2157,7 +2165,7 @@ static int colorize_device(gem_handle* h, const gem_camera* cam, int n, float* d
     sa.n_sweeps = 1; sa.n = n; sa.xyzi = reinterpret_cast<const float4*>(d_xyzi);
     for (int k = 0; k < 12; ++k) sa.cam.P[k] = cam->lidar_to_image[k];
     sa.cam.width = cam->width; sa.cam.height = cam->height;
-    sa.tiles_per_row = 1; sa.T = 1; sa.n_chunks1 = (int)NC;
+    sa.tiles_per_row = 1; sa.T = 1; sa.n_chunks1 = (int)NC; sa.chunk = kSortChunkRecords;
     for (int i = 0; i < sa.n_passes; ++i) {
         sa.cnt[i] = reinterpret_cast<uint32_t*>(d + (i == 0 ? o_cnt1 : o_cnt2));
         sa.segtot[i] = reinterpret_cast<uint32_t*>(d + o_seg[i]);
@@ -2323,6 +2331,7 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "walk_lds_pad")       { if (value < 0 || value > 100 * 1024) return fail(h, GEM_ERR_INVALID, "walk_lds_pad: 0 .. 102400 bytes"); h->walk_lds_pad = (int)value; }
     else if (k == "ride_events")        { if (value < 0 || value > 1) return fail(h, GEM_ERR_INVALID, "ride_events: 0 or 1"); h->ride_events = value != 0; }
     else if (k == "copy_threads")       { if (value < 0 || value > gem::CopyPool::kMaxThreads) return fail(h, GEM_ERR_INVALID, "copy_threads: 0 (the runtime's pageable path) .. 16"); h->copy_threads = (int)value; }
+    else if (k == "sort_chunk")         { if (value != 0 && value != kSortChunkSmall && value != kSortChunkRecords) return fail(h, GEM_ERR_INVALID, "sort_chunk: 0 (by pass), 1024 or 4096"); h->sort_chunk = (int)value; }
     else if (k == "walk_prio")          { if (value < 0 || value > (1 << 30)) return fail(h, GEM_ERR_INVALID, "walk_prio: 0 (off) or a record count"); h->walk_prio = (int)value; }
     else if (k == "blk_batch")          { if (value != 0 && value != 512 && value != 2048) return fail(h, GEM_ERR_INVALID, "blk_batch: 0 (by pass), 512 or 2048"); h->blk_batch = (int)value; }
     else if (k == "few_bins")           { if (value < -1 || value > 64) return fail(h, GEM_ERR_INVALID, "few_bins: -1 (one ballot per digit bit), 0 (by pass), 1..64"); h->few_bins = (int)value; }

@@ -134,6 +134,7 @@ struct SortArgs {
     uint32_t *key_a, *key_b, *src_a, *src_b;      // keys; source point | colour flag << 31 (src only when colours are fused)
     unsigned long long* counters;      // optional: [0] += records
     uint32_t* odd_flag; uint32_t epoch; // k_sort_project stores `epoch` here when a record's h or v lies outside the plain range of the walks' chain loops
+    int chunk;                         // records per counting-sort chunk of this pass: kSortChunkRecords, or kSortChunkSmall for passes that would not fill the chip otherwise (sort_chunk_for)
 };
 
 // one counting-sort pass over a digit of the key
@@ -150,6 +151,7 @@ struct PassArgs {
     unsigned long long* counters;
     int few_bins;                                // COHERENT ranking: ballots per wave instruction before the LDS way takes over (kFewBins)
     int coherent;                                // coarse digits (block-sorted form): consecutive records mostly share their bin
+    int chunk;                                   // records per chunk (SortArgs::chunk)
 };
 
 struct WalkArgs {
@@ -200,14 +202,22 @@ inline int walk_plain_env(float var_floor, float mahal, const float* pending, in
 
 struct LaunchEvents { hipEvent_t start = nullptr, stop = nullptr; };   // optional dispatch time-stamps
 struct SortShape { int nt, chunk; size_t lds; };
-SortShape  sort_shape(int bins, bool attr);   // workgroup shape of a pass with that many bins
+SortShape  sort_shape(int bins, bool attr, int chunk);   // workgroup shape of a pass with that many bins and that chunk
 hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, const LaunchEvents ev[9]);   // project, scan, scatter | count, scan, scatter | (count, scan, scatter)
 hipError_t launch_walk(hipStream_t st, const WalkArgs& a, int flags, LaunchEvents ev);                    // cell-sorted records
 hipError_t launch_block_prefix(hipStream_t st, uint32_t* blk_cnt, int n_blocks, uint2* ranges);   // ranges[b] = {first, end} of block b in the sorted records; leaves blk_cnt zero
 hipError_t launch_block_walk(hipStream_t st, const WalkArgs& a, int flags, LaunchEvents ev);              // block-sorted records
 constexpr int kOnePassMaxBins = 2048;  // block-sorted: maps of up to this many blocks are sorted by ONE counting-sort pass
 hipError_t launch_strip_bounds(hipStream_t st, const uint32_t* keys, const uint32_t* n_records, int id_bits, const uint32_t* ids, uint32_t* out, int n);
-constexpr int kSortChunkRecords = 4096, kSortSegsPerChunk = 4;   // records per counting-sort chunk; 1024-point wave segments per pass-1 chunk (seg_cnt words)
+constexpr int kSortChunkRecords = 4096, kSortSegsPerChunk = 4;   // records per counting-sort chunk; wave segments per pass-1 chunk (seg_cnt words: a quarter of a chunk each)
+constexpr int kSortChunkSmall = 1024;  // ... of passes too small to fill the chip with chunks of 4096 (a 307 200-point depth image: 75 workgroups on 256 CUs)
+// The chunk of a pass of n points: every kernel of the sort launches one workgroup per chunk, and below ~2 chunks per CU the chip idles
+// (round 4, C3: k_sort_project / count / scatter at 75 workgroups, 51 us for 8.6 MB).
+inline int sort_chunk_for(long long n, int forced = 0)
+{
+    if (forced == kSortChunkRecords || forced == kSortChunkSmall) return forced;
+    return n / kSortChunkRecords < 2 * 256 ? kSortChunkSmall : kSortChunkRecords;
+}
 constexpr int kSortMaxBins = 8000;     // bins per pass the sorted pipeline handles (LDS of k_sort_scatter)
 
 hipError_t launch_project(hipStream_t st, const FrameConst& fc, int first, int n, float* x, float* y, float* z, const int* orig,

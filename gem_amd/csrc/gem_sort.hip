@@ -49,8 +49,8 @@
 
 namespace gem {
 
-constexpr int kSortChunk = kSortChunkRecords;    // records per chunk of every pass (its sorted copy is staged in LDS)
-static_assert(kSortChunk == kSortSegsPerChunk * 1024, "k_sort_project: four waves of 1024 points per chunk, one seg_cnt word each");
+constexpr int kSortChunk = kSortChunkRecords;    // records per chunk of a big pass (its sorted copy is staged in LDS); small passes: kSortChunkSmall
+static_assert(kSortSegsPerChunk == 4, "k_sort_project: four waves per chunk, one seg_cnt word each");
 constexpr uint32_t kKeyInvalid = 0xffffffffu;   // key of a rejected / outside point in the input-ordered record arrays
 
 // ------------------------------------------------------------------------------------------
@@ -136,10 +136,10 @@ __device__ __forceinline__ ChunkRange chunk_range(const int* __restrict__ sweep_
 // ------------------------------------------------------------------------------------------
 // (256-thread workgroups whatever the chunk size: the projection needs ~100 VGPRs, and five light workgroups per CU hide its
 //  load latency better than one of 1024 threads)
-template <int SRC>
+template <int SRC, int CH>
 __global__ __launch_bounds__(256, (SRC == 4 ? 4 : (SRC == 2 ? 3 : 1))) void k_sort_project(SortArgs a)
 {
-    constexpr int NT = 256, CH = kSortChunk, K = CH / NT;
+    constexpr int NT = 256, K = CH / NT, KB = K < 8 ? K : 8;           // KB: point loads of a thread in flight together
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_sort[];
     uint32_t* hist = lds_sort;                                         // [bins0]
     __shared__ uint32_t btag[NT], bcnt[NT];                            // the chunk's records per block, direct-mapped by the block id's low bits (a.blk_cnt)
@@ -164,14 +164,14 @@ __global__ __launch_bounds__(256, (SRC == 4 ? 4 : (SRC == 2 ? 3 : 1))) void k_so
     const uint32_t d0mask = (1u << a.dbits[0]) - 1u, d0shift = (uint32_t)a.dshift[0];
     __syncthreads();
     // blocks of eight points: the loads of a block are in flight together, then each point is projected, stored and counted
-    for (int k0 = 0; k0 < K; k0 += 8) {
-        float4 p[8];
+    for (int k0 = 0; k0 < K; k0 += KB) {
+        float4 p[KB];
         if (SRC != 1) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { const long long i = base + (k0 + k) * 64; p[k] = a.xyzi[i < cr.end ? i : cr.first]; }
+            for (int k = 0; k < KB; ++k) { const long long i = base + (k0 + k) * 64; p[k] = a.xyzi[i < cr.end ? i : cr.first]; }
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < KB; ++k) {
             const long long i = base + (k0 + k) * 64;
             Binned b; b.valid = false;
             if constexpr (SRC == 4) {
@@ -240,13 +240,13 @@ constexpr int kScanSegs = 4;
 __device__ __forceinline__ int scan_seg_chunks(int nc) { return (nc + kScanSegs - 1) / kScanSegs; }     // chunks per segment
 
 __global__ __launch_bounds__(1024) void k_sort_scan(uint32_t* __restrict__ cnt, uint32_t* __restrict__ segtot, int bins, int n_chunks,
-                                                    const uint32_t* __restrict__ records, uint32_t* __restrict__ total_out)
+                                                    const uint32_t* __restrict__ records, uint32_t* __restrict__ total_out, int chunk_records)
 {
     __shared__ uint32_t part[16][64];
     const int lane = lane_id(), w = (int)(threadIdx.x >> 6), seg = (int)blockIdx.y;
     const int b = (int)blockIdx.x * 64 + lane;
     // pass 2: the number of chunks depends on how many records pass 1 kept (known on the device only)
-    const int nc = records ? (int)(((unsigned long long)*records + (unsigned)kSortChunk - 1u) / (unsigned)kSortChunk) : n_chunks;
+    const int nc = records ? (int)(((unsigned long long)*records + (unsigned)chunk_records - 1u) / (unsigned)chunk_records) : n_chunks;
     const int Q = scan_seg_chunks(nc);
     const int s_lo = min(nc, seg * Q), s_hi = min(nc, s_lo + Q);
     const int S = (Q + 15) >> 4;
@@ -319,10 +319,10 @@ __host__ __device__ constexpr size_t rank_words(int nw, int bins) { return (size
 // count + scatter of one digit (both passes), chunks of kSortChunk records.  Pass 1 reads the input-ordered records of
 // k_sort_project (sweep-aligned chunks, rejected points carry an invalid key); pass 2 reads the output of pass 1.
 // ------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, int CH>
 __global__ __launch_bounds__(NT) void k_sort_count(PassArgs a)
 {
-    constexpr int CH = kSortChunk, K = CH / NT;
+    constexpr int K = CH / NT;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_sort[];
     uint32_t* hist = lds_sort;                                         // [bins]
     const int tid = (int)threadIdx.x, chunk = (int)blockIdx.x;
@@ -361,10 +361,10 @@ __global__ __launch_bounds__(NT) void k_sort_count(PassArgs a)
 // The chunk's records are ranked (stable), put into LDS in their sorted order and written out from there: consecutive threads
 // then write consecutive records of a bin -- runs of several records, 64-byte segments -- instead of 64 lanes writing 64
 // scattered 8-byte pieces (which cost 55 us for the 2.9 M records of C4 against 24 from LDS).
-template <int NT, bool ATTR, bool COHERENT>
+template <int NT, bool ATTR, bool COHERENT, int CH>
 __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void k_sort_scatter(PassArgs a)
 {
-    constexpr int NW = NT / 64, CH = kSortChunk, K = CH / NT;
+    constexpr int NW = NT / 64, K = CH / NT, SEG = CH / kSortSegsPerChunk;     // SEG: slots of a k_sort_project wave's segment
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_sort[];
     const int bins = a.bins;
     uint32_t* lbase = lds_sort;                                        // [bins] first LOCAL (chunk-sorted) position of every bin
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void k_sort_scatter(PassAr
     // pass 1: the wave's 512 or 1024 positions lie in ONE 1024-slot segment of the chunk, whose first seg_cnt records are there
     // (k_sort_project); the later passes read dense arrays
     uint32_t seg_off = 0, seg_n = 0xffffffffu;
-    if (a.seg_cnt) { const uint32_t pos = (uint32_t)(w * (K * 64)); seg_off = pos & 1023u; seg_n = a.seg_cnt[(size_t)chunk * kSortSegsPerChunk + (pos >> 10)]; }
+    if (a.seg_cnt) { const uint32_t pos = (uint32_t)(w * (K * 64)); seg_off = pos % (uint32_t)SEG; seg_n = a.seg_cnt[(size_t)chunk * kSortSegsPerChunk + pos / (uint32_t)SEG]; }
     uint2 hv[K]; uint32_t key[K], src[K], rk[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -1618,13 +1618,13 @@ __global__ __launch_bounds__(64) void k_strip_bounds(const uint32_t* __restrict_
 
 // Threads of the count / scatter workgroups of a pass with `bins` bins.  LDS of k_sort_scatter: 2 bins + 16 words + the larger of
 // the ranking tables (rank_words) and the staged chunk (3 or 4 words per record).
-SortShape sort_shape(int bins, bool attr)
+SortShape sort_shape(int bins, bool attr, int chunk)
 {
     SortShape s;
-    const size_t stage = (size_t)(attr ? 4 : 3) * kSortChunk;
+    const size_t stage = (size_t)(attr ? 4 : 3) * chunk;
     // eight waves while two workgroups of them fit a CU's LDS (the ranking tables of 1444 bins x 8 waves exceed the stage: 74 KB)
     s.nt = ((size_t)2 * bins + 16 + std::max(rank_words(8, bins), stage)) * 4 <= 80 * 1024 ? 512 : 256;
-    s.chunk = kSortChunk;
+    s.chunk = chunk;
     s.lds = ((size_t)2 * bins + 16 + std::max(rank_words(s.nt / 64, bins), stage)) * 4;
     return s;
 }
@@ -1654,51 +1654,66 @@ static hipError_t lds_opt_in(const void* fn, size_t lds)
 static hipError_t launch_project(hipStream_t st, const SortArgs& a, int src, LaunchEvents ev)
 {
     const size_t lds = (size_t)a.dbins[0] * 4;
-    if (src == 0)      GEM_LAUNCH((k_sort_project<0>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
-    else if (src == 2) GEM_LAUNCH((k_sort_project<2>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
-    else if (src == 4) GEM_LAUNCH((k_sort_project<4>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
-    else if (src == 3) GEM_LAUNCH((k_sort_project<3>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
-    else               GEM_LAUNCH((k_sort_project<1>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
+    if (a.chunk == kSortChunkSmall) {
+        constexpr int C = kSortChunkSmall;
+        if (src == 0)      GEM_LAUNCH((k_sort_project<0, C>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
+        else if (src == 2) GEM_LAUNCH((k_sort_project<2, C>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
+        else if (src == 4) GEM_LAUNCH((k_sort_project<4, C>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
+        else if (src == 3) GEM_LAUNCH((k_sort_project<3, C>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
+        else               GEM_LAUNCH((k_sort_project<1, C>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
+        return hipGetLastError();
+    }
+    constexpr int C = kSortChunk;
+    if (src == 0)      GEM_LAUNCH((k_sort_project<0, C>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
+    else if (src == 2) GEM_LAUNCH((k_sort_project<2, C>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
+    else if (src == 4) GEM_LAUNCH((k_sort_project<4, C>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
+    else if (src == 3) GEM_LAUNCH((k_sort_project<3, C>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
+    else               GEM_LAUNCH((k_sort_project<1, C>), dim3(a.n_chunks1), dim3(256), lds, st, ev, a);
     return hipGetLastError();
 }
 
-template <int NT, bool ATTR, bool COHERENT>
+template <int NT, bool ATTR, bool COHERENT, int CH>
 static hipError_t launch_scatter(hipStream_t st, const PassArgs& p, int grid, size_t lds, LaunchEvents ev)
 {
-    const hipError_t e = lds_opt_in((const void*)k_sort_scatter<NT, ATTR, COHERENT>, lds);
+    const hipError_t e = lds_opt_in((const void*)k_sort_scatter<NT, ATTR, COHERENT, CH>, lds);
     if (e != hipSuccess) return e;
-    GEM_LAUNCH((k_sort_scatter<NT, ATTR, COHERENT>), dim3(grid), dim3(NT), lds, st, ev, p);
+    GEM_LAUNCH((k_sort_scatter<NT, ATTR, COHERENT, CH>), dim3(grid), dim3(NT), lds, st, ev, p);
     return hipGetLastError();
 }
 
-template <int NT>
+template <int NT, int CH>
 static hipError_t launch_pass_nt(hipStream_t st, const PassArgs& p, bool attr, bool coherent, int grid, bool count, size_t lds, LaunchEvents ev)
 {
     if (count) {
-        GEM_LAUNCH((k_sort_count<NT>), dim3(grid), dim3(NT), (size_t)p.bins * 4, st, ev, p);
+        GEM_LAUNCH((k_sort_count<NT, CH>), dim3(grid), dim3(NT), (size_t)p.bins * 4, st, ev, p);
         return hipGetLastError();
     }
-    if (attr) return coherent ? launch_scatter<NT, true, true>(st, p, grid, lds, ev) : launch_scatter<NT, true, false>(st, p, grid, lds, ev);
-    return coherent ? launch_scatter<NT, false, true>(st, p, grid, lds, ev) : launch_scatter<NT, false, false>(st, p, grid, lds, ev);
+    if (attr) return coherent ? launch_scatter<NT, true, true, CH>(st, p, grid, lds, ev) : launch_scatter<NT, true, false, CH>(st, p, grid, lds, ev);
+    return coherent ? launch_scatter<NT, false, true, CH>(st, p, grid, lds, ev) : launch_scatter<NT, false, false, CH>(st, p, grid, lds, ev);
 }
 
 static hipError_t launch_pass(hipStream_t st, const SortShape& sh, const PassArgs& p, bool attr, bool coherent, int grid, bool count, LaunchEvents ev)
 {
-    if (sh.nt == 512) return launch_pass_nt<512>(st, p, attr, coherent, grid, count, sh.lds, ev);
-    return launch_pass_nt<256>(st, p, attr, coherent, grid, count, sh.lds, ev);
+    if (sh.chunk == kSortChunkSmall) {
+        if (sh.nt == 512) return launch_pass_nt<512, kSortChunkSmall>(st, p, attr, coherent, grid, count, sh.lds, ev);
+        return launch_pass_nt<256, kSortChunkSmall>(st, p, attr, coherent, grid, count, sh.lds, ev);
+    }
+    if (sh.nt == 512) return launch_pass_nt<512, kSortChunk>(st, p, attr, coherent, grid, count, sh.lds, ev);
+    return launch_pass_nt<256, kSortChunk>(st, p, attr, coherent, grid, count, sh.lds, ev);
 }
 
 hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, const LaunchEvents ev[9])
 {
-    if (a.n <= 0 || a.n_chunks1 <= 0 || a.n_passes < 1 || a.n_passes > 3) return hipErrorInvalidValue;
+    if (a.n <= 0 || a.n_chunks1 <= 0 || a.n_passes < 1 || a.n_passes > 3 || (a.chunk != kSortChunk && a.chunk != kSortChunkSmall)) return hipErrorInvalidValue;
     SortShape sh[3];
-    for (int i = 0; i < a.n_passes; ++i) { sh[i] = sort_shape(a.dbins[i], attr); if (sh[i].lds > 160 * 1024) return hipErrorInvalidValue; }
+    for (int i = 0; i < a.n_passes; ++i) { sh[i] = sort_shape(a.dbins[i], attr, a.chunk); if (sh[i].lds > 160 * 1024) return hipErrorInvalidValue; }
     hipError_t e;
     // ---- pass 1: project + count, scan, scatter by the lowest digit (input order in arrays a -> arrays b)
     if ((e = launch_project(st, a, src, ev[0])) != hipSuccess) return e;
     GEM_LAUNCH(k_sort_scan, dim3((a.dbins[0] + 63) / 64, kScanSegs), dim3(1024), 0, st, ev[1], a.cnt[0], a.segtot[0], a.dbins[0], a.n_chunks1,
-               (const uint32_t*)nullptr, a.total);
+               (const uint32_t*)nullptr, a.total, a.chunk);
     PassArgs p{};
+    p.chunk = a.chunk;
     p.hv_in = a.hv_a; p.key_in = a.key_a; p.src_in = a.src_a; p.hv_out = a.hv_b; p.key_out = a.key_b; p.src_out = a.src_b;
     p.cnt = a.cnt[0]; p.segtot = a.segtot[0]; p.n_chunks = a.n_chunks1; p.bins = a.dbins[0]; p.shift = a.dshift[0]; p.digit_bits = a.dbits[0];
     p.mask = (1u << a.dbits[0]) - 1u;
@@ -1712,7 +1727,7 @@ hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, co
     if ((e = launch_pass(st, sh[0], p, attr, coherent, a.n_chunks1, false, ev[2])) != hipSuccess) return e;
     // ---- the higher digits: count, scan, scatter on the records of the pass before (ping-pong between the arrays); the
     //      live chunks are known on the device only
-    const int grid = std::max(1, (int)((a.n + kSortChunk - 1) / kSortChunk));
+    const int grid = std::max(1, (int)((a.n + a.chunk - 1) / a.chunk));
     for (int i = 1; i < a.n_passes; ++i) {
         const bool from_b = (i & 1) != 0, last = i == a.n_passes - 1;
         p.hv_in = from_b ? a.hv_b : a.hv_a; p.key_in = from_b ? a.key_b : a.key_a; p.src_in = from_b ? a.src_b : a.src_a;
@@ -1724,7 +1739,7 @@ hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, co
         p.few_bins = a.few_bins != 0 ? a.few_bins : kFewBins;
         if ((e = launch_pass(st, sh[i], p, attr, coherent, grid, true, ev[3 * i])) != hipSuccess) return e;
         GEM_LAUNCH(k_sort_scan, dim3((a.dbins[i] + 63) / 64, kScanSegs), dim3(1024), 0, st, ev[3 * i + 1], a.cnt[i], a.segtot[i], a.dbins[i], 0,
-                   (const uint32_t*)a.total, (uint32_t*)nullptr);
+                   (const uint32_t*)a.total, (uint32_t*)nullptr, a.chunk);
         if ((e = launch_pass(st, sh[i], p, attr, coherent, grid, false, ev[3 * i + 2])) != hipSuccess) return e;
     }
     return hipSuccess;

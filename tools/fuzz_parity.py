@@ -24,7 +24,9 @@ F32 = np.float32
 KNOBS = [{}, {}, {"sort_min_points": 1}, {"sort_min_points": 1, "sort_form": 1}, {"sort_min_points": 1, "sort_form": 2},
          {"sort_min_points": 1, "sort_form": 2, "sort_passes": 2}, {"sort_min_points": 1, "sort_form": 2, "sort_passes": 2, "blk_batch": 2048},
          {"sort_min_points": 1, "sort_form": 2, "blk_batch": 2048}, {"sort_min_points": 1, "sort_form": 1, "sort_passes": 3},
-         {"sort_min_points": 1, "fast_laser": 0}, {"dense_min": 0}, {"sort_min_points": 1, "sort_form": 2, "lane_sort": 0}]
+         {"sort_min_points": 1, "fast_laser": 0}, {"dense_min": 0}, {"sort_min_points": 1, "sort_form": 2, "lane_sort": 0},
+         {"sort_min_points": 1, "sort_form": 1, "sort_chunk": 4096}, {"sort_min_points": 1, "sort_form": 2, "sort_chunk": 4096},
+         {"sort_min_points": 1, "sort_form": 2, "sort_passes": 2, "sort_chunk": 1024}]
 
 
 def make_cloud(rng, kind, n, extent, T):
@@ -125,7 +127,11 @@ def scenario(seed):
                 ora.add(frames[0], c0, rgb, oi)
         else:
             off = np.concatenate([[0], np.cumsum([c.shape[0] for c in clouds])])
-            gpu.add_batch(frames, torch.from_numpy(np.concatenate(clouds, 0)).cuda(), off, incs)
+            if rng.random() < 0.3:                             # the batch as separate HOST arrays (gem_add_batch)
+                entry = "add_batch (host arrays)"
+                gpu.add_batch_host(frames, clouds, incs)
+            else:
+                gpu.add_batch(frames, torch.from_numpy(np.concatenate(clouds, 0)).cuda(), off, incs)
             for k in range(n_sweeps):
                 if incs:
                     ora.mapvar_update(incs[k])

@@ -45,6 +45,28 @@ int main()
         {"event DisableTiming|DisableSystemFence, A dirties 32 MB, stream 2 busy", hipEventDisableTiming | hipEventDisableSystemFence, 1, 0, 1, 0},
         {"stop event of A's dispatch (hipExtLaunch), stream 2 busy", hipEventDisableTiming, 1, 1, 0, 0},
     };
+    // ... and the steady state of the overlapped pipelines: the event stream 2 waits for completed LONG before stream 2's own kernel C
+    // (the walk before) ends -- how long after C does B start then?
+    for (int late_us : {5, 20, 60}) {
+        for (unsigned flags : {(unsigned)hipEventDisableTiming, (unsigned)(hipEventDisableTiming | hipEventDisableSystemFence)}) {
+            hipEvent_t ev; hipEventCreateWithFlags(&ev, flags);
+            std::vector<double> gap;
+            for (int rep = 0; rep < 50; ++rep) {
+                st[0] = st[1] = st[2] = 0;
+                const unsigned long long a_ticks = 2000;
+                hipLaunchKernelGGL(k_spin, dim3(256), dim3(256), 0, s2, a_ticks + 100ull * late_us, st + 2, sink);      // C: ends late_us after A
+                hipLaunchKernelGGL(k_spin, dim3(256), dim3(256), 0, s1, a_ticks, st, sink); hipEventRecord(ev, s1);
+                hipStreamWaitEvent(s2, ev, 0);
+                hipLaunchKernelGGL(k_stamp, dim3(1024), dim3(256), 0, s2, st + 1, data, sink);
+                hipStreamSynchronize(s1); hipStreamSynchronize(s2);
+                if (rep >= 5) gap.push_back(((double)st[1] - (double)st[2]) * 0.01);
+            }
+            std::sort(gap.begin(), gap.end());
+            printf("event %s, completed ~%2d us before stream 2's own kernel C ends          B starts %6.2f us after C ends (median; min %6.2f, max %6.2f)\n",
+                   flags & hipEventDisableSystemFence ? "DisableTiming|DisableSystemFence" : "DisableTiming                   ", late_us, gap[gap.size() / 2], gap.front(), gap.back());
+            hipEventDestroy(ev);
+        }
+    }
     for (const V& v : vs) {
         hipEvent_t ev; hipEventCreateWithFlags(&ev, v.flags ? v.flags : hipEventDefault);
         std::vector<double> gap;
