@@ -370,6 +370,8 @@ template <int CPT> struct TileState { float e[CPT], s[CPT], lw[CPT]; uint32_t tm
 
 // FLAGS: bits 0-1 = ATTR (0 none, 1 colours from the cloud, 2 colours from gem_fuse's arrays), bit 2 = LOWEST (also maintain the
 // map_lowest layer, GPU:432-439, for gem_raytracing)
+constexpr int kFrameRunBits = 3;                    // k_frame: runs of 2^kFrameRunBits neighbouring tiles per XCD (fuse_list_body, RANKED; runs of 2 / 4 / 8: FETCH_SIZE 4.9 / 4.35 / 4.03 MB per C2 frame, 8.56 / 8.41 / 8.40 us per step)
+constexpr int kFrameGridUnit = 8 << kFrameRunBits;  // ... its tile blocks come in multiples of this
 template <int TS, int NT, int PB, int FLAGS, bool BATCH, int MODE, bool RANKED = false>
 __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsigned char* lds_raw, TileState<(1 << (2 * TS)) / NT>& st)
 {
@@ -430,11 +432,20 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
     int tr, tc;
     if constexpr (!BATCH) {
         const int q4 = (a.T + 3) >> 2;
-        // (RANKED: k_frame, whose tiles are all resident at once, starts them in plain centre-first order -- see k_frame)
-        const int rnk = RANKED ? tile : (tile & 3) * q4 + (tile >> 2);
+        // RANKED (k_frame, whose tiles are all resident at once): centre-first in dispatch order, and XCD-AWARE -- workgroup b runs on
+        // XCD b % 8, each XCD has its own L2, and four tiles that follow each other in a tile row share their 128-byte lines of the
+        // layers: runs of 2^kFrameRunBits consecutive ranks go to ONE XCD (with plain rank = block the neighbours sat on eight different XCDs
+        // and every shared line was fetched twice: FETCH_SIZE 5.6 MB per frame instead of 3.6, profiles/r05_c2_bench.txt)
+        int rnk;
+        if (RANKED) { const int x = tile & 7, i = tile >> 3; rnk = ((((i >> kFrameRunBits) << 3) + x) << kFrameRunBits) + (i & ((1 << kFrameRunBits) - 1)); }
+        else rnk = (tile & 3) * q4 + (tile >> 2);
         if (rnk >= a.T) return false;
         const int bi = rnk / tpr, bj = rnk - bi * tpr;
-        const int oi = (bi & 1) ? -((bi + 1) >> 1) : (bi >> 1), oj = (bj & 1) ? -((bj + 1) >> 1) : (bj >> 1);
+        const int oi = (bi & 1) ? -((bi + 1) >> 1) : (bi >> 1);
+        // columns: plain alternation c, c-1, c+1, ... or (RANKED) runs of neighbours on alternating sides: 0 1 2 3 | -1 -2 -3 -4 | 4 5 6 7 | ...
+        int oj;
+        if (RANKED) { const int cj = bj >> kFrameRunBits, t = bj & ((1 << kFrameRunBits) - 1); oj = (cj & 1) ? -(((cj - 1) >> 1) << kFrameRunBits) - 1 - t : ((cj >> 1) << kFrameRunBits) + t; }
+        else oj = (bj & 1) ? -((bj + 1) >> 1) : (bj >> 1);
         tr = a.center_tr + oi; tr = tr < 0 ? tr + tpr : (tr >= tpr ? tr - tpr : tr);
         tc = a.center_tc + oj; tc = tc < 0 ? tc + tpr : (tc >= tpr ? tc - tpr : tc);
         tile = tr * tpr + tc;
@@ -1040,7 +1051,12 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
         if (owned[q]) {
-            const int c = tid + NT * q;
+            int c = tid + NT * q;
+#if defined(__HIP_DEVICE_COMPILE__)
+            // (recomputed from the thread's number HERE: the address of the tile's read, kept alive across the whole kernel for this
+            //  store, was the one value the 80-register budget of k_frame spilled -- 8 bytes per thread, 5 MB of scratch traffic per frame)
+            asm volatile("" : "+v"(c));
+#endif
             const size_t g = (size_t)(row_base + (c >> TS)) * L + col_base + (c & (TE - 1));
             // A sweep touches a fraction of a tile's cells: writing the tile back whole was 1.8 MB of the 4.3 MB a C2 frame wrote
             // (profiles/r01f_c2_bench.txt).  (A tile resumed by the dense copy of the loop has lost its loaded values: written whole.)
@@ -1098,7 +1114,7 @@ template <int FLAGS>
 __global__ __launch_bounds__(256, kFrameWG) void k_frame(FuseArgs fa, BinArgs ba)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
-    const int nf = (fa.T + 3) & ~3;                                      // fuse blocks (see the block -> tile mapping)
+    const int nf = (fa.T + kFrameGridUnit - 1) & ~(kFrameGridUnit - 1);     // fuse blocks (see the block -> tile mapping)
     if ((int)blockIdx.x < nf) { TileState<1> st; fuse_list_body<4, 256, kFramePB, FLAGS, false, 0, true>(fa, (int)blockIdx.x, lds_dyn, st); }
     else bin_wave_body<0, 4, false>(ba, (int)blockIdx.x - nf);
 }
@@ -1597,7 +1613,7 @@ hipError_t launch_fuse(hipStream_t st, const FuseArgs& a, int ts, int attr, int 
 // fuse of the previous frame + bin of this one (single sweeps on 16x16 tiles, no attributes)
 hipError_t launch_frame(hipStream_t st, const FuseArgs& fa, const BinArgs& ba, int attr, LaunchEvents ev)
 {
-    const dim3 grid(((fa.T + 3) & ~3) + (ba.B + 3) / 4), block(256);
+    const dim3 grid(((fa.T + kFrameGridUnit - 1) & ~(kFrameGridUnit - 1)) + (ba.B + 3) / 4), block(256);
     if (attr == 4)      GEM_LAUNCH((k_frame<4>), grid, block, fuse_list_lds(256, 4, kFramePB, 0), st, ev, fa, ba);
     else if (attr == 0) GEM_LAUNCH((k_frame<0>), grid, block, fuse_list_lds(256, 4, kFramePB, 0), st, ev, fa, ba);
     else return hipErrorInvalidValue;
