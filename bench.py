@@ -843,11 +843,13 @@ def main():
             stale = abs(pm[2] - dom_us) > 0.25 * dom_us
             traffic_note += (f"; kernel duration in that run {pm[2]:.2f} us vs {dom_us:.2f} us now" +
                              (" -- MORE THAN 25 % APART: the counters may describe an older kernel, re-run tools/profile_c2.sh" if stale else ""))
+    # (the fuse launch of a stream of sweeps is k_frame WITHOUT a binning half: the last sweep's list, at the synchronisation)
+    fl = "k_frame_fuse_half_only" if st["launches_frame"] > st["launches_fuse"] else "k_fuse_list"
     roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "frac_of_6300": achieved / HBM_ACHIEVABLE_GBS, "traffic": traffic, "traffic_source": traffic_note,
-                "us_per_launch": {"k_frame": us_frame, "k_bin_wave": us_bin, "k_fuse_list": us_fuse},
-                "launches": {"k_frame": st["launches_frame"], "k_bin_wave": st["launches_bin"], "k_fuse_list": st["launches_fuse"]},
-                "algorithmic_bytes_per_launch": {"k_frame": alg_bin + alg_fuse, "k_bin_wave": alg_bin, "k_fuse_list": alg_fuse},
+                "us_per_launch": {"k_frame": us_frame, "k_bin_wave": us_bin, fl: us_fuse},
+                "launches": {"k_frame": st["launches_frame"], "k_bin_wave": st["launches_bin"], fl: st["launches_fuse"]},
+                "algorithmic_bytes_per_launch": {"k_frame": alg_bin + alg_fuse, "k_bin_wave": alg_bin, fl: alg_fuse},
                 "note": "one sweep is ~3 MB of algorithmic traffic (0.5 us at the HBM rate): the frame is launch / latency bound, see "
                         "DESIGN.md section 6; `batched_c4` is the bandwidth-regime figure"}
 

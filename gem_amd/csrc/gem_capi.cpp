@@ -579,7 +579,11 @@ int flush_deferred(gem_handle* h)
     h->main_reads_pb = true;
     if (h->dbg_frame) h->deferred.fa.dbg = nullptr;            // (the stamps of the last k_frame stay readable: this flush is not the launch being profiled)
     Timed t(h, 1);
-    GEM_HIP(h, launch_fuse(h->stream, h->deferred.fa, h->deferred.ts, h->deferred.attr, h->fuse_variant, t.events()));
+    // A deferred list is one k_frame would have fused beside the next sweep's binning (16x16 tiles, one sweep, no attributes):
+    // the same kernel without a binning half -- six workgroups per CU hold every tile of a 600^2 map at once, k_fuse_list's four
+    // take two tile lifetimes (10.0-10.4 us against ~6.5 for the C2 sweep; this launch ends every synchronised run of sweeps)
+    gem::BinArgs no_bin{};
+    GEM_HIP(h, launch_frame(h->stream, h->deferred.fa, no_bin, h->deferred.attr, t.events()));
     return GEM_OK;
 }
 
