@@ -39,7 +39,10 @@ class CopyPool {
 public:
     static constexpr int    kMaxThreads = 16;
     static constexpr size_t kPiece = 64u << 10;
-    static constexpr long long kSpinNs = 300000;
+#ifndef GEM_COPY_SPIN_NS
+#define GEM_COPY_SPIN_NS 300000
+#endif
+    static constexpr long long kSpinNs = GEM_COPY_SPIN_NS;
 
     static CopyPool& get() { static CopyPool* pool = new CopyPool(); return *pool; }   // never destroyed: the workers outlive main()
 
