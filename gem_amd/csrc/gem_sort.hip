@@ -1515,6 +1515,10 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         dbg[2] = acc_rank; dbg[3] = acc_base; dbg[4] = acc_place; dbg[5] = acc_walk; dbg[6] = __builtin_readcyclecounter();
         dbg[8] = n_batches; dbg[9] = acc_nmax; dbg[10] = acc_rare; dbg[11] = acc_pre;
     }
+    if (dbg) {                                                         // per wave: chain steps it ran << 32 | records its lanes fused (lane use of the chains)
+        const uint32_t recs = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(n_total), 63);
+        if (lane == 0) dbg[12 + w] = ((unsigned long long)acc_nmax << 32) | recs;
+    }
     if (__ballot(n_total != 0) == 0 && !a.dense) return;               // nothing reached this wave's cells and nothing is pending
     if constexpr (HAS_VU) rp.finish(cs, last_sw, vu, a.var_floor);
     if (cs < a.var_floor) cs = a.var_floor;                            // GPU:533-534, on every cell

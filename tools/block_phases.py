@@ -57,3 +57,13 @@ for i in late:
     print(f"last to end: end@{s[i, 6] - t0:7d} start@{s[i, 0] - t0:7d} total {tot[i]:7d} R {s[i, 7]:6d} batches {s[i, 8]:3d} chains {s[i, 9]:4d}")
 h = np.histogram(s[:, 0] - t0, bins=8)
 print("start-time histogram:", list(h[0]), [int(x) for x in h[1]])
+# lane use of the chains: every wave runs as many steps as its busiest cell has records in the round; a step is 64 lane-steps
+ws = s[:, 12:16]
+steps = (ws >> 32).astype(np.int64); recs = (ws & 0xffffffff).astype(np.int64)
+if steps.sum() > 0:
+    print("chains, all blocks: %d wave-steps for %d records: lane use %.1f %%; per wave (0 = the busiest cells): " % (steps.sum(), recs.sum(), 100.0 * recs.sum() / (64.0 * steps.sum())) +
+          ", ".join("w%d %d steps / %d records = %.0f %%" % (w, steps[:, w].sum(), recs[:, w].sum(), 100.0 * recs[:, w].sum() / max(64.0 * steps[:, w].sum(), 1)) for w in range(4)))
+    for lo, hi in ((0, 512), (512, 2048), (2048, 8192), (8192, 1 << 30)):
+        sel = (s[:, 7] >= lo) & (s[:, 7] < hi)
+        if sel.any():
+            print("  blocks of %d..%d records: %d blocks, %d wave-steps, lane use %.1f %%" % (lo, hi, int(sel.sum()), steps[sel].sum(), 100.0 * recs[sel].sum() / max(64.0 * steps[sel].sum(), 1)))
