@@ -1780,7 +1780,10 @@ static hipError_t launch_block_walk_fmb(hipStream_t st, const WalkArgs& a, Launc
     return launch_block_walk_fmbm<FLAGS, MODE, B, false>(st, a, ev);
 }
 
-constexpr int kBlkBatch = 2048;   // records of a block staged in LDS per round: three workgroups per CU (4096: two per CU, half the rounds
+#ifndef GEM_BLK_BATCH
+#define GEM_BLK_BATCH 2048
+#endif
+constexpr int kBlkBatch = GEM_BLK_BATCH;   // records of a block staged in LDS per round: three workgroups per CU (4096: two per CU, half the rounds
                                   // for the blocks under the sensor -- whose chains stay as long; C4 104 -> 116 us per batch)
 
 constexpr int kBlkBatchLight = 512;   // ... for passes whose blocks hold a few hundred records each (C5: 10 M points over 22 500 blocks): a quarter of the
