@@ -93,6 +93,13 @@ struct gem_handle {
     // frame's records next to the binning of the new cloud.  The fuse of the newest frame is therefore
     // deferred until the next gem_add_device -- or until anything observes or modifies the map.
     struct Deferred { bool valid = false; FuseArgs fa{}; int ts = 0, attr = 0; } deferred;
+    // The sorted pipeline's walk of an overlapped pass is launched by the NEXT call (or by whatever observes the map): by then its sort
+    // has usually completed, and a walk that need not be put behind a hipStreamWaitEvent starts 1.4 us after the walk before it
+    // instead of 5-7 (tools/ubench/handover.hip: the wait costs that much even when the event completed long before).  A stream of
+    // depth images is bound by exactly that chain of walks (C3: 45.7 us per frame = 38 us walk + the hand-over).
+    struct DeferredWalk { bool valid = false; WalkArgs wa{}; bool block_form = false; int attr = 0; unsigned slot = 0; } dwalk;
+    bool defer_walk = true;             // (debug knob "defer_walk")
+    long long walks_unwaited = 0, walks_left = 0;   // walks left to the next call (gem_debug_get "walks_left"); of those, launched without a stream wait ("walks_unwaited")
     bool defer = true;
     hipStream_t bin_stream = nullptr;
     hipStream_t bin_stream2 = nullptr;  // the sorted pipeline sorts consecutive big passes on two streams (see run_sort_pipeline)
@@ -118,6 +125,7 @@ struct gem_handle {
     bool ride_events = true;            // the sort's last dispatch carries the event the walk waits for (no marker behind it)
     int  walk_lds_pad = 0;              // k_fuse_block: extra dynamic LDS per workgroup (debug knob: fewer workgroups per CU)
     int  walk_prio = 4096;              // k_fuse_block: blocks of at least this many records run at raised issue priority (debug knob, 0 = off)
+    int  fuse_count = 1;                // pass 2's counts from pass 1's scatter (SortArgs::fuse_count): 0 = never, 1 = passes of up to kFuseCountMaxPoints points, 2 = always (debug knob)
     int  sort_chunk = 0;                // records per counting-sort chunk: 0 = by the pass's size (sort_chunk_for), 1024 / 4096 forced (debug knob)
     bool light_fast = true;             // k_fuse_block's light rounds by arrival slots + sorting network (debug knob)
     bool cache_tables = true;           // batched calls: skip building / uploading tables equal to the ones the buffer set already holds (debug knob)
@@ -587,6 +595,22 @@ int flush_deferred(gem_handle* h)
     return GEM_OK;
 }
 
+// The walk a sorted pass left to its successor (gem_handle::dwalk): behind its sort -- by an event wait only if the sort is still running.
+int flush_walk(gem_handle* h)
+{
+    if (!h->dwalk.valid) return GEM_OK;
+    h->dwalk.valid = false;
+    gem_handle::PassBuffers& pb = h->pb[h->dwalk.slot];
+    if (hipEventQuery(pb.bin_done) == hipSuccess) ++h->walks_unwaited;
+    else { (void)hipGetLastError(); GEM_HIP(h, hipStreamWaitEvent(h->stream, pb.bin_done, 0)); }
+    {
+        Timed t(h, 9);
+        GEM_HIP(h, h->dwalk.block_form ? launch_block_walk(h->stream, h->dwalk.wa, h->dwalk.attr, t.events()) : launch_walk(h->stream, h->dwalk.wa, h->dwalk.attr, t.events()));
+    }
+    GEM_HIP(h, hipEventRecord(pb.fuse_done, h->stream)); pb.fuse_recorded = true;
+    return GEM_OK;
+}
+
 // An all-gather of the fused strips still in flight on the gather stream writes the other ranks' strips: whatever observes or
 // modifies the whole map on the handle's stream comes after it.
 int wait_gather(gem_handle* h)
@@ -607,6 +631,7 @@ int ensure_recv(gem_handle* h, int parity, size_t records);
 int settle(gem_handle* h)
 {
     { const int rc = shard_finish_locked(h); if (rc) return rc; }
+    { const int rc = flush_walk(h); if (rc) return rc; }
     { const int rc = flush_deferred(h); if (rc) return rc; }
     return wait_gather(h);
 }
@@ -633,6 +658,7 @@ int index_to_range(int index, int L)          // gpu_process.cu:914-919
 struct PassInput {
     int src = 0;                       // 0 = XYZI cloud, 1 = Fuse() arrays
     bool device_input = false;         // the caller's device buffers are read directly (no staging copy)
+    bool caller_device = false;        // ... and they ARE the caller's (gem_add_device, gem_add_batch_device: untouched until gem_synchronize by contract), not an arena or a staging half of the handle that the next call refills
     int n_sweeps = 1;
     long long n = 0;
     const gem_frame_params* params = nullptr;      // [n_sweeps] (src 0)
@@ -807,6 +833,9 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     bool overlap = h->overlap && in.n >= std::min(h->overlap_min_points, h->sort_overlap_min_points) && h->stream == h->own_stream && !h->counting &&
                    (!shard || shard->bounds_stay_on_device);          // (the halves' sort returns its strip boundaries to the host: nothing to overlap)
     { const int rcd = flush_deferred(h); if (rcd) return rcd; }
+    // this pass leaves its walk to the next call (gem_handle::dwalk) -- and then launches the previous pass's walk late, behind its own sort's launches
+    const bool leave_walk = overlap && !shard && h->defer_walk && in.caller_device && attr == 0 && !h->timing && !h->dbg_on;
+    if (!leave_walk) { const int rcd = flush_walk(h); if (rcd) return rcd; }
     // a shard bins into the WHOLE map (its records go to the strip owners); the frames carry the strip
     const int keep_row0 = h->row0, keep_row1 = h->row1;
     struct RestoreRows { gem_handle* h; int r0, r1; ~RestoreRows() { h->row0 = r0; h->row1 = r1; } } restore{h, keep_row0, keep_row1};
@@ -936,6 +965,11 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     sa.id_bits = geo.id_bits; sa.n_passes = geo.n_passes;
     for (int i = 0; i < 3; ++i) { sa.dshift[i] = geo.dshift[i]; sa.dbits[i] = geo.dbits[i]; sa.dbins[i] = geo.dbins[i]; }
     sa.n_chunks1 = NC1; sa.chunk = chunk;
+    // Small two-pass sorts (a depth image: 300 k points, six launches of 5-10 us each, the frame bound by them and by the host's
+    // enqueue) let pass 1's scatter count pass 2's digit with atomics: one launch and one pass over the keys less.  Big passes keep
+    // k_sort_count: ten million device-scope atomics cost more than its 8 us (k_sort_project's block counts were 4.4 ns each).
+    constexpr long long kFuseCountMaxPoints = 600000;
+    sa.fuse_count = (geo.n_passes >= 2 && (h->fuse_count == 2 || (h->fuse_count == 1 && in.n <= kFuseCountMaxPoints))) ? 1 : 0;
     unsigned char* misc = static_cast<unsigned char*>(pb.s_misc.p);
     for (int i = 0; i < geo.n_passes; ++i) {
         sa.cnt[i] = static_cast<uint32_t*>(i == 0 ? pb.s_cnt1.p : pb.s_cnt2.p);
@@ -994,7 +1028,7 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
         // (a third pass is accounted with the second: count / scan / scatter of the higher digits)
         // (event pairs only for the kernels that are launched: the elapsed time of a pair that was never recorded is an error)
         const bool two = geo.n_passes >= 2, three = geo.n_passes == 3;
-        Timed t0(h, 3), t1(h, 4), t2(h, 5), t3(h, two ? 6 : -1), t4(h, two ? 7 : -1), t5(h, two ? 8 : -1), t6(h, three ? 6 : -1), t7(h, three ? 7 : -1), t8(h, three ? 8 : -1);
+        Timed t0(h, 3), t1(h, 4), t2(h, 5), t3(h, two && !sa.fuse_count ? 6 : -1), t4(h, two ? 7 : -1), t5(h, two ? 8 : -1), t6(h, three ? 6 : -1), t7(h, three ? 7 : -1), t8(h, three ? 8 : -1);
         LaunchEvents ev[9] = {t0.events(), t1.events(), t2.events(), t3.events(), t4.events(), t5.events(), t6.events(), t7.events(), t8.events()};
         // The walk waits for the sort across streams: as the STOP EVENT of the sort's last dispatch the event is seen 3 us earlier
         // than a marker recorded behind it (tools/ubench/handover.hip: 7 against 10 us) -- when that kernel is the last thing on the
@@ -1048,6 +1082,17 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
         pb.blkcnt_dirty = false;
         wa.ranges = static_cast<const uint2*>(pb.s_ranges.p);
     }
+    { const int rcd = flush_walk(h); if (rcd) return rcd; }           // the pass before: its sort has had this call's launches to finish
+    if (leave_walk) {
+        if (!ride_bin) GEM_HIP(h, hipEventRecord(pb.bin_done, sbin));
+        h->dwalk.wa = wa; h->dwalk.block_form = geo.block_form; h->dwalk.attr = attr; h->dwalk.slot = slot; h->dwalk.valid = true;
+        ++h->walks_left;
+        h->dbg_rows = 0;
+        h->n_pending = 0;
+        h->floor_dirty = false;
+        h->stats.points_in = in.n;
+        return GEM_OK;
+    }
     if (overlap) {
         if (!ride_bin) GEM_HIP(h, hipEventRecord(pb.bin_done, sbin));
         GEM_HIP(h, hipStreamWaitEvent(h->stream, pb.bin_done, 0));
@@ -1092,6 +1137,7 @@ int run_pipeline(gem_handle* h, const PassInput& in0)
         if (!geo.ok) { geo = sort_geometry(h, in0.n_sweeps, !block_form); ++h->sort_fallbacks; }    // (a forced form / pass count that does not fit this map: counted, gem_debug_get)
         if (geo.ok) return run_sort_pipeline(h, in0, attr, geo);
     }
+    { const int rcw = flush_walk(h); if (rcw) return rcw; }           // (a sorted pass's walk still to be launched: before anything of this pass fuses)
     // A big single cloud becomes a batch of sweeps with one frame: every tile then only reads the descriptor
     // rows of the sweeps that reach it (flag[tile][sweep]) instead of one row over all units.  The
     // recurrence is unchanged: the per-sweep variance floor is idempotent with the floor at the start of every
@@ -1670,7 +1716,7 @@ int gem_add_device(gem_handle* h, const gem_frame_params* p, int n, const void* 
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
     { const int rcs = shard_finish_locked(h); if (rcs) return rcs; }
-    PassInput in; in.src = 0; in.n = n; in.params = p; in.device_input = true;
+    PassInput in; in.src = 0; in.n = n; in.params = p; in.device_input = true; in.caller_device = true;
     in.xyzi = static_cast<const float4*>(d_xyzi); in.rgb = static_cast<const uint32_t*>(d_rgb); in.orig = static_cast<const int*>(d_orig_index);
     return run_pipeline(h, in);
 }
@@ -1806,11 +1852,11 @@ int gem_add_batch_device(gem_handle* h, int n_sweeps, const gem_frame_params* pa
             if (h->n_pending == kMaxPending) { int rc = flush_pending(h, false); if (rc) return rc; }
             h->pending[h->n_pending++] = var_updates[0];
         }
-        PassInput in; in.src = 0; in.n = offsets[1] - offsets[0]; in.params = params; in.device_input = true;
+        PassInput in; in.src = 0; in.n = offsets[1] - offsets[0]; in.params = params; in.device_input = true; in.caller_device = true;
         in.xyzi = static_cast<const float4*>(d_xyzi) + offsets[0];
         return run_pipeline(h, in);
     }
-    PassInput in; in.src = 0; in.n_sweeps = n_sweeps; in.n = offsets[n_sweeps]; in.params = params;
+    PassInput in; in.src = 0; in.n_sweeps = n_sweeps; in.n = offsets[n_sweeps]; in.params = params; in.caller_device = true;
     in.offsets = offsets; in.var_updates = var_updates;
     in.xyzi = static_cast<const float4*>(d_xyzi);
     return run_pipeline(h, in);
@@ -2306,6 +2352,7 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     if (k == "fuse_variant")            { if (value < 10 || value > 12) return fail(h, GEM_ERR_INVALID, "fuse_variant: 10..12"); h->fuse_variant = (int)value; }
     else if (k == "tile_shift")         { if (value != 0 && value != 4 && value != 5) return fail(h, GEM_ERR_INVALID, "tile_shift: 0, 4 or 5"); h->ts = (int)value; }
     else if (k == "defer")              h->defer = value != 0;
+    else if (k == "defer_walk")         { const int rcw = flush_walk(h); if (rcw) return rcw; h->defer_walk = value != 0; }
     else if (k == "dense_min")          { if (value < 0 || value > 0xffffffffll) return fail(h, GEM_ERR_INVALID, "dense_min: 0 .. 2^32 - 1"); h->dense_min = (unsigned)value; }
     else if (k == "dbg_sweep")          h->dbg_sweep = (int)value;
     else if (k == "dbg_frame")          h->dbg_frame = value != 0;
@@ -2338,6 +2385,7 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "walk_lds_pad")       { if (value < 0 || value > 100 * 1024) return fail(h, GEM_ERR_INVALID, "walk_lds_pad: 0 .. 102400 bytes"); h->walk_lds_pad = (int)value; }
     else if (k == "ride_events")        { if (value < 0 || value > 1) return fail(h, GEM_ERR_INVALID, "ride_events: 0 or 1"); h->ride_events = value != 0; }
     else if (k == "copy_threads")       { if (value < 0 || value > gem::CopyPool::kMaxThreads) return fail(h, GEM_ERR_INVALID, "copy_threads: 0 (the runtime's pageable path) .. 16"); h->copy_threads = (int)value; }
+    else if (k == "fuse_count")         { if (value < 0 || value > 2) return fail(h, GEM_ERR_INVALID, "fuse_count: 0 (never), 1 (small passes) or 2 (always)"); h->fuse_count = (int)value; }
     else if (k == "sort_chunk")         { if (value != 0 && value != kSortChunkSmall && value != kSortChunkRecords) return fail(h, GEM_ERR_INVALID, "sort_chunk: 0 (by pass), 1024 or 4096"); h->sort_chunk = (int)value; }
     else if (k == "walk_prio")          { if (value < 0 || value > (1 << 30)) return fail(h, GEM_ERR_INVALID, "walk_prio: 0 (off) or a record count"); h->walk_prio = (int)value; }
     else if (k == "blk_batch")          { if (value != 0 && value != 512 && value != 2048) return fail(h, GEM_ERR_INVALID, "blk_batch: 0 (by pass), 512 or 2048"); h->blk_batch = (int)value; }
@@ -2364,6 +2412,8 @@ int gem_debug_get(gem_handle* h, const char* key, long long* out)
     else if (k == "xfer_download_wait_ns") *out = h->xfer_ns[3];
     else if (k == "xfer_download_memcpy_ns") *out = h->xfer_ns[4];
     else if (k == "sort_fallbacks") *out = h->sort_fallbacks;
+    else if (k == "walks_unwaited") *out = h->walks_unwaited;
+    else if (k == "walks_left") *out = h->walks_left;
     else if (k == "step_pending") *out = h->step.valid ? 1 : 0;
     else if (k.rfind("step_", 0) == 0) {
         // time stamps of the LAST finished step of gem_add_sharded_device on W > 1 ranks (recorded while gem_set_timing is on; read

@@ -135,6 +135,8 @@ struct SortArgs {
     unsigned long long* counters;      // optional: [0] += records
     uint32_t* odd_flag; uint32_t epoch; // k_sort_project stores `epoch` here when a record's h or v lies outside the plain range of the walks' chain loops
     int chunk;                         // records per counting-sort chunk of this pass: kSortChunkRecords, or kSortChunkSmall for passes that would not fill the chip otherwise (sort_chunk_for)
+    int fuse_count;                    // 1 (n_passes >= 2, small passes): pass 1's scatter counts pass 2's digit on the way out -- no k_sort_count launch for pass 2;
+                                       // k_sort_project clears the count rows pass 2 can have (gem_capi.cpp: kFuseCountMaxPoints)
 };
 
 // one counting-sort pass over a digit of the key
@@ -152,6 +154,7 @@ struct PassArgs {
     int few_bins;                                // COHERENT ranking: ballots per wave instruction before the LDS way takes over (kFewBins)
     int coherent;                                // coarse digits (block-sorted form): consecutive records mostly share their bin
     int chunk;                                   // records per chunk (SortArgs::chunk)
+    uint32_t* next_cnt; int next_bins, next_shift; uint32_t next_mask;   // SortArgs::fuse_count: the NEXT pass's count table and digit (NULL: that pass counts for itself)
 };
 
 struct WalkArgs {

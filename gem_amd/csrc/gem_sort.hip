@@ -147,6 +147,8 @@ __global__ __launch_bounds__(256, (SRC == 4 ? 4 : (SRC == 2 ? 3 : 1))) void k_so
     for (int i = tid; i < a.dbins[0]; i += NT) hist[i] = 0u;
     btag[tid] = 0xffffffffu; bcnt[tid] = 0u;
     if (chunk == 0 && tid == 0) *a.total = 0u;                         // k_sort_scan of this pass adds the column totals up
+    // fuse_count: pass 1's scatter adds pass 2's counts up with atomics; the rows pass 2 can have (at most n / CH) start from zero
+    if (a.fuse_count && (long long)chunk * CH < a.n) { uint32_t* row = a.cnt[1] + (size_t)chunk * a.dbins[1]; for (int i = tid; i < a.dbins[1]; i += NT) row[i] = 0u; }
     ChunkRange cr = chunk_range<CH>(a.sweep_chunk0, a.sweep_first, a.sweep_orig0, a.n_sweeps, a.n, chunk);
     if (!a.sweep_chunk0) cr.orig0 = a.orig0_single;                    // (a single sweep whose head another device holds)
     // BY VALUE: the stores below may alias the frame table as far as the compiler knows, and a reference would make it reload
@@ -537,12 +539,28 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void k_sort_scatter(PassAr
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const uint32_t j = (uint32_t)(tid + k * NT);
-        if (j < chunk_records) {
-            const uint32_t kk = st_key[j];
-            const uint32_t pos = j + delta[(kk >> a.shift) & a.mask];
+        const bool on = j < chunk_records;
+        uint32_t kk = 0u, pos = 0u;
+        if (on) {
+            kk = st_key[j];
+            pos = j + delta[(kk >> a.shift) & a.mask];
             a.hv_out[pos] = st_hv[j];
             a.key_out[pos] = kk;
             if (ATTR) a.src_out[pos] = st_src[j];
+        }
+        // The NEXT pass's count on the way out (small passes: one launch and one pass over the keys less): the record's place in
+        // the output is its chunk there.  A lane adds for its whole run of neighbours with the same (chunk, digit) -- the records
+        // of a dense tile follow each other here, and a thousand atomics on one word would take a thousand turns at the L2.
+        if (a.next_cnt) {                                              // block-uniform
+            const uint32_t tag = on ? (pos / (uint32_t)CH) * (uint32_t)a.next_bins + ((kk >> a.next_shift) & a.next_mask) : 0xffffffffu;
+            const uint32_t pv = wave_prev(tag);                        // (every lane takes part, see k_sort_count)
+            const bool head = lane == 0 || tag != pv;
+            const uint64_t heads = __ballot(head);
+            if (head && on) {
+                const uint64_t later = lane == 63 ? 0ull : heads >> (lane + 1);
+                const uint32_t run = later ? (uint32_t)__ffsll((unsigned long long)later) : 64u - (uint32_t)lane;
+                __hip_atomic_fetch_add(a.next_cnt + tag, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -1728,7 +1746,10 @@ hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, co
     const bool coherent = a.dshift[0] >= 8 || a.rank_by_ballot;                          // block-sorted form: coarse digits, few bins per wave instruction
     p.coherent = coherent ? 1 : 0;
     p.few_bins = a.few_bins != 0 ? a.few_bins : (a.n_passes > 1 && a.dbits[0] <= 8 ? -1 : kFewBins);
+    const bool fused = a.fuse_count != 0 && a.n_passes >= 2;
+    if (fused) { p.next_cnt = a.cnt[1]; p.next_bins = a.dbins[1]; p.next_shift = a.dshift[1]; p.next_mask = (1u << a.dbits[1]) - 1u; }
     if ((e = launch_pass(st, sh[0], p, attr, coherent, a.n_chunks1, false, ev[2])) != hipSuccess) return e;
+    p.next_cnt = nullptr;
     // ---- the higher digits: count, scan, scatter on the records of the pass before (ping-pong between the arrays); the
     //      live chunks are known on the device only
     const int grid = std::max(1, (int)((a.n + a.chunk - 1) / a.chunk));
@@ -1741,7 +1762,7 @@ hipError_t launch_sort(hipStream_t st, const SortArgs& a, int src, bool attr, co
         p.n_dev = a.total; p.n_host = 0; p.sweep_chunk0 = nullptr; p.sweep_first = nullptr; p.n_sweeps = 1; p.seg_cnt = nullptr;
         p.bin_base = last ? a.bin_base : nullptr; p.counters = last ? a.counters : nullptr;
         p.few_bins = a.few_bins != 0 ? a.few_bins : kFewBins;
-        if ((e = launch_pass(st, sh[i], p, attr, coherent, grid, true, ev[3 * i])) != hipSuccess) return e;
+        if (!(fused && i == 1) && (e = launch_pass(st, sh[i], p, attr, coherent, grid, true, ev[3 * i])) != hipSuccess) return e;
         GEM_LAUNCH(k_sort_scan, dim3((a.dbins[i] + 63) / 64, kScanSegs), dim3(1024), 0, st, ev[3 * i + 1], a.cnt[i], a.segtot[i], a.dbins[i], 0,
                    (const uint32_t*)a.total, (uint32_t*)nullptr, a.chunk);
         if ((e = launch_pass(st, sh[i], p, attr, coherent, grid, false, ev[3 * i + 2])) != hipSuccess) return e;

@@ -60,9 +60,9 @@ def ref_mod():
 PIPELINES = {
     "default": {},                                                                   # the library's own choice per pass
     "cell": {"sort_min_points": 1, "sort_form": 1},                                  # cell-sorted (k_fuse_walk) for every pass, however small
-    "cell3": {"sort_min_points": 1, "sort_form": 1, "sort_passes": 3, "sort_chunk": 4096},               # ... with three counting-sort passes (maps beyond 2^20 cells) and the chunks of 4096 records big passes take (small ones take 1024)
+    "cell3": {"sort_min_points": 1, "sort_form": 1, "sort_passes": 3, "sort_chunk": 4096, "fuse_count": 0},   # ... with three counting-sort passes (maps beyond 2^20 cells), the chunks of 4096 records big passes take (small ones take 1024) and every pass counting for itself (small ones let the first scatter count for the second)
     "block": {"sort_min_points": 1, "sort_form": 2},                                 # block-sorted (k_fuse_block) for every pass
-    "block2": {"sort_min_points": 1, "sort_form": 2, "sort_passes": 2, "blk_batch": 2048, "sort_chunk": 4096},   # ... with two passes (a block's records are found by search) and the rounds of 2048 records that heavy blocks take (small passes take 512)
+    "block2": {"sort_min_points": 1, "sort_form": 2, "sort_passes": 2, "blk_batch": 2048, "sort_chunk": 4096, "fuse_count": 2},   # ... with two passes (a block's records are found by search) and the rounds of 2048 records that heavy blocks take (small passes take 512)
     "cell_ballot": {"sort_min_points": 1, "sort_form": 1, "rank_by_ballot": 1},     # ... ranking by ballot instead of through the LDS: the two must agree (the LDS exchange leans on relaxed atomics staying in program order)
     "generic_laser": {"sort_min_points": 1, "fast_laser": 0},                        # the laser variance with its rotation term (frames that do not qualify for the short form)
     "guarded": {"sort_min_points": 1, "plain_loop": 0, "light_fast": 0},             # the walks' guarded chain loops and k_fuse_block's general rounds everywhere (what blocks / passes with values outside the plain range take)

@@ -1034,3 +1034,48 @@ def test_stream_of_host_sweeps_with_the_uploads_in_flight(oracle_mod):
         if k in (2, 6):
             assert_maps_match(gpu, ref)
     assert_maps_match(gpu, ref)
+
+
+# ---- the sorted pipeline's walk left to the next call (round 5: gem_handle::dwalk) ---------------------------------------------
+@pytest.mark.parametrize("form", [1, 2])
+def test_stream_of_sorted_passes_whose_walks_the_next_call_launches(oracle_mod, form):
+    """Device clouds through the OVERLAPPED sorted pipeline call after call with nothing read in between: every call sorts, leaves its
+    walk to its successor and launches its predecessor's -- clouds of different sizes, single clouds and batches, a variance increment,
+    a small sweep that takes the tile pipeline, a move, and a host array (never deferred) in between; the map is compared at the end
+    and once in the middle.  The same with the deferral switched off must give the same map."""
+    import torch
+    wl = synth.config_c4(n_sweeps=8)
+    knobs = dict(ElevationMap.base_debug or {}); knobs.update({"overlap_min_points": 1})
+    if "sort_form" not in knobs:
+        knobs.update({"sort_min_points": 20000, "sort_form": form})
+    maps = []
+    for defer in (1, 0):
+        gpu, ref = make_pair(oracle_mod, wl.length, wl.resolution)
+        for k, v in dict(knobs, defer_walk=defer).items():
+            gpu.debug_set(k, v)
+        d = [torch.from_numpy(c).to("cuda:0") for c in wl.clouds]
+        sizes = [131072, 60000, 131072, 25000, 131072, 9000, 131072, 100001]
+        for k in range(8):
+            n = sizes[k]
+            if k == 2:
+                gpu.mapvar_update(2e-5); ref.mapvar_update(2e-5)
+            if k == 4:
+                gpu.move(np.array([0.37, -0.21, 0.0])); ref.move(np.array([0.37, -0.21, 0.0]))
+            if k == 6:                                                   # a batch of two sweeps with increments, device-resident
+                cat = torch.cat([d[6][:n], d[7][:sizes[7]]])
+                gpu.add_batch(wl.frames[6:8], cat, np.array([0, n, n + sizes[7]]), wl.var_updates[6:8])
+                for j in (6, 7):
+                    ref.mapvar_update(wl.var_updates[j]); ref.add(wl.frames[j], wl.clouds[j][:sizes[j]])
+                break
+            if k == 3:
+                gpu.add(wl.frames[k], wl.clouds[k][:n])                  # host array: sorted or tiled, its walk is never left behind
+            else:
+                gpu.add(wl.frames[k], d[k][:n].contiguous())
+            ref.add(wl.frames[k], wl.clouds[k][:n])
+            if k == 1:
+                assert_maps_match(gpu, ref)
+        assert_maps_match(gpu, ref)
+        maps.append((gpu.layer("elevation"), gpu.layer("variance"), gpu.debug_get("walks_left")))
+        gpu.close()
+    assert np.array_equal(maps[0][0], maps[1][0]) and np.array_equal(maps[0][1], maps[1][1])
+    assert maps[0][2] >= 4 and maps[1][2] == 0                           # (walks were left to later calls; switched off: none)

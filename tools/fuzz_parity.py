@@ -26,7 +26,8 @@ KNOBS = [{}, {}, {"sort_min_points": 1}, {"sort_min_points": 1, "sort_form": 1},
          {"sort_min_points": 1, "sort_form": 2, "blk_batch": 2048}, {"sort_min_points": 1, "sort_form": 1, "sort_passes": 3},
          {"sort_min_points": 1, "fast_laser": 0}, {"dense_min": 0}, {"sort_min_points": 1, "sort_form": 2, "lane_sort": 0},
          {"sort_min_points": 1, "sort_form": 1, "sort_chunk": 4096}, {"sort_min_points": 1, "sort_form": 2, "sort_chunk": 4096},
-         {"sort_min_points": 1, "sort_form": 2, "sort_passes": 2, "sort_chunk": 1024}]
+         {"sort_min_points": 1, "sort_form": 2, "sort_passes": 2, "sort_chunk": 1024}, {"sort_min_points": 1, "sort_form": 1, "fuse_count": 0},
+         {"sort_min_points": 1, "sort_form": 1, "sort_passes": 3, "fuse_count": 2, "sort_chunk": 4096}, {"sort_min_points": 1, "sort_form": 2, "sort_passes": 2, "fuse_count": 0}]
 
 
 def make_cloud(rng, kind, n, extent, T):
