@@ -25,5 +25,8 @@ timeout -s KILL 100 python tools/dbg/host_c3.py > gpurun_out/final/host_c3.txt 2
 timeout -s KILL 100 python tools/dbg/host_c2.py > gpurun_out/final/host_c2.txt 2>/dev/null
 timeout -s KILL 300 bash tools/profile_host_path.sh $R > gpurun_out/final/prof_host_path.log 2>&1
 timeout -s KILL 60 tools/ubench/bin/handover > gpurun_out/final/ubench_handover.txt 2>/dev/null
+timeout -s KILL 60 tools/ubench/bin/sync > gpurun_out/final/ubench_sync.txt 2>/dev/null
+timeout -s KILL 100 python tools/dbg/sync_cost.py >> gpurun_out/final/ubench_sync.txt 2>/dev/null
+timeout -s KILL 200 python tools/dbg/walk_defer.py > gpurun_out/final/walk_defer.txt 2>/dev/null
 timeout -s KILL 200 python tools/fuzz_parity.py --seconds 150 --seed 9 > gpurun_out/final/fuzz9.log 2>&1; tail -1 gpurun_out/final/fuzz9.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final/smoke.log 2>&1; tail -2 gpurun_out/final/smoke.log
