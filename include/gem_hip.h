@@ -151,7 +151,8 @@ int  gem_add(gem_handle* h, const gem_frame_params* p, int n, const float* xyzi,
  *      any call that returns map data).  The order of operations the caller issues is the order the map sees;
  *      underneath, a stream of single colourless sweeps runs as ONE launch per frame (binning of the new cloud next
  *      to the fusion of the previous frame's records), the newest frame's fusion being launched by the next call
- *      that needs it.                                                                                          */
+ *      that needs it; a cloud big enough for the sorted pipeline (a depth image) likewise leaves its last kernel, the walk
+ *      over its sorted records, to the next call -- which can then launch it without a stream wait.           */
 int  gem_add_device(gem_handle* h, const gem_frame_params* p, int n, const void* d_xyzi,
                     const void* d_rgb, const void* d_orig_index);
 
