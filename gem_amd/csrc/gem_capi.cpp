@@ -965,9 +965,10 @@ int run_sort_pipeline(gem_handle* h, const PassInput& in, int attr, const SortGe
     sa.id_bits = geo.id_bits; sa.n_passes = geo.n_passes;
     for (int i = 0; i < 3; ++i) { sa.dshift[i] = geo.dshift[i]; sa.dbits[i] = geo.dbits[i]; sa.dbins[i] = geo.dbins[i]; }
     sa.n_chunks1 = NC1; sa.chunk = chunk;
-    // Small two-pass sorts (a depth image: 300 k points, six launches of 5-10 us each, the frame bound by them and by the host's
-    // enqueue) let pass 1's scatter count pass 2's digit with atomics: one launch and one pass over the keys less.  Big passes keep
-    // k_sort_count: ten million device-scope atomics cost more than its 8 us (k_sort_project's block counts were 4.4 ns each).
+    // Small two-pass sorts (a depth image: 300 k points, six launches of 5-10 us each) let pass 1's scatter count pass 2's digit with
+    // atomics: one launch and one pass over the keys less (4.7 us of the chip per frame; the frame's period is its walk and does not
+    // move).  Big passes keep k_sort_count: ten million device-scope atomics cost more than its 8 us (k_sort_project's block counts
+    // were 4.4 ns each).
     constexpr long long kFuseCountMaxPoints = 600000;
     sa.fuse_count = (geo.n_passes >= 2 && (h->fuse_count == 2 || (h->fuse_count == 1 && in.n <= kFuseCountMaxPoints))) ? 1 : 0;
     unsigned char* misc = static_cast<unsigned char*>(pb.s_misc.p);
