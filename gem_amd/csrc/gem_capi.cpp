@@ -99,6 +99,7 @@ struct gem_handle {
     // depth images is bound by exactly that chain of walks (C3: 45.7 us per frame = 38 us walk + the hand-over).
     struct DeferredWalk { bool valid = false; WalkArgs wa{}; bool block_form = false; int attr = 0; unsigned slot = 0; } dwalk;
     bool defer_walk = true;             // (debug knob "defer_walk")
+    bool walk_always_wait = false;                  // a walk left to the next call waits for its sort's event even when the host has seen it complete (flush_walk)
     long long walks_unwaited = 0, walks_left = 0;   // walks left to the next call (gem_debug_get "walks_left"); of those, launched without a stream wait ("walks_unwaited")
     bool defer = true;
     hipStream_t bin_stream = nullptr;
@@ -601,7 +602,12 @@ int flush_walk(gem_handle* h)
     if (!h->dwalk.valid) return GEM_OK;
     h->dwalk.valid = false;
     gem_handle::PassBuffers& pb = h->pb[h->dwalk.slot];
-    if (hipEventQuery(pb.bin_done) == hipSuccess) ++h->walks_unwaited;
+    // ORDERING ASSUMPTION (stated, not proven by the API): once hipEventQuery reports bin_done complete, the sort's stores are visible
+    // to a kernel launched afterwards on ANOTHER stream of this device -- bin_done carries no system-scope fence, so this rests on the
+    // release at the end of the sort's last dispatch (L2 write-back of the device's own XCDs) and the acquire at the start of the
+    // walk's, which is what ROCm 7.x does for every kernel boundary.  The "walk_always_wait" knob states the edge instead (5 us of
+    // the walk's stream, profiles/r05_ubench_handover.txt); the soak and tests/test_parity_gpu.py run both.
+    if (!h->walk_always_wait && hipEventQuery(pb.bin_done) == hipSuccess) ++h->walks_unwaited;
     else { (void)hipGetLastError(); GEM_HIP(h, hipStreamWaitEvent(h->stream, pb.bin_done, 0)); }
     {
         Timed t(h, 9);
@@ -609,6 +615,14 @@ int flush_walk(gem_handle* h)
     }
     GEM_HIP(h, hipEventRecord(pb.fuse_done, h->stream)); pb.fuse_recorded = true;
     return GEM_OK;
+}
+
+// Every launch this handle has put off on its OWN stream, oldest first: the walk a sorted pass left to its successor, then the fuse
+// of the newest single sweep.  Whatever fuses, publishes or observes the map calls this (or settle, which does) -- never one of the two alone.
+int flush_local(gem_handle* h)
+{
+    { const int rc = flush_walk(h); if (rc) return rc; }
+    return flush_deferred(h);
 }
 
 // An all-gather of the fused strips still in flight on the gather stream writes the other ranks' strips: whatever observes or
@@ -631,8 +645,7 @@ int ensure_recv(gem_handle* h, int parity, size_t records);
 int settle(gem_handle* h)
 {
     { const int rc = shard_finish_locked(h); if (rc) return rc; }
-    { const int rc = flush_walk(h); if (rc) return rc; }
-    { const int rc = flush_deferred(h); if (rc) return rc; }
+    { const int rc = flush_local(h); if (rc) return rc; }
     return wait_gather(h);
 }
 
@@ -1886,7 +1899,12 @@ int gem_reserve(gem_handle* h, long long max_points, int max_sweeps, int with_co
         // where that is a modest amount: larger ones grow on first use
         constexpr size_t kReserveMax = 64u << 20;
         const size_t a = ((size_t)max_points * 4 + 256) * 9, b = ((size_t)h->cells * 4 + 256) * 9;
-        const size_t want = std::max(a <= kReserveMax ? a : 0, b <= kReserveMax ? b : 0);
+        // the deferred / zero-copy uploads (upload_arrays) keep TWO calls' arrays in the buffer, a half each: gem_fuse's seven arrays
+        // are the largest (28 B per point; gem_add with rgb + orig_index: 24), as long as one call stays below the 16 MB from which
+        // uploads go to the runtime's pageable path
+        const size_t one = ((size_t)max_points * 4 + 256) * 7;
+        const size_t c = one < (16u << 20) ? 2 * one + 512 : 0;
+        const size_t want = std::max(std::max(a <= kReserveMax ? a : 0, b <= kReserveMax ? b : 0), c);
         if (want) (void)host_stage(h, want);
     }
     auto reserve_tables = [&](int sweeps) -> int {                       // the batched calls' tables and their pinned staging copies
@@ -2353,6 +2371,7 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     if (k == "fuse_variant")            { if (value < 10 || value > 12) return fail(h, GEM_ERR_INVALID, "fuse_variant: 10..12"); h->fuse_variant = (int)value; }
     else if (k == "tile_shift")         { if (value != 0 && value != 4 && value != 5) return fail(h, GEM_ERR_INVALID, "tile_shift: 0, 4 or 5"); h->ts = (int)value; }
     else if (k == "defer")              h->defer = value != 0;
+    else if (k == "walk_always_wait")   h->walk_always_wait = value != 0;
     else if (k == "defer_walk")         { const int rcw = flush_walk(h); if (rcw) return rcw; h->defer_walk = value != 0; }
     else if (k == "dense_min")          { if (value < 0 || value > 0xffffffffll) return fail(h, GEM_ERR_INVALID, "dense_min: 0 .. 2^32 - 1"); h->dense_min = (unsigned)value; }
     else if (k == "dbg_sweep")          h->dbg_sweep = (int)value;
@@ -2622,7 +2641,7 @@ int gem_allgather_layers(gem_handle* h, int with_attributes)
         h->step.gather = true; h->step.gather_attrs = with_attributes;
         return GEM_OK;
     }
-    { const int rc = flush_deferred(h); if (rc) return rc; }
+    { const int rc = flush_local(h); if (rc) return rc; }                                 // (a sorted pass's walk left to "the next call": this is the next call)
     if (h->n_pending) { const int rc = flush_pending(h, false); if (rc) return rc; }      // queued increments are part of what the peers get
     return gather_layers_locked(h, with_attributes);
 }
@@ -2727,7 +2746,7 @@ int shard_fuse_locked(gem_handle* h, int n_src, const void* const* d_hv, const v
     SortGeometry geo;
     int rc = shard_checks(h, n_global_sweeps, &geo);
     if (rc) return rc;
-    { const int rcd = flush_deferred(h); if (rcd) return rcd; }
+    { const int rcd = flush_local(h); if (rcd) return rcd; }            // an earlier pass's walk fuses BEFORE this one (the recurrence is order dependent)
     WalkArgs wa{};
     wa.n_src = own ? 1 : std::max(n_src, 2);             // the multi-source form (a single source is followed by an empty one) unless the records are this device's own
     if (own) { wa.hv = own->hv; wa.key = own->key; wa.ranges = own->ranges; }

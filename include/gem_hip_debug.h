@@ -30,7 +30,7 @@ extern "C" {
  *       "light_fast" (0/1: k_fuse_block's rounds of 512 by arrival slots + a per-cell sorting network; 0 = the general rounds),
  *       "cache_tables" (0/1: a batched call whose frames / offsets / increments / map pose equal what a buffer set's device tables were
  *       built from skips building and uploading them), "walk_prio" (0 = off; blocks of at least that many records raise their waves'
- *       issue priority), "sort_chunk" (0 = by the pass's size, 1024 / 4096: records per counting-sort chunk of the sorted pipelines), "defer_walk" (0/1: an overlapped sorted pass of caller-owned device input leaves its walk to the next call, which launches it without a stream wait when its sort has completed), "fuse_count" (0 / 1 / 2: the second pass's counts come from the first pass's scatter never / for passes of up to 600 k points / always), "walk_lds_pad" (bytes of unused LDS per k_fuse_block workgroup: fewer workgroups per CU; an experiment's knob),
+ *       issue priority), "sort_chunk" (0 = by the pass's size, 1024 / 4096: records per counting-sort chunk of the sorted pipelines), "defer_walk" (0/1: an overlapped sorted pass of caller-owned device input leaves its walk to the next call, which launches it without a stream wait when its sort has completed), "walk_always_wait" (0/1: that launch waits for the sort's event on the device even then -- the cross-stream ordering stated rather than assumed), "fuse_count" (0 / 1 / 2: the second pass's counts come from the first pass's scatter never / for passes of up to 600 k points / always), "walk_lds_pad" (bytes of unused LDS per k_fuse_block workgroup: fewer workgroups per CU; an experiment's knob),
  *       "ride_events" (0/1: the sort's last dispatch carries the event the walk waits for, instead of a marker recorded behind it),
  *       "copy_threads" (0 .. 16, default 4: caller-owned HOST arrays travel through the handle's pinned staging buffer, this many threads
  *       -- the caller's and process-wide workers on its CCD -- copying between it and the arrays (csrc/gem_hostcopy.hpp); 0 = the arrays are

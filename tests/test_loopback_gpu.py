@@ -236,6 +236,60 @@ def test_stage_a_row_strips_through_the_loopback(oracle_mod, world, L, res):
         tm.map.close()
 
 
+@pytest.mark.parametrize("entry", ["add_device", "add_batch_device", "shard_fuse"])
+def test_stage_a_gathers_behind_a_walk_left_to_the_next_call(oracle_mod, entry):
+    """ADVICE r5 high + medium: a sorted pass over caller-owned device input leaves its walk to "the next call"
+    (gem_handle::dwalk).  gem_allgather_layers IS that next call: the strip it publishes must hold the newest frame (add_device: one
+    cloud of >= sort_min_points; add_batch_device: a batch of >= sort_min_points_batch, attr == 0 both).  And gem_shard_fuse_device
+    behind such a pass must fuse AFTER the pass's walk (the recurrence is order dependent)."""
+    import torch
+    world, L, res = 2, 256, 0.1
+    f = synth._frame_for(synth.pose_matrix(0.0, 0.0, 0.0), synth.SensorModel.velodyne())
+    big = synth.random_cloud(11, 260000, 0.45 * L * res, z_sigma=0.2, dup_fraction=0.3)
+    small = synth.random_cloud(12, 30000, 0.45 * L * res, z_sigma=0.3, dup_fraction=0.3)
+    maps = make_world(world, L, res, tile_strips=(entry == "shard_fuse"))
+    ref = oracle_mod.OracleMap(L, res)
+    d_big, d_small = torch.from_numpy(big).cuda(), torch.from_numpy(small).cuda()
+    left = [0] * world
+
+    if entry == "add_device":
+        ref.add(f, small); ref.add(f, big)
+    elif entry == "add_batch_device":
+        for _ in range(2):
+            ref.mapvar_update(2e-5); ref.add(f, big)
+    else:
+        ref.add(f, big); ref.add(f, small)
+
+    def rank(r):
+        tm = maps[r]
+        m = tm.map
+        before = m.debug_get("walks_left")
+        if entry == "add_device":
+            tm.add(f, d_small)
+            tm.add(f, d_big)                                                 # cell-sorted, walk left behind
+        elif entry == "add_batch_device":
+            off = np.array([0, big.shape[0], 2 * big.shape[0]])
+            m.add_batch([f, f], torch.cat([d_big, d_big]), off, [2e-5, 2e-5])
+        else:
+            # `small` sorted FIRST (its records copied out of the handle's arenas), then the big pass, whose walk is left behind,
+            # then the fuse of this strip's share of `small`: it must come after that walk
+            pb = m.pack_batch([f], [0, small.shape[0]])
+            rows = tile_strip_rows(L, world)
+            bounds, hv, key = m.shard_sort_tensors(pb, d_small, 0, 1, rows)
+            lo, hi = int(bounds[r]), int(bounds[r + 1])
+            hv, key = hv[lo:hi].clone(), key[lo:hi].clone()
+            m.add(f, d_big)
+            m.shard_fuse_tensors([hv], [key], 1)
+        left[r] = m.debug_get("walks_left") - before
+        tm.allgather()
+        m.synchronize()
+    run_ranks(world, rank)
+    assert all(n >= 1 for n in left), f"no pass left its walk to the next call ({left}): the test does not reach the path"
+    check_all(maps, ref, entry)
+    for tm in maps:
+        tm.map.close()
+
+
 def test_c5_over_eight_loopback_ranks_equals_the_committed_digest(pipeline):
     """BASELINE configs[4] at full size: 10^7 points -> 2400 x 2400 over eight ranks (one device), two steps; after the first, every
     rank's all-gathered map must have the committed digest of the ONE-device map (tests/golden/digests.json c5_full)."""
