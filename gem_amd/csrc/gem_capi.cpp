@@ -531,6 +531,8 @@ void fill_frame(const gem_handle* h, const gem_frame_params* p, FrameConst& f)
         for (int i = 0; i < 3; ++i) ok = ok && small(f.T[4 * i + 3], 1e9f);
         ok = ok && std::isfinite(f.lower) && std::isfinite(f.upper) && std::fabs(f.lower) <= 1e9 && std::fabs(f.upper) <= 1e9;
         ok = ok && small(f.cx, 1e9f) && small(f.cy, 1e9f) && (double)f.L * (double)f.res <= 1e9;
+        // the straight-line binning divides by the resolution through its refined reciprocal (gem_device.hpp, div_binning)
+        ok = ok && f.res >= 9.5367431640625e-7f && f.res <= 1048576.0f && f.L >= 2;
         if (ok) { f.t2 = t2; f.fast_laser = 1; }
     }
 }

@@ -43,7 +43,7 @@ struct FrameConst {
     int    row0, row1;
     // kModelLaserFast (see height_variance): the laser model's constants as floats and the point-independent term of the variance
     float  beam_a, beam_c, t2;
-    int    fast_laser;       // 1: the frame qualifies for kModelLaserFast (fill_frame decides)
+    int    fast_laser;       // 1: the frame qualifies for kModelLaserFast (fill_frame decides: among other things 2^-20 <= res <= 2^20)
 };
 
 constexpr int kModelLaserFast = 4;   // template argument only: the laser model of a frame whose rotation variance is zero
@@ -171,11 +171,48 @@ __device__ __forceinline__ void sensor_variances(const FrameConst& f, float x, f
 // frame that bounds the points it accepts (orthonormal rotation, finite height window: a point inside the map and the window
 // then has |p| < 1e10, so Jq is finite) -- every point that leaves a record gets the reference's variance bit for bit; a
 // frame that does not qualify takes the generic instantiation.
+// sqrtf(x) for x >= 0 as hipcc expands it (v_sqrt_f32, then the two neighbours' residuals pick the correctly rounded value) WITHOUT
+// the expansion's rescaling of tiny arguments: the same operations on the same values -- the same bits -- for x = 0, x = inf, NaN and
+// every x >= 2^-96 (below that the expansion multiplies by 2^32 first: the residual fmas would lose bits); seven instructions
+// instead of fourteen.  A wave that holds a positive x below 2^-96 (a point within 3.5e-15 m of the sensor) takes sqrtf as written.
+__device__ __forceinline__ float sqrt_plain(float x)
+{
+    const bool tiny = (__float_as_uint(x) - 1u) < 0x0f7fffffu;          // 0 < x < 2^-96 (the kernels pass sums of squares: never negative)
+    if (__builtin_expect(__ballot(tiny) != 0, 0)) return sqrtf(x);      // wave-uniform
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+    float r = rm <= 0.0f ? sm : s;
+    r = rp > 0.0f ? sp : r;
+    return r;
+}
+
+// n / d for a divisor d in [2^-20, 2^20] whose refined reciprocal r = rcp_refined(d) is at hand: hipcc expands an IEEE float division
+// into v_div_scale x 2, v_rcp, a Newton step on the reciprocal, the quotient, two residual corrections (the last a v_div_fmas) and
+// v_div_fixup; for 2^-60 <= |n| <= 2^60 the scale factors are 1, v_div_fmas is a plain fma and the fix-up passes the quotient
+// through -- the same operations on the same values, the same bits, in five instructions instead of eleven (fuse_step<true> has
+// the same argument for the Kalman quotients).  OUTSIDE that range of n the result may differ from n / d, but only where the
+// binning cannot tell: |n| < 2^-60 gives |q| < 2^-40 either way, which (float)(L / 2) - q rounds away for L >= 2; |n| > 2^60
+// gives |q| > 2^40, an infinity or a NaN: outside the int range either way (the callers test that before the cast).
+__device__ __forceinline__ float rcp_refined(float d)
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
+}
+__device__ __forceinline__ float div_binning(float n, float d, float r)
+{
+    float q = n * r;
+    float t = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(t, r, q);
+    t = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(t, r, q);
+}
+
 template <int MODEL = -1>
 __device__ __forceinline__ float height_variance(const FrameConst& f, float x, float y, float z, int orig)
 {
     if constexpr (MODEL == kModelLaserFast) {
-        const float d = sqrtf(dot3(x, x, y, y, z, z));                  // GPU:404
+        const float d = sqrt_plain(dot3(x, x, y, y, z, z));             // GPU:404
         const float t = f.beam_c + f.beam_a * d;
         const float vl = t * t;                                         // GPU:407
         return ((f.Js[0] * vl) * f.Js[0] + (f.Js[1] * vl) * f.Js[1]) + f.t2;
@@ -241,7 +278,8 @@ __device__ __forceinline__ bool project_bin_laser_fast(const FrameConst& fc, flo
     const float shx = xt - fc.cx, shy = yt - fc.cy;
     int ix, iy;
     if ((fc.L & 1) == 0) {                                                         // GPU:340-348, even L (map-uniform)
-        const float vx = (float)(fc.L / 2) - shx / fc.res, vy = (float)(fc.L / 2) - shy / fc.res;
+        const float rr = rcp_refined(fc.res);                                      // (frame-uniform: hoisted out of the callers' loops)
+        const float vx = (float)(fc.L / 2) - div_binning(shx, fc.res, rr), vy = (float)(fc.L / 2) - div_binning(shy, fc.res, rr);
         const bool okx = vx > -2147483648.0f && vx < 2147483648.0f, oky = vy > -2147483648.0f && vy < 2147483648.0f;
         ix = okx ? (int)(okx ? vx : 0.0f) : -1;                                    // truncation toward zero; non-finite / unrepresentable -> outside
         iy = oky ? (int)(oky ? vy : 0.0f) : -1;

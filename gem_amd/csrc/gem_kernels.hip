@@ -545,7 +545,6 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
     // ---- the single read of the tile ---------------------------------------------------------------
     float ce[CPT], cs[CPT], lw[CPT];
     float ce0[CPT], cs0[CPT];                                            // as loaded: only cells that changed are written back
-    size_t lgeo[CPT];
     bool  owned[CPT];
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
@@ -563,8 +562,7 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
             // map_lowest is indexed by the GEOGRAPHIC cell (GPU:430 PointsToIndex), not by the circular-buffer cell
             int gr = row - a.start0, gc = col - a.start1;
             gr += gr < 0 ? L : 0; gc += gc < 0 ? L : 0;
-            lgeo[q] = owned[q] ? (size_t)gr * L + gc : 0;
-            if constexpr (MODE == 2) lw[q] = st.lw[q]; else lw[q] = a.lowest[lgeo[q]];
+            if constexpr (MODE == 2) lw[q] = st.lw[q]; else lw[q] = a.lowest[owned[q] ? (size_t)gr * L + gc : 0];
         }
     }
 
@@ -1062,7 +1060,12 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
             // (profiles/r01f_c2_bench.txt).  (A tile resumed by the dense copy of the loop has lost its loaded values: written whole.)
             if (MODE == 2 || __float_as_uint(ce[q]) != __float_as_uint(ce0[q])) a.elevation[g] = ce[q];
             if (MODE == 2 || __float_as_uint(cs[q]) != __float_as_uint(cs0[q])) a.variance[g] = cs[q];
-            if constexpr (LOWEST) a.lowest[lgeo[q]] = lw[q];
+            if constexpr (LOWEST) {
+                // (its geographic address recomputed like g: kept alive from the tile's read it was the value k_frame<4>'s budget spilled)
+                int gr = row_base + (c >> TS) - a.start0, gc = col_base + (c & (TE - 1)) - a.start1;
+                gr += gr < 0 ? L : 0; gc += gc < 0 ? L : 0;
+                a.lowest[(size_t)gr * L + gc] = lw[q];
+            }
         }
     }
     GEM_STAMP();                                                         // 6: stores issued
@@ -1075,8 +1078,20 @@ __device__ __forceinline__ bool fuse_list_body(const FuseArgs& a, int tile, unsi
     return false;
 }
 
+// waves per SIMD the register budget of a k_fuse_list instantiation is set for.  The single-sweep forms fit 128 VGPRs (four waves);
+// the BATCH forms carry the sweep loop's tables and, with colours / lowest scan points, spilled up to 46 VGPRs there (scratch
+// traffic in the middle of the chains): they get the budget of one wave less.  32x32 tiles (maps whose 16x16 descriptor table
+// would exceed 512 MB, or the tile_shift knob) are a fallback: whatever does not spill.  tests/test_code_objects.py holds every
+// kernel of the library to zero VGPR spills.
+constexpr int fuse_list_waves(int TS, int NT, int PB, int FLAGS, bool BATCH)
+{
+    if (TS == 4) return BATCH ? 3 : 4;
+    if (PB > 2048) return (BATCH && NT == 256) ? 1 : 2;
+    return BATCH ? 2 : 4;
+}
+
 template <int TS, int NT, int PB, int ATTR, bool BATCH>
-__global__ __launch_bounds__(NT, ((TS == 4 || PB <= 2048) ? 4 : 2)) void k_fuse_list(FuseArgs a)
+__global__ __launch_bounds__(NT, fuse_list_waves(TS, NT, PB, ATTR, BATCH)) void k_fuse_list(FuseArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
     TileState<(1 << (2 * TS)) / NT> st;

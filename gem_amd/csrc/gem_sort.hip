@@ -154,11 +154,24 @@ __global__ __launch_bounds__(256, (SRC == 4 ? 4 : (SRC == 2 ? 3 : 1))) void k_so
     // BY VALUE: the stores below may alias the frame table as far as the compiler knows, and a reference would make it reload
     // every constant after every store (measured: 105 us instead of 25 for the 32 sweeps of C4)
     const FrameConst fc = a.sweep_chunk0 ? a.frames[cr.sweep] : a.frame0;
-    const long long base = cr.first + (long long)(tid >> 6) * (K * 64) + (tid & 63);
     // The records of a wave's 1024 points are stored COMPACTED at the head of the wave's segment of the chunk, in input order: a
     // point outside the map (or rejected) leaves nothing behind -- on a LiDAR batch that is three points in ten, which pass 1's
     // scatter then neither reads nor ranks.  seg_cnt[chunk][wave] says how many there are.
-    const long long seg0 = cr.first + (long long)(tid >> 6) * (K * 64);
+    // The chunk's arrays through UNIFORM bases (the chunk's first point: scalar registers) and 32-bit byte offsets per lane -- the
+    // loads' and stores' scalar-base form; 64-bit indices cost six VALU instructions per point on address arithmetic alone.
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(1))) char* gbytes_t;
+    typedef const __attribute__((address_space(1))) char* gcbytes_t;
+    typedef const __attribute__((address_space(1))) float4* gf4_t;
+    typedef __attribute__((address_space(1))) uint32_t* gu32_t;
+    typedef __attribute__((address_space(1))) uint2* gu2_t;
+#else
+    typedef char* gbytes_t; typedef const char* gcbytes_t; typedef const float4* gf4_t; typedef uint32_t* gu32_t; typedef uint2* gu2_t;
+#endif
+    const gcbytes_t xyzi_c = (gcbytes_t)(a.xyzi + cr.first);
+    const gbytes_t key_c = (gbytes_t)(a.key_a + cr.first), hv_c = (gbytes_t)(a.hv_a + cr.first), src_c = (gbytes_t)(a.src_a ? a.src_a + cr.first : nullptr);
+    const uint32_t n_here = (uint32_t)(cr.end - cr.first < (long long)CH ? (cr.end > cr.first ? cr.end - cr.first : 0) : CH);   // points of this chunk
+    const uint32_t j_lane = (uint32_t)(tid >> 6) * (uint32_t)(K * 64) + (uint32_t)(tid & 63), j_seg = (uint32_t)(tid >> 6) * (uint32_t)(K * 64);
     const uint64_t lt = lanemask_lt();
     uint32_t kept = 0;                                                 // wave-uniform
     bool odd = false;                                                  // a record outside the plain range of the walks' chain loops (k_fuse_walk)
@@ -170,27 +183,29 @@ __global__ __launch_bounds__(256, (SRC == 4 ? 4 : (SRC == 2 ? 3 : 1))) void k_so
         float4 p[KB];
         if (SRC != 1) {
 #pragma unroll
-            for (int k = 0; k < KB; ++k) { const long long i = base + (k0 + k) * 64; p[k] = a.xyzi[i < cr.end ? i : cr.first]; }
+            for (int k = 0; k < KB; ++k) { const uint32_t j = j_lane + (uint32_t)((k0 + k) * 64); p[k] = *(gf4_t)(xyzi_c + (uint32_t)((j < n_here ? j : 0u) * 16u)); }
         }
 #pragma unroll
         for (int k = 0; k < KB; ++k) {
-            const long long i = base + (k0 + k) * 64;
+            const uint32_t j = j_lane + (uint32_t)((k0 + k) * 64);
+            const bool in_chunk = j < n_here;
+            const long long i = cr.first + (long long)j;               // (only the colour / camera-model paths look at it)
             Binned b; b.valid = false;
             if constexpr (SRC == 4) {
-                b = bin_one_laser_fast(a, fc, p[k], i < cr.end);
+                b = bin_one_laser_fast(a, fc, p[k], in_chunk);
                 if (a.rgb) {                                           // (frame-uniform)
-                    const uint32_t c = a.rgb[i < cr.end ? i : cr.first];
+                    const uint32_t c = a.rgb[in_chunk ? i : cr.first];
                     b.colour_ok = ((c >> 16) & 0xff) != 0 && ((c >> 8) & 0xff) != 0 && (c & 0xff) != 0 && p[k].w != 0.0f;
                 }
-            } else if (i < cr.end) b = bin_one<SRC>(a, fc, SRC != 1 ? p[k] : make_float4(0.f, 0.f, 0.f, 0.f), i, (int)i + cr.orig0);
+            } else if (in_chunk) b = bin_one<SRC>(a, fc, SRC != 1 ? p[k] : make_float4(0.f, 0.f, 0.f, 0.f), i, (int)i + cr.orig0);
             const uint64_t m = __ballot(b.valid);
             const uint32_t bin = (b.id >> d0shift) & d0mask;
             if (b.valid) {
                 if constexpr (SRC != 3) odd = odd | !(fabsf(b.h) <= 268435456.0f) | !(b.v >= 3.7252902984619140625e-9f) | !(b.v <= 268435456.0f);
-                const long long at = seg0 + kept + (uint32_t)__popcll(m & lt);
-                a.key_a[at] = b.id | sweep_bits;
-                a.hv_a[at] = make_uint2(__float_as_uint(b.h), __float_as_uint(b.v));
-                if (a.src_a) a.src_a[at] = (uint32_t)i | (b.colour_ok ? 0x80000000u : 0u);  // source point; bit 31: R, G, B, intensity all non-zero
+                const uint32_t at = j_seg + kept + (uint32_t)__popcll(m & lt);       // slot inside the chunk
+                *(gu32_t)(key_c + (uint32_t)(at * 4u)) = b.id | sweep_bits;
+                *(gu2_t)(hv_c + (uint32_t)(at * 8u)) = make_uint2(__float_as_uint(b.h), __float_as_uint(b.v));
+                if (a.src_a) *(gu32_t)(src_c + (uint32_t)(at * 4u)) = (uint32_t)i | (b.colour_ok ? 0x80000000u : 0u);  // source point; bit 31: R, G, B, intensity all non-zero
             }
             // Histogram.  With a coarse digit (the blocks of the block-sorted form) consecutive points of a scan share their bin, and
             // 64 lanes adding 1 to one LDS word take 64 turns: a lane adds for its whole RUN of equal neighbours instead (the run's
@@ -387,20 +402,32 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 4 : 2)) void k_sort_scatter(PassAr
     if (first >= end && !(a.bin_base && chunk == 0)) return;           // workgroup 0 of the last pass always publishes the bin bases
     for (int i = tid; i < NW * bins; i += NT) wcnt[i] = 0u;
     for (int i = tid; i < NW * 64; i += NT) wpms[i] = 0ull;
-    const long long base = first + (long long)w * (K * 64) + lane;
     // pass 1: the wave's 512 or 1024 positions lie in ONE 1024-slot segment of the chunk, whose first seg_cnt records are there
     // (k_sort_project); the later passes read dense arrays
     uint32_t seg_off = 0, seg_n = 0xffffffffu;
     if (a.seg_cnt) { const uint32_t pos = (uint32_t)(w * (K * 64)); seg_off = pos % (uint32_t)SEG; seg_n = a.seg_cnt[(size_t)chunk * kSortSegsPerChunk + pos / (uint32_t)SEG]; }
     uint2 hv[K]; uint32_t key[K], src[K], rk[K];
+    {
+        // the chunk's records through uniform bases (its first record: scalar registers) and 32-bit byte offsets per lane, see k_sort_project
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef const __attribute__((address_space(1))) char* gcbytes_t;
+        typedef const __attribute__((address_space(1))) uint32_t* gcu32_t;
+        typedef const __attribute__((address_space(1))) uint2* gcu2_t;
+#else
+        typedef const char* gcbytes_t; typedef const uint32_t* gcu32_t; typedef const uint2* gcu2_t;
+#endif
+        const gcbytes_t key_c = (gcbytes_t)(a.key_in + first), hv_c = (gcbytes_t)(a.hv_in + first), src_c = (gcbytes_t)(ATTR ? a.src_in + first : nullptr);
+        const uint32_t n_here = (uint32_t)(end - first < (long long)CH ? (end > first ? end - first : 0) : CH);
+        const uint32_t j0 = (uint32_t)(w * (K * 64) + lane);
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const long long i = base + k * 64;
-        const bool there = i < end && seg_off + (uint32_t)(k * 64 + lane) < seg_n;
-        const long long ic = there ? i : first;
-        key[k] = a.key_in[ic]; hv[k] = a.hv_in[ic];
-        if (ATTR) src[k] = a.src_in[ic];
-        if (!there) key[k] = kKeyInvalid;
+        for (int k = 0; k < K; ++k) {
+            const uint32_t j = j0 + (uint32_t)(k * 64);
+            const bool there = j < n_here && seg_off + (uint32_t)(k * 64 + lane) < seg_n;
+            const uint32_t jc = there ? j : 0u;
+            key[k] = *(gcu32_t)(key_c + (uint32_t)(jc * 4u)); hv[k] = *(gcu2_t)(hv_c + (uint32_t)(jc * 8u));
+            if (ATTR) src[k] = *(gcu32_t)(src_c + (uint32_t)(jc * 4u));
+            if (!there) key[k] = kKeyInvalid;
+        }
     }
     __syncthreads();
     // ---- 1. stable rank inside the wave's share, per-wave counts
@@ -614,6 +641,21 @@ struct SweepReplay {
             if (cur < s + 3u && s + 3u <= last_sw) one(cs, u3, var_floor);
         }
     }
+    // ... when the pass's floor is positive and its increments are not negative (WalkArgs::plain_env): after a lane's first floor the
+    // later ones change nothing and the variance is never the -10 of an empty cell, so a lane's way to the last sweep is ONE floor and
+    // the rounded additions of its sweeps' increments, in order -- three instructions per sweep of the wave's earliest lane instead
+    // of the guarded steps' dozen (every cell of the map lives through every sweep: a batch of 32 sweeps spent an eighth of
+    // k_fuse_block's VALU instructions here)
+    __device__ __forceinline__ void finish_plain(float& cs, uint32_t last_sw, const float* vu, float var_floor)
+    {
+        const uint32_t behind = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_max(0xffffu - cur), 63);
+        const uint32_t s0 = 0xffffu - behind + 1u;                      // the earliest lane's next sweep (wave-uniform)
+        if (s0 > last_sw) return;
+        const float fl = cs < var_floor ? var_floor : cs;
+        cs = cur < last_sw ? fl : cs;
+        for (uint32_t s = s0; s <= last_sw; ++s) { const float c1 = cs + vu[s]; cs = cur < s ? c1 : cs; }
+        cur = cur < last_sw ? last_sw : cur;
+    }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -677,7 +719,7 @@ __global__ __launch_bounds__(kWalkNT) void k_fuse_walk(WalkArgs a)
         gr += gr < 0 ? L : 0; gc += gc < 0 ? L : 0;
         l_t = a.lowest[owned_t ? (size_t)gr * L + gc : 0];
     }
-    if constexpr (HAS_VU) for (int i = tid; i < kWalkMaxSweeps + 8; i += NT) vu[i] = i < a.n_sweeps ? a.var_updates[i] : 0.0f;
+    if constexpr (HAS_VU) for (int i = tid; i < a.n_sweeps + 8; i += NT) vu[i] = i < a.n_sweeps ? a.var_updates[i] : 0.0f;   // (nothing reads past sweep n_sweeps + 3)
 
     // ---- where the cells of this workgroup begin and end in one SOURCE of records sorted by cell id (keys[lo0, hi0) may hold
     //      them): cstart / cend in LDS; false if the source has nothing for these cells.  Block-uniform.
@@ -934,7 +976,7 @@ __global__ __launch_bounds__(kWalkNT) void k_fuse_walk(WalkArgs a)
     }
     if (have) { if (plain) walk_run_plain(a.hv); else walk_run(a.key, a.hv, a.src); }
     if (__ballot(n_total != 0) == 0 && !a.dense) return;               // nothing reached this wave's cells and nothing is pending
-    if constexpr (HAS_VU) rp.finish(cs, last_sw, vu, a.var_floor);
+    if constexpr (HAS_VU) { if (a.plain_env) rp.finish_plain(cs, last_sw, vu, a.var_floor); else rp.finish(cs, last_sw, vu, a.var_floor); }
     if (cs < a.var_floor) cs = a.var_floor;                            // GPU:533-534, on every cell
 
     if (owned) {
@@ -1035,6 +1077,9 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
     // |N1| >= 2^-60 (a cancellation) and at the threshold band.  Anything else takes the loop as it was.
     constexpr bool PLAIN_OK = FLAGS == 0 && !COUNT_SWEEPS;
     constexpr float kPlainHi = 268435456.0f, kPlainLo = 3.7252902984619140625e-9f;      // 2^28, 2^-28
+    // (k_sort_project has looked at every record of THIS device's pass already and says so in one word: then only the cells' states
+    //  are checked here; records that came from other ranks carry no such word)
+    const bool records_plain = !MULTI && a.odd_flag != nullptr && *a.odd_flag != a.epoch;      // block-uniform
     if (tid == 0) { blk_odd = 0u; blk_over = 0u; }
     ccnt[tid] = 0u;
 
@@ -1078,7 +1123,7 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
     bool odd = false;                                                  // this thread has seen a value outside the plain range
     if (tid < 128) phist[tid] = 0u;
     perm[tid] = (uint16_t)tid;
-    if constexpr (HAS_VU) for (int i = tid; i < kWalkMaxSweeps + 8; i += NT) vu[i] = i < a.n_sweeps ? a.var_updates[i] : 0.0f;
+    if constexpr (HAS_VU) for (int i = tid; i < a.n_sweeps + 8; i += NT) vu[i] = i < a.n_sweeps ? a.var_updates[i] : 0.0f;   // (nothing reads past sweep n_sweeps + 3)
 
     // ---- where the block's records are in every source.  One-pass sort: the last pass's bins are the blocks.  Otherwise a
     //      32-ary search, both ends at once (lanes 0-31 look for the first record of the block, lanes 32-63 for the first one
@@ -1351,8 +1396,10 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
                         const uint32_t slot = atomicAdd(&ccnt[cell], 1u);
                         if (slot < (uint32_t)kLightSlots) cslot[cell * kLightSlots + slot] = (uint16_t)j; else over = true;
                         if constexpr (PLAIN_OK) {
-                            const float hh = __uint_as_float(hv[k].x), vv = __uint_as_float(hv[k].y);
-                            odd = odd || !(fabsf(hh) <= kPlainHi) || !(vv >= kPlainLo) || !(vv <= kPlainHi);
+                            if (!records_plain) {
+                                const float hh = __uint_as_float(hv[k].x), vv = __uint_as_float(hv[k].y);
+                                odd = odd || !(fabsf(hh) <= kPlainHi) || !(vv >= kPlainLo) || !(vv <= kPlainHi);
+                            }
                         }
                     }
                 }
@@ -1465,8 +1512,10 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
                 if constexpr (KEYED) st_sw[at] = (uint16_t)(key[k] >> a.id_bits);
                 if constexpr (ATTR != 0) st_src[at] = src[k];
                 if constexpr (PLAIN_OK) {
-                    const float hh = __uint_as_float(hv[k].x), vv = __uint_as_float(hv[k].y);
-                    odd = odd || !(fabsf(hh) <= kPlainHi) || !(vv >= kPlainLo) || !(vv <= kPlainHi);
+                    if (!records_plain) {
+                        const float hh = __uint_as_float(hv[k].x), vv = __uint_as_float(hv[k].y);
+                        odd = odd || !(fabsf(hh) <= kPlainHi) || !(vv >= kPlainLo) || !(vv <= kPlainHi);
+                    }
                 }
             }
         }
@@ -1538,7 +1587,7 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         if (lane == 0) dbg[12 + w] = ((unsigned long long)acc_nmax << 32) | recs;
     }
     if (__ballot(n_total != 0) == 0 && !a.dense) return;               // nothing reached this wave's cells and nothing is pending
-    if constexpr (HAS_VU) rp.finish(cs, last_sw, vu, a.var_floor);
+    if constexpr (HAS_VU) { if (a.plain_env) rp.finish_plain(cs, last_sw, vu, a.var_floor); else rp.finish(cs, last_sw, vu, a.var_floor); }
     if (cs < a.var_floor) cs = a.var_floor;                            // GPU:533-534, on every cell
 
     if (owned) {                                                       // only what changed goes back
