@@ -495,7 +495,7 @@ def c2_variants(emap_cls, dev, torch, reps: int = 400):
     return out
 
 
-def node_host_arrays(emap_cls, dev, reps: int = 40, copy_threads=None):
+def node_host_arrays(emap_cls, dev, reps: int = 40, copy_threads=None, debug=None):
     """The path the UNMODIFIED node drives, with its caller-owned host arrays (never `value`): per frame Mapvar_update, Process_points
     (3 arrays up, 5 down: gpu_process.cu:1096-1141), Fuse (7 arrays up: :1165-1192), Map_feature (nine L x L layers down: :1283-1291)
     and Raytracing, through the C ABI entry points the nine-symbol adapter calls (include/gem/gem_compat_eigen.hpp), arrays
@@ -512,6 +512,8 @@ def node_host_arrays(emap_cls, dev, reps: int = 40, copy_threads=None):
     m.set_lowest_tracking(True)
     if copy_threads is not None:
         m.debug_set("copy_threads", int(copy_threads))
+    for k, v in (debug or {}).items():
+        m.debug_set(k, int(v))
     m.reserve(n, 1, True)                               # (the node's maximum cloud: every arena and the pinned staging sized up front)
     lib, h, P = m._lib, m._h, f.to_struct()
     vp = lambda a: a.ctypes.data_as(C.c_void_p)

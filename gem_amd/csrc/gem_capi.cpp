@@ -157,6 +157,7 @@ struct gem_handle {
     bool   hstage_failed = false;       // an allocation failed: not tried again
     size_t hstage_max = 256u << 20;     // larger transfers go through the runtime
     int    copy_threads = 4;            // the calling thread + 3 workers (gem_debug_set "copy_threads")
+    int    download_groups = 8;         // pieces a download is cut into: the device writes piece g + 1 into the staging buffer while the copy threads move piece g on (gem_debug_set "download_groups")
     hipEvent_t ev_stage[kStageEvents] = {};      // host-visible: a segment's DMA into the staging buffer is done
     hipEvent_t stage_read = nullptr;    // the last DMA OUT of the staging buffer is done (it may be written again)
     bool   stage_read_pending = false;
@@ -445,7 +446,8 @@ int download_arrays(gem_handle* h, const HostXfer* x, int n, size_t stage_off)
     // Eight groups (at least 768 KB each).  Measured alternatives on the 13 MB of Map_feature: two streams taking turns, to hide the
     // ~6 us the link idles at the event between two launches: 322 -> 338 us; few large groups first and small ones last: 322 -> 404 us
     // (the copy threads fall behind on a 5 MB group: 84 -> 54 GB/s).
-    size_t group = std::max<size_t>(768u << 10, (total + 7) / 8);
+    const size_t n_groups = (size_t)std::max(1, std::min(h->download_groups, (int)gem_handle::kStageEvents - 10));     // (nine arrays can add nine part groups)
+    size_t group = std::max<size_t>(n_groups > 8 ? (256u << 10) : (768u << 10), (total + n_groups - 1) / n_groups);
     group = (group + 255) & ~(size_t)255;
     gem::CopySeg segs[gem_handle::kStageEvents][kCopyListMax];
     int nseg[gem_handle::kStageEvents] = {};
@@ -2406,6 +2408,7 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "light_fast")         h->light_fast = value != 0;
     else if (k == "walk_lds_pad")       { if (value < 0 || value > 100 * 1024) return fail(h, GEM_ERR_INVALID, "walk_lds_pad: 0 .. 102400 bytes"); h->walk_lds_pad = (int)value; }
     else if (k == "ride_events")        { if (value < 0 || value > 1) return fail(h, GEM_ERR_INVALID, "ride_events: 0 or 1"); h->ride_events = value != 0; }
+    else if (k == "download_groups")    { if (value < 1 || value > 14) return fail(h, GEM_ERR_INVALID, "download_groups: 1 .. 14"); h->download_groups = (int)value; }
     else if (k == "copy_threads")       { if (value < 0 || value > gem::CopyPool::kMaxThreads) return fail(h, GEM_ERR_INVALID, "copy_threads: 0 (the runtime's pageable path) .. 16"); h->copy_threads = (int)value; }
     else if (k == "fuse_count")         { if (value < 0 || value > 2) return fail(h, GEM_ERR_INVALID, "fuse_count: 0 (never), 1 (small passes) or 2 (always)"); h->fuse_count = (int)value; }
     else if (k == "sort_chunk")         { if (value != 0 && value != kSortChunkSmall && value != kSortChunkRecords) return fail(h, GEM_ERR_INVALID, "sort_chunk: 0 (by pass), 1024 or 4096"); h->sort_chunk = (int)value; }

@@ -136,10 +136,21 @@ __device__ __forceinline__ ChunkRange chunk_range(const int* __restrict__ sweep_
 // ------------------------------------------------------------------------------------------
 // (256-thread workgroups whatever the chunk size: the projection needs ~100 VGPRs, and five light workgroups per CU hide its
 //  load latency better than one of 1024 threads)
+// waves per SIMD the laser-only projection's register budget is set for / point loads a thread keeps in flight.  Round 6, same-box A/B
+// (tools/ab_run.sh, bench_configs c4,c5): 4 waves x 8 loads (128 VGPRs) C5 299.1-299.3 us, 5 x 4: 293.7-297.0, 6 x 2 (80 VGPRs): 287.0-288.6;
+// C4 98.2 / 98.5-98.8 / 97.5-98.3 -- the kernel shares its CUs with the scatter and the walk of the neighbouring passes, and what it
+// gives up in loads in flight per wave it gets back in waves.
+#ifndef GEM_PROJECT_WAVES
+#define GEM_PROJECT_WAVES 6
+#endif
 template <int SRC, int CH>
-__global__ __launch_bounds__(256, (SRC == 4 ? 4 : (SRC == 2 ? 3 : 1))) void k_sort_project(SortArgs a)
+__global__ __launch_bounds__(256, (SRC == 4 ? GEM_PROJECT_WAVES : (SRC == 2 ? 3 : 1))) void k_sort_project(SortArgs a)
 {
-    constexpr int NT = 256, K = CH / NT, KB = K < 8 ? K : 8;           // KB: point loads of a thread in flight together
+#ifndef GEM_PROJECT_KB
+#define GEM_PROJECT_KB 2
+#endif
+    constexpr int KBW = SRC == 4 ? GEM_PROJECT_KB : 8;                // (the other sources keep eight: their budgets are not the laser form's)
+    constexpr int NT = 256, K = CH / NT, KB = K < KBW ? K : KBW;       // KB: point loads of a thread in flight together
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_sort[];
     uint32_t* hist = lds_sort;                                         // [bins0]
     __shared__ uint32_t btag[NT], bcnt[NT];                            // the chunk's records per block, direct-mapped by the block id's low bits (a.blk_cnt)
