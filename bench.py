@@ -637,6 +637,26 @@ def run_c5_distributed(args, torch, dist, world, rank, local_rank, dev):
             ns = emap.debug_get(f"step_{key}_ns")
             phases[key] = None if ns <= -(1 << 60) else ns / 1e3
     emap.set_timing(False)
+    # what this rank's links carried in the last step (the library's own byte counts), priced against xGMI: 7 point-to-point links per
+    # GPU, ~153 GB/s each way at peak (/opt/skills/guides/MI355X_MICROARCH.md); the direct all-gather and the exchange use every link at once
+    links = None
+    if world > 1:
+        XGMI_LINK_GBPS = 153.0
+        g_in, g_out = emap.debug_get("gather_bytes_in"), emap.debug_get("gather_bytes_out")
+        x_in, x_out = emap.debug_get("step_exchange_bytes_in"), emap.debug_get("step_exchange_bytes_out")
+        peers = world - 1
+        per_link_gather = max(g_in, g_out) / peers            # every peer's strip arrives over its own link while ours leaves over the same one
+        per_link_exchange = max(x_in, x_out) / peers
+        links = {"rccl_ranks": world, "peers_per_rank": peers, "xgmi_link_peak_GBps_each_way": XGMI_LINK_GBPS,
+                 "allgather_bytes_in": g_in, "allgather_bytes_out": g_out, "allgather_bytes_per_link": per_link_gather,
+                 "allgather_us_predicted_at_link_peak": per_link_gather / (XGMI_LINK_GBPS * 1e3),
+                 "allgather_us_predicted_at_75pct": per_link_gather / (0.75 * XGMI_LINK_GBPS * 1e3),
+                 "allgather_us_measured": phases.get("gather"),
+                 "exchange_bytes_in": x_in, "exchange_bytes_out": x_out, "exchange_bytes_per_link_mean": per_link_exchange,
+                 "exchange_us_predicted_at_link_peak": per_link_exchange / (XGMI_LINK_GBPS * 1e3),
+                 "exchange_us_measured": phases.get("exchange"),
+                 "note": "rank 0's byte counts of ONE step; a measured time far above the prediction at 75 % of the link peak means the "
+                         "collective is not using the links in parallel (or the ranks do not start it together: compare `phases_us_rank0`)"}
     us_step = 1e6 * elapsed / args.steps
     us_step_nogather = 1e6 * elapsed_nogather / args.steps
     rows = tile_strip_rows(wl.length, world)
@@ -667,6 +687,7 @@ def run_c5_distributed(args, torch, dist, world, rank, local_rank, dev):
                        "points_per_step": n_total, "grid": "2400x2400@0.05m", "parallelism": f"shard{world}+strips{world}", "strip_rows": rows},
             "one_gpu_us_per_step": one["us_per_step"], "speedup_vs_one_gpu": one["us_per_step"] / us_step, "c5_one_gpu": one,
             "value_without_allgather": n_total * args.steps / elapsed_nogather, "us_per_step_without_allgather": us_step_nogather,
+            "xgmi": links,
             "allgather_us": phases.get("gather"), "allgather_bytes_received_per_rank": gathered_bytes if world > 1 else 0.0,
             "allgather_GBps_per_rank": (gathered_bytes / (phases["gather"] * 1e-6) / 1e9) if world > 1 and phases.get("gather") else None,
             "phases_us_rank0": dict(phases, step=us_step,

@@ -16,8 +16,9 @@ CSRC = ROOT / "csrc"
 LIBDIR = ROOT / "lib"
 LIB = LIBDIR / "libgem_hip.so"
 
-SOURCES = [CSRC / "gem_kernels.hip", CSRC / "gem_sort.hip", CSRC / "gem_capi.cpp"]
-HEADERS = [CSRC / "gem_device.hpp", CSRC / "gem_kernels.hpp", CSRC / "gem_wave.hpp", CSRC / "gem_transport.hpp", CSRC / "gem_hostcopy.hpp", ROOT.parent / "include" / "gem_hip_debug.h", ROOT.parent / "include" / "gem_hip.h"]
+SOURCES = [CSRC / "gem_kernels.hip", CSRC / "gem_sort.hip", CSRC / "gem_capi.cpp", CSRC / "gem_capi_core.cpp", CSRC / "gem_capi_pipeline.cpp", CSRC / "gem_capi_comm.cpp"]
+HEADERS = [CSRC / "gem_device.hpp", CSRC / "gem_kernels.hpp", CSRC / "gem_wave.hpp", CSRC / "gem_transport.hpp", CSRC / "gem_hostcopy.hpp", CSRC / "gem_capi_internal.hpp",
+           ROOT.parent / "include" / "gem_hip_debug.h", ROOT.parent / "include" / "gem_hip.h"]
 
 # -ffp-contract=off: cell indices must be bit-exact with the reference arithmetic, so no product+sum
 # may be contracted into an FMA (see csrc/gem_device.hpp).  hipcc's default IEEE divide/sqrt stay on.

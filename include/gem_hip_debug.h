@@ -34,7 +34,8 @@ extern "C" {
  *       "ride_events" (0/1: the sort's last dispatch carries the event the walk waits for, instead of a marker recorded behind it),
  *       "copy_threads" (0 .. 16, default 4: caller-owned HOST arrays travel through the handle's pinned staging buffer, this many threads
  *       -- the caller's and process-wide workers on its CCD -- copying between it and the arrays (csrc/gem_hostcopy.hpp); 0 = the arrays are
- *       handed to the runtime as they are),
+ *       handed to the runtime as they are), "download_groups" (1 .. 14, default 8: pieces a download of caller-owned host arrays is cut into -- the device
+ *       writes piece g + 1 into the staging buffer while the copy threads move piece g on; profiles/r06_download_groups.txt),
  *       "trace" (0/1: one line on stderr per pass of the sorted pipeline), "stream_roles" (a permutation of 0123 as a decimal
  *       number: which of the handle's current own / bin / bin2 / upload streams takes each role; tools/dbg/roles.py).  Returns GEM_ERR_INVALID for an unknown key or a value out of range. */
 int gem_debug_set(gem_handle* h, const char* key, long long value);
@@ -47,7 +48,9 @@ int gem_debug_set(gem_handle* h, const char* key, long long value);
  *            "walks_left" (walks of the sorted pipeline left to the next call) and "walks_unwaited" (those of them launched without a stream wait: their sort had completed),
  *            "step_pending" (1: the second half of a gem_add_sharded_device step is still to come),
  *            "step_exchange_ns", "step_walk_ns", "step_publish_ns", "step_gather_ns", "step_exchange_to_walk_ns": device time stamps of
- *            the last finished multi-rank step (recorded while gem_set_timing is on; read after gem_synchronize; -2^62 = not recorded) */
+ *            the last finished multi-rank step (recorded while gem_set_timing is on; read after gem_synchronize; -2^62 = not recorded),
+ *            "step_exchange_bytes_out", "step_exchange_bytes_in" (bytes of sorted records + block ranges this rank sent / received in its last
+ *            sharded step), "gather_bytes_out", "gather_bytes_in" (... in its last all-gather of the layers): bench.py --gpus N prices them against the links */
 int gem_debug_get(gem_handle* h, const char* key, long long* out);
 
 /* LOOPBACK communicator: nranks handles of THIS process, on ONE device, join the world `world_id` (any number the caller picks,

@@ -61,7 +61,7 @@ def test_the_product_reads_no_environment_variables():
 def test_every_debug_key_is_documented_in_the_debug_header():
     """gem_debug_set / gem_debug_get accept a closed list of keys (gem_capi.cpp); include/gem_hip_debug.h names every one of them."""
     import re
-    src = (ROOT / "gem_amd" / "csrc" / "gem_capi.cpp").read_text()
+    src = "".join((ROOT / "gem_amd" / "csrc" / f).read_text() for f in ("gem_capi.cpp", "gem_capi_core.cpp", "gem_capi_pipeline.cpp", "gem_capi_comm.cpp"))
     hdr = (ROOT / "include" / "gem_hip_debug.h").read_text()
     keys = sorted(set(re.findall(r'k == "([a-z_0-9]+)"', src)))
     assert len(keys) >= 40

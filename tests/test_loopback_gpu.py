@@ -66,7 +66,7 @@ def test_sharded_steps_through_the_loopback(oracle_mod, world, L, res, rotate):
     """Steps of gem_add_sharded_device + gem_allgather_layers on W ranks: uneven strips (L = 75: three tile rows over three ranks;
     L = 96 over eight: five ranks own NOTHING and one sweep of the batch is empty), variance increments, a moved map, two more
     steps into the populated strips without a synchronisation in between.  rotate: the shards' sorts take a pass-buffer set of
-    their own (as big shards do), so the second half of every step is deferred to the next call (gem_capi.cpp)."""
+    their own (as big shards do), so the second half of every step is deferred to the next call (gem_capi_comm.cpp)."""
     import torch
     if L == 600:
         wl = synth.config_c4(n_sweeps=6)
@@ -202,6 +202,8 @@ def test_step_phase_time_stamps(oracle_mod):
         st = tm.map.stats()
         got[r] = {k: tm.map.debug_get(f"step_{k}_ns") for k in ("exchange", "exchange_to_walk", "walk", "publish", "gather")}
         got[r]["launches_walk"] = st["launches_walk"]
+        for k in ("step_exchange_bytes_out", "step_exchange_bytes_in", "gather_bytes_out", "gather_bytes_in"):
+            got[r][k] = tm.map.debug_get(k)
         tm.map.set_timing(False)
     run_ranks(world, rank)
     for r in range(world):
@@ -210,6 +212,10 @@ def test_step_phase_time_stamps(oracle_mod):
             assert got[r][k] > 0, (r, k, got[r])
         for k in ("exchange_to_walk", "publish"):                          # (hand-overs between two hardware queues: recorded; a few us of skew either way)
             assert got[r][k] > -1_000_000, (r, k, got[r])
+    # the byte counts bench.py --gpus N prices against the links: what one rank sends is what the other receives (two ranks), and the
+    # all-gather moves every rank's strip of two layers to its peer
+    assert got[0]["step_exchange_bytes_out"] == got[1]["step_exchange_bytes_in"] > 0 and got[1]["step_exchange_bytes_out"] == got[0]["step_exchange_bytes_in"] > 0, got
+    assert got[0]["gather_bytes_out"] == got[1]["gather_bytes_in"] and got[0]["gather_bytes_out"] + got[1]["gather_bytes_out"] == 8 * L * L, got
     for tm in maps:
         tm.map.close()
 

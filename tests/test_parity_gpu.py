@@ -72,7 +72,7 @@ def test_process_points_nonfinite_inputs(oracle_mod):
                                     (0.25, 0.5), (np.nan, 1.0), (0.0, np.nan), (3.5e38, np.inf)])
 def test_height_window_edges(oracle_mod, bounds):
     """GPU:397 compares (double)h with DOUBLE bounds; the kernels compare h with float bounds chosen on the host so that the
-    decision is the same (gem_capi.cpp fill_frame): heights on either side of each bound, one float apart, on all three paths"""
+    decision is the same (gem_capi_core.cpp fill_frame): heights on either side of each bound, one float apart, on all three paths"""
     lo, hi = bounds
     gpu, ref = make_pair(oracle_mod, 64, 0.1)
     f = synth._frame_for(np.eye(4), SensorModel.velodyne()); f.lower, f.upper = lo, hi
@@ -581,7 +581,7 @@ def test_mixed_fast_and_generic_batches(oracle_mod):
 
 def _laser_frames():
     """Laser frames either side of every condition under which the library takes the short form of the laser variance
-    (gem_capi.cpp: fill_frame): the map it writes must be the oracle's whichever form ran."""
+    (gem_capi_core.cpp: fill_frame): the map it writes must be the oracle's whichever form ran."""
     base = synth.pose_matrix(0.3, -0.2, 0.9, 0.4, 0.05, -0.03)
     out = {}
     out["plain"] = synth._frame_for(base, SensorModel.velodyne())
