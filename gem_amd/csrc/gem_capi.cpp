@@ -156,6 +156,7 @@ int gem_wait_event(gem_handle* h, void* hip_event)
 
 int gem_synchronize(gem_handle* h)
 {
+    ApiRange api_range(h, "gem_synchronize");
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
@@ -177,6 +178,7 @@ int gem_get_pose(gem_handle* h, float out_center[2], int out_start[2])
 // writer), so the reference's two cudaMemcpyFromSymbol round trips per frame disappear.
 int gem_move(gem_handle* h, const float position[3], float out_center[2], int out_start[2], float out_aligned_shift[2])
 {
+    ApiRange api_range(h, "gem_move");
     if (!h || !position) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
@@ -226,6 +228,7 @@ int gem_process_points(gem_handle* h, const gem_frame_params* p, int n, float* x
                        const int* orig_index, int write_back_xyz,
                        int* map_index, float* var, float* x_ts, float* y_ts, float* z_ts)
 {
+    ApiRange api_range(h, "gem_process_points");
     if (!h || !p || n < 0 || (n > 0 && (!x || !y || !z))) return h ? fail(h, GEM_ERR_INVALID, "gem_process_points: bad argument") : GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
@@ -310,6 +313,7 @@ int gem_process_points(gem_handle* h, const gem_frame_params* p, int n, float* x
 int gem_fuse(gem_handle* h, int n, const int* index, const int* R, const int* G, const int* B,
              const float* intensity, const float* height, const float* var)
 {
+    ApiRange api_range(h, "gem_fuse");
     if (!h || n < 0 || (n > 0 && (!index || !height || !var))) return h ? fail(h, GEM_ERR_INVALID, "gem_fuse: bad argument") : GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
@@ -350,6 +354,7 @@ int gem_fuse(gem_handle* h, int n, const int* index, const int* R, const int* G,
 
 int gem_add_device(gem_handle* h, const gem_frame_params* p, int n, const void* d_xyzi, const void* d_rgb, const void* d_orig_index)
 {
+    ApiRange api_range(h, "gem_add_device");
     if (!h || !p || n < 0 || (n > 0 && !d_xyzi)) return h ? fail(h, GEM_ERR_INVALID, "gem_add_device: bad argument") : GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
@@ -361,6 +366,7 @@ int gem_add_device(gem_handle* h, const gem_frame_params* p, int n, const void* 
 
 int gem_add(gem_handle* h, const gem_frame_params* p, int n, const float* xyzi, const uint32_t* rgb, const int* orig_index)
 {
+    ApiRange api_range(h, "gem_add");
     if (!h || !p || n < 0 || (n > 0 && !xyzi)) return h ? fail(h, GEM_ERR_INVALID, "gem_add: bad argument") : GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
@@ -406,6 +412,7 @@ int gem_add(gem_handle* h, const gem_frame_params* p, int n, const float* xyzi, 
 // s + 1 beside the DMA of sweep s -- and fused by ONE batched pass; the caller's arrays have been read when the call returns.
 int gem_add_batch(gem_handle* h, int n_sweeps, const gem_frame_params* params, const float* const* clouds, const int* counts, const float* var_updates)
 {
+    ApiRange api_range(h, "gem_add_batch");
     if (!h || n_sweeps <= 0 || !params || !clouds || !counts) return h ? fail(h, GEM_ERR_INVALID, "gem_add_batch: bad argument") : GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
@@ -452,6 +459,7 @@ int gem_add_batch(gem_handle* h, int n_sweeps, const gem_frame_params* params, c
 int gem_add_aos(gem_handle* h, const gem_frame_params* p, int n, const void* points, int point_step,
                 int off_x, int off_y, int off_z, int off_intensity, int off_rgb)
 {
+    ApiRange api_range(h, "gem_add_aos");
     if (!h || !p || n < 0 || (n > 0 && !points)) return h ? fail(h, GEM_ERR_INVALID, "gem_add_aos: bad argument") : GEM_ERR_INVALID;
     auto field_ok = [&](int o, bool optional) { return (optional && o < 0) || (o >= 0 && (o & 3) == 0 && o + 4 <= point_step); };
     if (point_step < 12 || (point_step & 3) || !field_ok(off_x, false) || !field_ok(off_y, false) || !field_ok(off_z, false) ||
@@ -479,6 +487,7 @@ int gem_add_aos(gem_handle* h, const gem_frame_params* p, int n, const void* poi
 int gem_add_batch_device(gem_handle* h, int n_sweeps, const gem_frame_params* params, const void* d_xyzi,
                          const long long* offsets, const float* var_updates)
 {
+    ApiRange api_range(h, "gem_add_batch_device");
     if (!h || n_sweeps <= 0 || !params || !offsets) return h ? fail(h, GEM_ERR_INVALID, "gem_add_batch_device: bad argument") : GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
@@ -640,6 +649,7 @@ int gem_reserve(gem_handle* h, long long max_points, int max_sweeps, int with_co
 
 int gem_mapvar_update(gem_handle* h, float var_update)
 {
+    ApiRange api_range(h, "gem_mapvar_update");
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
@@ -671,6 +681,7 @@ static void* layer_ptr(gem_handle* h, int layer)
 
 int gem_get_layer(gem_handle* h, int layer, int layout, void* dst_host)
 {
+    ApiRange api_range(h, "gem_get_layer");
     if (!h || !dst_host) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
@@ -765,6 +776,7 @@ int gem_map_closeloop(gem_handle* h, const float update_position[2], float heigh
 int gem_map_feature(gem_handle* h, float* elevation, float* variance, int* colorR, int* colorG, int* colorB,
                     float* rough, float* slope, float* traver, float* intensity)
 {
+    ApiRange api_range(h, "gem_map_feature");
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
@@ -787,6 +799,7 @@ int gem_map_feature(gem_handle* h, float* elevation, float* variance, int* color
 int gem_show(gem_handle* h, double map_length, double resolution, const double position[2],
              float* visual, float* points_xyz, unsigned char* points_rgb, int* out_count, unsigned char* image_bgr)
 {
+    ApiRange api_range(h, "gem_show");
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
@@ -887,6 +900,7 @@ static int colorize_device(gem_handle* h, const gem_camera* cam, int n, float* d
 int gem_colorize_device(gem_handle* h, const gem_camera* cam, int n, float* d_xyzi, const unsigned char* d_image_bgr, size_t row_stride,
                         uint32_t* d_rgb)
 {
+    ApiRange api_range(h, "gem_colorize_device");
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
@@ -895,6 +909,7 @@ int gem_colorize_device(gem_handle* h, const gem_camera* cam, int n, float* d_xy
 
 int gem_colorize(gem_handle* h, const gem_camera* cam, int n, float* xyzi, const unsigned char* image_bgr, size_t row_stride, uint32_t* rgb)
 {
+    ApiRange api_range(h, "gem_colorize");
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
@@ -926,6 +941,7 @@ int gem_set_lowest_tracking(gem_handle* h, int enabled)
 
 int gem_raytracing(gem_handle* h)
 {
+    ApiRange api_range(h, "gem_raytracing");
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
@@ -1028,6 +1044,7 @@ int gem_debug_set(gem_handle* h, const char* key, long long value)
     else if (k == "light_fast")         h->light_fast = value != 0;
     else if (k == "walk_lds_pad")       { if (value < 0 || value > 100 * 1024) return fail(h, GEM_ERR_INVALID, "walk_lds_pad: 0 .. 102400 bytes"); h->walk_lds_pad = (int)value; }
     else if (k == "ride_events")        { if (value < 0 || value > 1) return fail(h, GEM_ERR_INVALID, "ride_events: 0 or 1"); h->ride_events = value != 0; }
+    else if (k == "roctx")              { if (value != 0 && !roctx_load()) return fail(h, GEM_ERR_INVALID, "roctx: no ROCm marker library (librocprofiler-sdk-roctx / libroctx64) to load"); h->roctx = value != 0; }
     else if (k == "download_groups")    { if (value < 1 || value > 14) return fail(h, GEM_ERR_INVALID, "download_groups: 1 .. 14"); h->download_groups = (int)value; }
     else if (k == "copy_threads")       { if (value < 0 || value > gem::CopyPool::kMaxThreads) return fail(h, GEM_ERR_INVALID, "copy_threads: 0 (the runtime's pageable path) .. 16"); h->copy_threads = (int)value; }
     else if (k == "fuse_count")         { if (value < 0 || value > 2) return fail(h, GEM_ERR_INVALID, "fuse_count: 0 (never), 1 (small passes) or 2 (always)"); h->fuse_count = (int)value; }

@@ -151,6 +151,7 @@ extern "C" {
 
 int gem_allgather_layers(gem_handle* h, int with_attributes)
 {
+    ApiRange api_range(h, "gem_allgather_layers");
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     hipSetDevice(h->device);
@@ -242,6 +243,7 @@ int gem_shard_sort_device(gem_handle* h, int n_local_sweeps, const gem_frame_par
                           int first_global_sweep, int n_global_sweeps, int first_point_in_sweep, int nstrips, const int* strip_rows,
                           uint32_t* out_bounds, const void** out_d_hv, const void** out_d_key, const void** out_d_ranges)
 {
+    ApiRange api_range(h, "gem_shard_sort_device");
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     return shard_sort_locked(h, n_local_sweeps, params, d_xyzi, offsets, first_global_sweep, n_global_sweeps, first_point_in_sweep, nstrips, strip_rows,
@@ -436,6 +438,7 @@ extern "C" {
 int gem_shard_fuse_device(gem_handle* h, int n_src, const void* const* d_hv, const void* const* d_key, const uint32_t* counts,
                           const void* const* d_ranges, const uint32_t* bases, int n_global_sweeps, const float* var_updates_global)
 {
+    ApiRange api_range(h, "gem_shard_fuse_device");
     if (!h || n_src <= 0 || n_src > kMaxRanks || !d_hv || !d_key || !counts || n_global_sweeps <= 0 || ((d_ranges == nullptr) != (bases == nullptr)))
         return h ? fail(h, GEM_ERR_INVALID, "gem_shard_fuse_device: bad argument") : GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
@@ -460,6 +463,7 @@ int gem_shard_fuse_device(gem_handle* h, int n_src, const void* const* d_hv, con
 int gem_add_sharded_device(gem_handle* h, int n_local_sweeps, const gem_frame_params* params, const void* d_xyzi, const long long* offsets,
                            int first_global_sweep, int n_global_sweeps, int first_point_in_sweep, const float* var_updates_global)
 {
+    ApiRange api_range(h, "gem_add_sharded_device");
     if (!h) return GEM_ERR_INVALID;
     std::lock_guard<std::mutex> lk(h->mu);
     if (!h->tp_x || !h->tile_strips) return fail(h, GEM_ERR_COMM, "gem_add_sharded_device: gem_comm_init_tiles not called");

@@ -7,9 +7,37 @@
 // stream, and nothing returns to the host unless the caller asks for it.
 #include "gem_capi_internal.hpp"
 
+#include <dlfcn.h>
+
 namespace gemi {
 
 thread_local std::string g_create_error;
+
+namespace {
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)();
+std::once_flag g_roctx_once;
+roctx_push_fn g_roctx_push = nullptr;
+roctx_pop_fn g_roctx_pop = nullptr;
+}
+
+bool roctx_load()
+{
+    std::call_once(g_roctx_once, [] {
+        for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            void* so = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+            if (!so) continue;
+            g_roctx_push = reinterpret_cast<roctx_push_fn>(dlsym(so, "roctxRangePushA"));
+            g_roctx_pop = reinterpret_cast<roctx_pop_fn>(dlsym(so, "roctxRangePop"));
+            if (g_roctx_push && g_roctx_pop) return;
+            g_roctx_push = nullptr; g_roctx_pop = nullptr;
+        }
+    });
+    return g_roctx_push != nullptr;
+}
+void roctx_push(const char* name) { if (g_roctx_push) g_roctx_push(name); }
+void roctx_pop() { if (g_roctx_pop) g_roctx_pop(); }
+ApiRange::ApiRange(const gem_handle* h, const char* name) : on(h && h->roctx && g_roctx_push != nullptr) { if (on) roctx_push(name); }
 
 int fail(gem_handle* h, int code, const char* what, hipError_t e)
 {

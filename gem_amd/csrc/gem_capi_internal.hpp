@@ -108,6 +108,7 @@ struct gem_handle {
     // what the LAST sharded step's exchange and the LAST all-gather moved on this rank, in bytes (gem_debug_get "step_exchange_bytes_out" / "_in",
     // "gather_bytes_out" / "_in"; bench.py --gpus N prices them against the xGMI links)
     long long xbytes_out = 0, xbytes_in = 0, gbytes_out = 0, gbytes_in = 0;
+    bool roctx = false;                             // roctx ranges around the entry points (gem_debug_set "roctx"; ApiRange)
     bool walk_always_wait = false;                  // a walk left to the next call waits for its sort's event even when the host has seen it complete (flush_walk)
     long long walks_unwaited = 0, walks_left = 0;   // walks left to the next call (gem_debug_get "walks_left"); of those, launched without a stream wait ("walks_unwaited")
     bool defer = true;
@@ -249,6 +250,18 @@ struct gem_handle {
 namespace gemi {
 
 int fail(gem_handle* h, int code, const char* what, hipError_t e = hipSuccess);
+
+// Optional roctx ranges around the entry points (tracing): off by default and free when off (one load of a flag);
+// gem_debug_set(h, "roctx", 1) resolves roctxRangePushA / roctxRangePop from the ROCm marker library at run time (the library does
+// not link against it) -- `rocprofv3 --kernel-trace --marker-trace` then shows which call enqueued which kernels.
+bool roctx_load();                                   // true when the marker library was found (process-wide, once)
+void roctx_push(const char* name);
+void roctx_pop();
+struct ApiRange {
+    bool on;
+    ApiRange(const gem_handle* h, const char* name);
+    ~ApiRange() { if (on) roctx_pop(); }
+};
 
 #define GEM_HIP(h, call)                                                        \
     do { hipError_t _e = (call); if (_e != hipSuccess) return fail(h, GEM_ERR_HIP, #call, _e); } while (0)

@@ -36,6 +36,8 @@ extern "C" {
  *       -- the caller's and process-wide workers on its CCD -- copying between it and the arrays (csrc/gem_hostcopy.hpp); 0 = the arrays are
  *       handed to the runtime as they are), "download_groups" (1 .. 14, default 8: pieces a download of caller-owned host arrays is cut into -- the device
  *       writes piece g + 1 into the staging buffer while the copy threads move piece g on; profiles/r06_download_groups.txt),
+ *       "roctx" (0/1: roctx ranges named after the entry points around every call that enqueues or transfers -- the marker library is
+ *       loaded at run time, GEM_ERR_INVALID if there is none; `rocprofv3 --kernel-trace --marker-trace` shows them beside the kernels),
  *       "trace" (0/1: one line on stderr per pass of the sorted pipeline), "stream_roles" (a permutation of 0123 as a decimal
  *       number: which of the handle's current own / bin / bin2 / upload streams takes each role; tools/dbg/roles.py).  Returns GEM_ERR_INVALID for an unknown key or a value out of range. */
 int gem_debug_set(gem_handle* h, const char* key, long long value);

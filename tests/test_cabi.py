@@ -297,3 +297,25 @@ def test_cpp_header_host_math_matches_the_references_code(lib, tmp_path):
     assert res.returncode == 0, res.stderr
     run = subprocess.run([str(exe), str(motion), str(sensors)], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0 and run.stdout.strip().endswith("ok"), run.stdout + run.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.one_pipeline
+def test_roctx_ranges_around_the_entry_points(oracle_mod):
+    """SURVEY section 5 (tracing): gem_debug_set "roctx" loads the ROCm marker library at run time and wraps the entry points in ranges;
+    the map is what it is without them, and switching them off again works.  (What a profiler shows: profiles/r06_roctx_trace.txt.)"""
+    import numpy as np
+    import torch
+    from gem_amd import ElevationMap, synth
+    wl = synth.config_c1()
+    ref = oracle_mod.OracleMap(wl.length, wl.resolution)
+    m = ElevationMap(wl.length, wl.resolution)
+    m.debug_set("roctx", 1)
+    d = torch.from_numpy(wl.clouds[0]).cuda()
+    for _ in range(2):
+        m.mapvar_update(1e-5); ref.mapvar_update(1e-5)
+        m.add(wl.frames[0], d); ref.add(wl.frames[0], wl.clouds[0])
+    m.debug_set("roctx", 0)
+    m.add(wl.frames[0], d); ref.add(wl.frames[0], wl.clouds[0])
+    assert np.array_equal(m.layer("elevation"), ref.layer("elevation")) and np.array_equal(m.layer("variance"), ref.layer("variance"))
+    m.close()
