@@ -269,8 +269,19 @@ class ElevationMap:
     def set_stream(self, hip_stream: Optional[int]) -> None:
         self._check(self._lib.gem_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None), "gem_set_stream")
 
+    def _hold(self, *tensors) -> None:
+        """gem_add_device / gem_add_batch_device only ENQUEUE: the caller's device buffers must stay untouched until gem_synchronize
+        (include/gem_hip.h).  A torch tensor that goes out of scope returns its memory to the caching allocator, which hands it to the
+        next `.cuda()` at once -- on torch's stream, which knows nothing of the handle's streams.  So the Python twin keeps a reference
+        to every device input until the handle is synchronised (tools/fuzz_parity.py passes temporaries; round 6 found that scenario)."""
+        self._held = getattr(self, "_held", [])
+        self._held.extend(t for t in tensors if t is not None)
+        if len(self._held) > 256:
+            self.synchronize()
+
     def synchronize(self) -> None:
         self._check(self._lib.gem_synchronize(self._h), "gem_synchronize")
+        self._held = []                              # (the device inputs of the calls so far have been read)
 
     def wait_event(self, hip_event) -> None:
         """Everything enqueued from now on waits (on the device) for this event -- a hipEvent_t handle, or a torch.cuda.Event that
@@ -324,6 +335,7 @@ class ElevationMap:
                 raise ValueError("xyzi must be a contiguous float32 [N,4] device tensor")
             dp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
             self._check(self._lib.gem_add_device(self._h, C.byref(p), n, dp(xyzi), dp(rgb), dp(orig_index)), "gem_add_device")
+            self._hold(xyzi, rgb, orig_index)
             return
         a = np.ascontiguousarray(xyzi, np.float32).reshape(-1, 4)
         n = a.shape[0]
@@ -359,6 +371,7 @@ class ElevationMap:
             raise ValueError("add_batch takes a device-resident float32 [N,4] tensor")
         self._check(self._lib.gem_add_batch_device(self._h, pb.n, pb.frames, C.c_void_p(xyzi_device.data_ptr()), pb.offsets,
                                                    pb.var_updates), "gem_add_batch_device")
+        self._hold(xyzi_device)
 
     def add_batch_host(self, frames, clouds, var_updates=None) -> None:
         """The same from HOST memory (gem_add_batch): `clouds` is a sequence of float32 [n_s, 4] numpy arrays, one per
@@ -481,6 +494,7 @@ class ElevationMap:
         is_int = lid in _INT_LAYERS and layout == _lib.LAYOUT_STORAGE_ROWMAJOR
         out = np.empty((self.length, self.length), np.int32 if is_int else np.float32)
         self._check(self._lib.gem_get_layer(self._h, lid, layout, out.ctypes.data_as(C.c_void_p)), "gem_get_layer")
+        self._held = []                              # (a call that returns map data has everything before it behind it)
         if layout == _lib.LAYOUT_GRIDMAP_COLMAJOR_NAN:
             return out.T          # buffer holds column-major data: view it as [row, col]
         return out

@@ -101,6 +101,55 @@ def test_height_window_edges(oracle_mod, bounds):
     assert_maps_match(gpu, ref)
 
 
+@pytest.mark.parametrize("beam_c", [0.0015, 0.0])
+@pytest.mark.parametrize("pose", ["identity", "shifted"])
+def test_straight_line_projection_on_adversarial_points(oracle_mod, pose, beam_c):
+    """Round 6: the laser-only straight-line projection (gem_device.hpp project_bin_laser_fast) takes sqrtf and the two binning
+    divisions WITHOUT their rescaling preambles (sqrt_plain, div_binning).  The ranges they are proven for have edges: a sum of squares
+    of exactly 0 (LiDARs report (0, 0, 0) for no return), positive but below 2^-96 (the wave falls back to sqrtf), denormal; a shift from
+    the map centre of exactly 0, below 2^-60, beyond 2^60, infinite, NaN.  Every one of them through gem_add (tile pipeline, and the
+    sorted forms by the pipeline fixture) on a map the fast form qualifies for; beam_c = 0 makes the variance a pure function of the
+    square root, so a wrong root near zero shows."""
+    L, res = 64, 0.1
+    gpu, ref = make_pair(oracle_mod, L, res)
+    model = SensorModel(_lib_model_laser(), (0.018, 0.0006, beam_c), 5.0, -5.0)
+    T = np.eye(4)
+    if pose == "shifted":
+        T = synth.pose_matrix(0.25, -0.15, 0.3, 0.4, 0.01, -0.02)
+        for m in (gpu, ref):
+            m.move([0.25, -0.15, 0.0])                              # the sensor stands on the map centre: shifts of exactly 0
+    f = synth._frame_for(T, model)
+    tiny = [0.0, -0.0, 1e-45, 1e-40, 1e-30, 3e-20, 1e-19, 2.8e-15, 1e-10]
+    pts = []
+    for a in tiny:
+        for b in (0.0, 1e-30, a):
+            pts += [(a, b, 0.0), (b, a, -a), (-a, 0.0, b), (a, a, a)]
+    edges = [3.15, 3.1999998, 3.2, 3.2000003, -3.1999998, -3.2, -3.2000003, 0.05, 0.049999997, 0.1, -0.1, 0.15000001]
+    pts += [(x, y, 0.01 * k) for k, x in enumerate(edges) for y in (0.0, 0.05, -3.2, 3.1999998)]
+    huge = [1e10, -1e10, 1.2e18, 2e19, 3e30, 3.4e38, np.inf, -np.inf, np.nan]
+    pts += [(h, 0.3, 0.1) for h in huge] + [(0.3, h, 0.1) for h in huge] + [(0.3, 0.2, h) for h in huge[:4]] + [(h, h, 0.0) for h in huge]
+    rng = np.random.default_rng(7)
+    pts += [tuple(v) for v in rng.uniform(-3.3, 3.3, (400, 3)) * np.array([1.0, 1.0, 0.1])]
+    c = np.array([p + (1.0,) for p in pts], F32)
+    c = np.concatenate([c, c[::-1]])                                 # every cell twice, in the other order the second time
+    with np.errstate(all="ignore"):
+        for _ in range(2):
+            gpu.add(f, c); ref.add(f, c)
+    assert int((ref.layer("elevation") != -10).sum()) > 200
+    assert_maps_match(gpu, ref)
+    import torch
+    with np.errstate(all="ignore"):
+        gpu.add_batch([f, f], torch.from_numpy(np.concatenate([c, c])).cuda(), np.array([0, len(c), 2 * len(c)]), [1e-6, 2e-6])
+        for u in (1e-6, 2e-6):
+            ref.mapvar_update(u); ref.add(f, c)
+    assert_maps_match(gpu, ref)
+
+
+def _lib_model_laser():
+    from gem_amd import _lib
+    return _lib.MODEL_LASER
+
+
 @pytest.mark.parametrize("model", ["structured_light", "stereo", "perfect"])
 def test_other_noise_models(oracle_mod, model):
     gpu, ref = make_pair(oracle_mod, 400, 0.025)

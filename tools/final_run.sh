@@ -1,9 +1,9 @@
 #!/bin/bash
 # One consolidated validation / evidence run on the MI355X box (through gpurun): the GPU suite, the contract bench, every configuration,
 # the rocprofv3 summaries per configuration, the soak.  Outputs under gpurun_out/ (copy what should be judged into profiles/).
-#   tools/final_run.sh [tag, default r05] [skip the GPU suite: nosuite]
+#   tools/final_run.sh [tag, default r06] [skip the GPU suite: nosuite]
 set -u
-R=${1:-r05}
+R=${1:-r06}
 mkdir -p gpurun_out/final
 if [ "${2:-}" != nosuite ]; then
 timeout -s KILL 1100 python -m pytest tests -m gpu -x -q > gpurun_out/final/pytest_gpu.log 2>&1; tail -3 gpurun_out/final/pytest_gpu.log
@@ -28,5 +28,7 @@ timeout -s KILL 60 tools/ubench/bin/handover > gpurun_out/final/ubench_handover.
 timeout -s KILL 60 tools/ubench/bin/sync > gpurun_out/final/ubench_sync.txt 2>/dev/null
 timeout -s KILL 100 python tools/dbg/sync_cost.py >> gpurun_out/final/ubench_sync.txt 2>/dev/null
 timeout -s KILL 200 python tools/dbg/walk_defer.py > gpurun_out/final/walk_defer.txt 2>/dev/null
+timeout -s KILL 100 bash tools/roctx_trace.sh $R > gpurun_out/final/roctx_trace.log 2>&1
+timeout -s KILL 200 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/final/bench_driver_style.json 2>/dev/null; cut -c1-200 gpurun_out/final/bench_driver_style.json
 timeout -s KILL 200 python tools/fuzz_parity.py --seconds 150 --seed 9 > gpurun_out/final/fuzz9.log 2>&1; tail -1 gpurun_out/final/fuzz9.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final/smoke.log 2>&1; tail -2 gpurun_out/final/smoke.log
