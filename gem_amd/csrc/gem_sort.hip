@@ -943,7 +943,14 @@ __global__ __launch_bounds__(kWalkNT) void k_fuse_walk(WalkArgs a)
         auto step = [&](uint32_t idx, uint32_t hb, uint32_t vb) {
             const bool live = idx < n;
             const float h = __uint_as_float(hb), v = __uint_as_float(vb);
-            const float sf = cs < fl_ ? fl_ : cs;                              // GPU:500-501
+            // GPU:500-501.  ONE v_max_f32 on the chain's critical path instead of a compare and a select: the plain loop never sees a
+            // NaN state (state_ok above; in-range arithmetic makes none), which is the only value the two forms treat differently
+            float sf;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm("v_max_f32 %0, %1, %2" : "=v"(sf) : "v"(cs), "v"(fl_));
+#else
+            sf = cs < fl_ ? fl_ : cs;
+#endif
             const float m = fabsf(h - ce) * __builtin_amdgcn_rsqf(sf);         // GPU:502, see fuse_step
             const float D = sf + v;                                            // GPU:518, 519
             v2f N; N.x = sf * h + v * ce; N.y = v * sf;
@@ -1308,6 +1315,7 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         const float h = __uint_as_float(r.x), v = __uint_as_float(r.y);
         bool rare = false;
         uint32_t sw = 0;
+        float sf_vu = 0.0f;
         if constexpr (HAS_VU) {
             // Between two records of sweeps s < t the cell lives through (t - s) x {floor (GPU:533-534); next sweep's increment
             // (GPU:540-547)}.  The floor is positive, so a floored variance is never the -10 of an empty cell and the increment
@@ -1318,17 +1326,33 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
             // branch per sweep of the widest gap in the wave -- was a third of its step.)
             sw = live ? swr : rp.cur;
             const uint32_t gap = sw - rp.cur;
-            const float c1 = (cs < fl_ ? fl_ : cs) + un1;
-            cs = gap >= 1u ? c1 : cs;
-            const float c2 = cs + un2;
-            cs = gap >= 2u ? c2 : cs;
-            const float c3 = cs + un3;
-            cs = gap >= 3u ? c3 : cs;
+            // The chain's critical path: the three candidate sums from the FLOORED variance without a select in between (the same
+            // additions in the same order: bit-identical), one select tree at the end, and the step's floored variance sf straight
+            // from it -- max(cs', floor) is cs' once an increment has been added to a floored value, and the floored value itself
+            // otherwise.  Six dependent operations from cs to sf instead of nine.
+            float cf;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm("v_max_f32 %0, %1, %2" : "=v"(cf) : "v"(cs), "v"(fl_));    // (one v_max_f32: no NaN state in the plain loop, see k_fuse_walk)
+#else
+            cf = cs < fl_ ? fl_ : cs;
+#endif
+            const float a1 = cf + un1, a2 = a1 + un2, a3 = a2 + un3;
+            const float tg = gap >= 3u ? a3 : (gap >= 2u ? a2 : a1);
+            cs = gap >= 1u ? tg : cs;                                      // (what the cell's variance is now: off the critical path)
+            sf_vu = gap >= 1u ? tg : cf;
             rp.cur += min(gap, 3u);
             rare = gap > 3u;
             un1 = vu[rp.cur + 1u]; un2 = vu[rp.cur + 2u]; un3 = vu[rp.cur + 3u];
         }
-        const float sf = cs < fl_ ? fl_ : cs;                              // GPU:500-501
+        float sf;                                                          // GPU:500-501
+        if constexpr (HAS_VU) sf = sf_vu;
+        else {
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm("v_max_f32 %0, %1, %2" : "=v"(sf) : "v"(cs), "v"(fl_));    // (see above)
+#else
+            sf = cs < fl_ ? fl_ : cs;
+#endif
+        }
         const float m = fabsf(h - ce) * __builtin_amdgcn_rsqf(sf);         // GPU:502, see fuse_step
         const float D = sf + v;                                            // GPU:518, 519
         v2f N; N.x = sf * h + v * ce; N.y = v * sf;
@@ -1344,6 +1368,9 @@ __global__ __launch_bounds__(kBlkNT) void k_fuse_block(WalkArgs a)
         q = __builtin_elementwise_fma(t, rr2, q);
         const bool outlier = m > thr_;
         const bool replace = (ce == kEmptyElevation) | (outlier & (ce < h));   // GPU:484-486, 505-507
+        // (tried and dropped, round 6, both bit-identical: ONE select behind the quotients with the alternatives picked beforehand --
+        //  the compiler's schedule got worse, C3's walk 37.8 -> 38.6 us, C4 95.2-96.9 -> 97.1-97.5; lanes without a record sent down
+        //  the outlier's way instead of a select on `live` -- nothing, 37.2-37.8 / 95.9-96.7)
         float e2 = replace ? h : (outlier ? ce : q.x);
         float s2 = replace ? v : (outlier ? sf : q.y);
         if (__builtin_expect(__ballot(rare) != 0, 0)) {                    // wave-uniform: the step as the guarded loop takes it
