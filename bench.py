@@ -637,26 +637,8 @@ def run_c5_distributed(args, torch, dist, world, rank, local_rank, dev):
             ns = emap.debug_get(f"step_{key}_ns")
             phases[key] = None if ns <= -(1 << 60) else ns / 1e3
     emap.set_timing(False)
-    # what this rank's links carried in the last step (the library's own byte counts), priced against xGMI: 7 point-to-point links per
-    # GPU, ~153 GB/s each way at peak (/opt/skills/guides/MI355X_MICROARCH.md); the direct all-gather and the exchange use every link at once
-    links = None
-    if world > 1:
-        XGMI_LINK_GBPS = 153.0
-        g_in, g_out = emap.debug_get("gather_bytes_in"), emap.debug_get("gather_bytes_out")
-        x_in, x_out = emap.debug_get("step_exchange_bytes_in"), emap.debug_get("step_exchange_bytes_out")
-        peers = world - 1
-        per_link_gather = max(g_in, g_out) / peers            # every peer's strip arrives over its own link while ours leaves over the same one
-        per_link_exchange = max(x_in, x_out) / peers
-        links = {"rccl_ranks": world, "peers_per_rank": peers, "xgmi_link_peak_GBps_each_way": XGMI_LINK_GBPS,
-                 "allgather_bytes_in": g_in, "allgather_bytes_out": g_out, "allgather_bytes_per_link": per_link_gather,
-                 "allgather_us_predicted_at_link_peak": per_link_gather / (XGMI_LINK_GBPS * 1e3),
-                 "allgather_us_predicted_at_75pct": per_link_gather / (0.75 * XGMI_LINK_GBPS * 1e3),
-                 "allgather_us_measured": phases.get("gather"),
-                 "exchange_bytes_in": x_in, "exchange_bytes_out": x_out, "exchange_bytes_per_link_mean": per_link_exchange,
-                 "exchange_us_predicted_at_link_peak": per_link_exchange / (XGMI_LINK_GBPS * 1e3),
-                 "exchange_us_measured": phases.get("exchange"),
-                 "note": "rank 0's byte counts of ONE step; a measured time far above the prediction at 75 % of the link peak means the "
-                         "collective is not using the links in parallel (or the ranks do not start it together: compare `phases_us_rank0`)"}
+    links = xgmi_summary(world, {k: emap.debug_get(k) for k in ("gather_bytes_in", "gather_bytes_out", "step_exchange_bytes_in", "step_exchange_bytes_out")},
+                         phases) if world > 1 else None
     us_step = 1e6 * elapsed / args.steps
     us_step_nogather = 1e6 * elapsed_nogather / args.steps
     rows = tile_strip_rows(wl.length, world)
@@ -703,6 +685,27 @@ def run_c5_distributed(args, torch, dist, world, rank, local_rank, dev):
         if cpu is not None:
             out["cpu_baseline"] = cpu
     return out
+
+
+def xgmi_summary(world: int, counts: dict, phases: dict):
+    """What rank 0's links carried in ONE step (the library's own byte counts, gem_debug_get), priced against xGMI: 7 point-to-point
+    links per GPU, ~153 GB/s each way at peak (/opt/skills/guides/MI355X_MICROARCH.md); the direct all-gather and the exchange use every
+    link at once.  Pure arithmetic (tests/test_bench_contract.py runs it without a GPU)."""
+    XGMI_LINK_GBPS = 153.0
+    peers = max(world - 1, 1)
+    g_in, g_out = int(counts.get("gather_bytes_in", 0)), int(counts.get("gather_bytes_out", 0))
+    x_in, x_out = int(counts.get("step_exchange_bytes_in", 0)), int(counts.get("step_exchange_bytes_out", 0))
+    per_link_gather = max(g_in, g_out) / peers                # every peer's strip arrives over its own link while ours leaves over the same one
+    per_link_exchange = max(x_in, x_out) / peers
+    us = lambda b, frac=1.0: b / (frac * XGMI_LINK_GBPS * 1e3)
+    return {"rccl_ranks": world, "peers_per_rank": world - 1, "xgmi_link_peak_GBps_each_way": XGMI_LINK_GBPS,
+            "allgather_bytes_in": g_in, "allgather_bytes_out": g_out, "allgather_bytes_per_link": per_link_gather,
+            "allgather_us_predicted_at_link_peak": us(per_link_gather), "allgather_us_predicted_at_75pct": us(per_link_gather, 0.75),
+            "allgather_us_measured": phases.get("gather"),
+            "exchange_bytes_in": x_in, "exchange_bytes_out": x_out, "exchange_bytes_per_link_mean": per_link_exchange,
+            "exchange_us_predicted_at_link_peak": us(per_link_exchange), "exchange_us_measured": phases.get("exchange"),
+            "note": "rank 0's byte counts of ONE step; a measured time far above the prediction at 75 % of the link peak means the collective "
+                    "is not using the links in parallel (or the ranks do not start it together: compare `phases_us_rank0`)"}
 
 
 def cpu_baseline_c5(wl, cat, off, budget_s: float):

@@ -274,14 +274,18 @@ class ElevationMap:
         (include/gem_hip.h).  A torch tensor that goes out of scope returns its memory to the caching allocator, which hands it to the
         next `.cuda()` at once -- on torch's stream, which knows nothing of the handle's streams.  So the Python twin keeps a reference
         to every device input until the handle is synchronised (tools/fuzz_parity.py passes temporaries; round 6 found that scenario)."""
-        self._held = getattr(self, "_held", [])
-        self._held.extend(t for t in tensors if t is not None)
-        if len(self._held) > 256:
+        held = getattr(self, "_held", None)
+        if not isinstance(held, dict):
+            held = self._held = {}
+        for t in tensors:
+            if t is not None:
+                held[id(t)] = t                      # (a stream that cycles through the same few tensors holds each once)
+        if len(held) > 256:
             self.synchronize()
 
     def synchronize(self) -> None:
         self._check(self._lib.gem_synchronize(self._h), "gem_synchronize")
-        self._held = []                              # (the device inputs of the calls so far have been read)
+        self._held = {}                              # (the device inputs of the calls so far have been read)
 
     def wait_event(self, hip_event) -> None:
         """Everything enqueued from now on waits (on the device) for this event -- a hipEvent_t handle, or a torch.cuda.Event that
@@ -494,7 +498,7 @@ class ElevationMap:
         is_int = lid in _INT_LAYERS and layout == _lib.LAYOUT_STORAGE_ROWMAJOR
         out = np.empty((self.length, self.length), np.int32 if is_int else np.float32)
         self._check(self._lib.gem_get_layer(self._h, lid, layout, out.ctypes.data_as(C.c_void_p)), "gem_get_layer")
-        self._held = []                              # (a call that returns map data has everything before it behind it)
+        self._held = {}                              # (a call that returns map data has everything before it behind it)
         if layout == _lib.LAYOUT_GRIDMAP_COLMAJOR_NAN:
             return out.T          # buffer holds column-major data: view it as [row, col]
         return out

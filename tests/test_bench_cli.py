@@ -20,3 +20,22 @@ def test_gpus_must_match_world_size():
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
     assert r.stdout.strip() == ""
+
+
+def test_xgmi_summary_of_the_multi_rank_line():
+    """The block `bench.py --gpus N` adds to its line for N > 1 (VERDICT r5 #6b) is plain arithmetic on the library's byte counts: run it
+    here, where there is no second device to run the rest on -- a typo in it would cost the first real 8-GPU run its line."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("gem_bench", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    strip = 300 * 2400 * 4 * 2                                # one rank's strip of C5 over eight ranks: elevation + variance
+    x = bench.xgmi_summary(8, {"gather_bytes_in": 7 * strip, "gather_bytes_out": 7 * strip,
+                               "step_exchange_bytes_in": 9_000_000, "step_exchange_bytes_out": 8_700_000}, {"gather": 70.0, "exchange": 40.0})
+    json.dumps(x)
+    assert x["rccl_ranks"] == 8 and x["peers_per_rank"] == 7 and x["allgather_bytes_per_link"] == strip
+    assert abs(x["allgather_us_predicted_at_link_peak"] - strip / 153e3) < 1e-9 and x["allgather_us_predicted_at_75pct"] > x["allgather_us_predicted_at_link_peak"]
+    assert x["allgather_us_measured"] == 70.0 and x["exchange_us_measured"] == 40.0
+    two = bench.xgmi_summary(2, {}, {})                       # (a line without counts still forms)
+    assert two["peers_per_rank"] == 1 and two["allgather_bytes_per_link"] == 0 and two["allgather_us_measured"] is None
